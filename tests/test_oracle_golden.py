@@ -1,0 +1,115 @@
+"""Pin the oracle: box_oracle.py must reproduce, BIT FOR BIT, what the reference's own
+odtk/box.py produced for the committed fixtures (tests/golden/*.npz, made by oracle/gen_golden.py
+from /root/reference), and -- when the reference tree is present (build container) -- what it
+produces live on fresh seeded inputs."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import box_oracle, ref_loader
+from odtk import synthetic
+
+RATIOS = [1.0, 2.0, 0.5]
+SCALES = [4 * 2 ** (i / 3) for i in range(3)]
+
+
+def _load(path):
+    with np.load(path) as z:
+        return {k: z[k] for k in z.files}
+
+
+def _cases(kind, golden_dir=os.path.join(os.path.dirname(__file__), 'golden')):
+    out = []
+    for p in sorted(glob.glob(os.path.join(golden_dir, '*.npz'))):
+        with np.load(p) as z:
+            if 'kind' in z.files and str(z['kind']) == kind:
+                out.append(p)
+    return out
+
+
+def _bit_equal(a, b):
+    a = np.ascontiguousarray(np.asarray(a, dtype=np.float32))
+    b = np.ascontiguousarray(np.asarray(b, dtype=np.float32))
+    return a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_fixtures_exist():
+    assert len(_cases('decode')) >= 6 and len(_cases('nms')) >= 3 and len(_cases('pipeline')) >= 2
+
+
+def test_anchor_known_answers(golden_dir):
+    """extras/cppapi/export.cpp:69-75 embeds the default anchors rounded to 2 dp."""
+    kat8 = [-12.0, -12.0, 20.0, 20.0, -7.31, -18.63, 15.31, 26.63, -18.63, -7.31, 26.63, 15.31]
+    a = box_oracle.generate_anchors(8, RATIOS, SCALES)
+    assert np.allclose(a.view(-1)[:12].numpy(), kat8, atol=5.1e-3)
+    g = _load(os.path.join(golden_dir, 'anchors.npz'))
+    for s in (8, 16, 32, 64, 128):
+        assert _bit_equal(box_oracle.generate_anchors(s, RATIOS, SCALES), g['s%d' % s])
+
+
+@pytest.mark.parametrize('path', _cases('decode'), ids=os.path.basename)
+def test_decode_matches_reference_fixture(path):
+    g = _load(path)
+    out = box_oracle.decode(torch.from_numpy(g['cls']), torch.from_numpy(g['box']), int(g['stride']),
+                            float(g['threshold']), int(g['top_n']), torch.from_numpy(g['anchors']))
+    assert _bit_equal(out[0], g['out_scores'])
+    assert _bit_equal(out[2], g['out_classes'])
+    assert _bit_equal(out[1], g['out_boxes'])
+
+
+@pytest.mark.parametrize('path', _cases('nms'), ids=os.path.basename)
+def test_nms_matches_reference_fixture(path):
+    g = _load(path)
+    out = box_oracle.nms(torch.from_numpy(g['scores']), torch.from_numpy(g['boxes']),
+                         torch.from_numpy(g['classes']), float(g['nms']), int(g['detections']))
+    for o, k in zip(out, ('out_scores', 'out_boxes', 'out_classes')):
+        assert _bit_equal(o, g[k])
+
+
+@pytest.mark.parametrize('path', _cases('pipeline'), ids=os.path.basename)
+def test_pipeline_matches_reference_fixture(path):
+    g = _load(path)
+    strides = [int(s) for s in g['strides']]
+    decoded = [box_oracle.decode(torch.from_numpy(g['cls%d' % i]), torch.from_numpy(g['box%d' % i]), s,
+                                 float(g['threshold']), int(g['top_n']), torch.from_numpy(g['anchors%d' % i]))
+               for i, s in enumerate(strides)]
+    cat = [torch.cat(t, 1) for t in zip(*decoded)]
+    for o, k in zip(cat, ('cat_scores', 'cat_boxes', 'cat_classes')):
+        assert _bit_equal(o, g[k])
+    out = box_oracle.nms(*cat, float(g['nms']), int(g['detections']))
+    for o, k in zip(out, ('out_scores', 'out_boxes', 'out_classes')):
+        assert _bit_equal(o, g[k])
+
+
+needs_ref = pytest.mark.skipif(not ref_loader.available() or torch.cuda.is_available(),
+                               reason='reference tree only exists in the build container')
+
+
+@needs_ref
+@pytest.mark.parametrize('kind,seed', [('sparse', 101), ('dense', 102), ('clustered', 103)])
+def test_live_reference_pipeline(kind, seed):
+    """Fresh inputs, bigger than the fixtures: reference vs restatement, live."""
+    cls, box, strides = synthetic.pyramid(2, 9, 80, 256, 320, kind, seed)
+    ref_dec, ora_dec = [], []
+    for c, b, s in zip(cls, box, strides):
+        a_ref = ref_loader.ref_generate_anchors(s, RATIOS, SCALES)
+        a_ora = box_oracle.generate_anchors(s, RATIOS, SCALES)
+        assert _bit_equal(a_ref, a_ora)
+        ref_dec.append(ref_loader.ref_decode(c, b, s, 0.05, 1000, a_ref))
+        ora_dec.append(box_oracle.decode(c, b, s, 0.05, 1000, a_ora))
+    ref_cat = [torch.cat(t, 1) for t in zip(*ref_dec)]
+    ora_cat = [torch.cat(t, 1) for t in zip(*ora_dec)]
+    for r, o in zip(ref_cat, ora_cat):
+        assert _bit_equal(r, o)
+    for r, o in zip(ref_loader.ref_nms(*ref_cat, 0.5, 100), box_oracle.nms(*ora_cat, 0.5, 100)):
+        assert _bit_equal(r, o)
+
+
+@needs_ref
+def test_truediv_shim_does_not_leak():
+    with ref_loader.legacy_int_division():
+        pass
+    assert (torch.tensor([7]) / 2).item() == 3.5
