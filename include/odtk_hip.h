@@ -1,0 +1,169 @@
+/*
+ * odtk_hip.h -- C ABI of the MI355X (gfx950) post-processing library  libodtk_hip.so
+ *
+ * Drop-in boundary for the per-anchor hot path of NVIDIA/retinanet-examples (ODTK):
+ * box decode + threshold/top-k prefilter, batched class-aware NMS, and the rotated-bbox
+ * decode / IoU / NMS variants.  Every entry point is `extern "C"`, takes plain pointers and
+ * sizes, never allocates device memory, never synchronises the host with the device, never
+ * throws, and only ENQUEUES work on the caller's HIP stream.
+ *
+ * Conventions shared by all entry points
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).
+ *   - all tensor pointers are DEVICE pointers; `anchors` is a HOST pointer (copied by value
+ *     into the kernel arguments -- nothing is uploaded, nothing outlives the call).
+ *   - two-phase workspace query, cub style, exactly like the reference
+ *     (csrc/cuda/decode.cu:53-72, nms.cu:87-105): call with workspace == NULL or
+ *     workspace_size == 0 -> the return value is the number of scratch bytes required
+ *     (> 0); call again with a buffer of at least that size -> returns ODTK_OK (0).
+ *   - errors are negative return values (the reference never checked a CUDA error and threw
+ *     std::runtime_error("Workspace is too small!") across the boundary, utils.h:55-57).
+ *   - the workspace is scratch: contents before the call are irrelevant, a call may not
+ *     share its workspace with another call that is in flight on a different stream.
+ *   - outputs are fully written (zero padded tails); they need not be pre-zeroed.
+ *
+ * Semantics are those of the reference's CPU path odtk/box.py (the normative ones, see
+ * DESIGN.md): candidates are `score >= score_thresh`, ordered score-descending with ties
+ * broken by ascending flat NCHW index (decode) / ascending candidate position (nms);
+ * boxes are clamped on both sides to [0, size*stride-1]; NMS uses the +1 pixel convention
+ * and suppresses iff same class and not (IoU <= nms_thresh).
+ */
+#ifndef ODTK_HIP_H
+#define ODTK_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ODTK_OK                0
+#define ODTK_ERR_INVALID      -1   /* bad argument (null pointer, size 0, limit exceeded) */
+#define ODTK_ERR_WORKSPACE    -2   /* workspace smaller than the size query reports       */
+#define ODTK_ERR_HIP          -3   /* a HIP runtime call failed; see odtk_last_hip_error() */
+#define ODTK_ERR_UNSUPPORTED  -4   /* dtype / layout combination not implemented          */
+
+#define ODTK_MAX_LEVELS    8       /* pyramid levels per odtk_decode_levels call          */
+#define ODTK_MAX_ANCHORS   32      /* anchors per cell (9 axis-aligned, 27 rotated)       */
+#define ODTK_MAX_TOP_N     4096    /* per-level top_n                                     */
+#define ODTK_MAX_NMS_COUNT 7680    /* candidates per image into nms (5 x 1000 by default) */
+
+/* element types of the head tensors */
+#define ODTK_F32   0
+#define ODTK_BF16  1
+#define ODTK_F16   2
+
+/* flags */
+#define ODTK_FLAG_ROTATED        1u   /* 6-parameter boxes [x1,y1,x2,y2,sin,cos]                       */
+#define ODTK_FLAG_LOGITS         2u   /* cls holds logits: sigmoid is fused into the prefilter          */
+#define ODTK_FLAG_ROTATED_NMS_FIXED_ANGLE 4u /* rotated nms: use each box's OWN angle (the reference   */
+                                      /* rotates both quads by the lower-scored box's angle,            */
+                                      /* csrc/cuda/nms_iou.cu:192; that is the default here too)        */
+
+const char *odtk_version(void);
+/* hipGetErrorString of the last HIP failure seen by this thread ("" if none). */
+const char *odtk_last_hip_error(void);
+
+/*
+ * odtk_decode / odtk_decode_rotate -- one pyramid level, whole batch.
+ * Replaces  int odtk::cuda::decode(...)         csrc/cuda/decode.h:30-35  (decode.cu:44-171)
+ *      and  int odtk::cuda::decode_rotate(...)  csrc/cuda/decode_rotate.h:30-35
+ * Same argument order and meaning; `const std::vector<float>& anchors` becomes
+ * (anchors, anchors_len) and cudaStream_t becomes a hipStream_t.
+ *   inputs[0]  scores  float32 [batch, num_anchors*num_classes, height, width]  contiguous NCHW
+ *   inputs[1]  deltas  float32 [batch, num_anchors*{4|6},       height, width]
+ *   outputs[0] scores  float32 [batch, top_n]
+ *   outputs[1] boxes   float32 [batch, top_n, {4|6}]
+ *   outputs[2] classes float32 [batch, top_n]
+ *   anchors    host float[anchors_len], anchors_len == 4*num_anchors (axis-aligned set,
+ *              also for rotated -- csrc/cuda/decode_rotate.cu:139, box.py:258-259)
+ */
+int odtk_decode(int batch_size, const void *const *inputs, void *const *outputs,
+                size_t height, size_t width, size_t scale, size_t num_anchors, size_t num_classes,
+                const float *anchors, size_t anchors_len, float score_thresh, int top_n,
+                void *workspace, size_t workspace_size, void *stream);
+
+int odtk_decode_rotate(int batch_size, const void *const *inputs, void *const *outputs,
+                       size_t height, size_t width, size_t scale, size_t num_anchors, size_t num_classes,
+                       const float *anchors, size_t anchors_len, float score_thresh, int top_n,
+                       void *workspace, size_t workspace_size, void *stream);
+
+/*
+ * odtk_nms / odtk_nms_rotate -- whole batch, one workgroup per image.
+ * Replaces  int odtk::cuda::nms(...)         csrc/cuda/nms.h:28-31      (nms.cu:82-160)
+ *      and  int odtk::cuda::nms_rotate(...)  csrc/cuda/nms_iou.h:28-31  (nms_iou.cu:260-322)
+ *   inputs[0]  scores  float32 [batch, count]          (<= 0 entries are padding)
+ *   inputs[1]  boxes   float32 [batch, count, {4|6}]
+ *   inputs[2]  classes float32 [batch, count]
+ *   outputs[0..2]      float32 [batch, detections_per_im], [.., {4|6}], [..]
+ */
+int odtk_nms(int batch_size, const void *const *inputs, void *const *outputs,
+             size_t count, int detections_per_im, float nms_thresh,
+             void *workspace, size_t workspace_size, void *stream);
+
+int odtk_nms_rotate(int batch_size, const void *const *inputs, void *const *outputs,
+                    size_t count, int detections_per_im, float nms_thresh,
+                    void *workspace, size_t workspace_size, void *stream);
+
+/*
+ * odtk_iou -- pairwise rotated-rectangle IoU (training-side target assignment).
+ * Replaces  int odtk::cuda::iou(...)  csrc/cuda/nms_iou.h:33-35 (nms_iou.cu:324-387).
+ *   inputs[0]  boxes   float32 [num_boxes, 4 corners, 2]
+ *   inputs[1]  anchors float32 [num_anchors, 4 corners, 2]
+ *   outputs[0] iou     float32 [num_anchors, num_boxes]   (layout of csrc/extensions.cpp:64-66)
+ */
+int odtk_iou(const void *const *inputs, void *const *outputs, int num_boxes, int num_anchors,
+             void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Extended entry points (no reference equivalent): the MI355X-first batched forms.
+ * ---------------------------------------------------------------------------------------- */
+
+typedef struct odtk_level {
+  const void *cls;          /* [batch, A*C, H, W] scores (or logits with ODTK_FLAG_LOGITS)   */
+  const void *box;          /* [batch, A*nb, H, W] deltas                                    */
+  int32_t height, width;    /* H, W of this level                                            */
+  int32_t stride;           /* pixels per cell (the reference's `scale`)                     */
+  int32_t channels_last;    /* 0: NCHW-contiguous, 1: NHWC-contiguous (torch.channels_last)  */
+  const float *anchors;     /* HOST float[4*A]                                               */
+} odtk_level_t;
+
+/*
+ * odtk_decode_levels -- ALL pyramid levels x whole batch in one enqueue (2 kernel launches,
+ * no host synchronisation; the reference needs >= 5 launches + 1 host sync per image per
+ * level, decode.cu:86-168).  Outputs are written directly in the concatenated layout that
+ * `torch.cat(per_level, 1)` produces in the reference (odtk/model.py:164):
+ *   outputs[0] scores  float32 [batch, n_levels*top_n]
+ *   outputs[1] boxes   float32 [batch, n_levels*top_n, {4|6}]
+ *   outputs[2] classes float32 [batch, n_levels*top_n]
+ *   outputs[3] (optional, may be NULL) int32 [batch, n_levels*top_n] flat NCHW index of each
+ *              detection inside its level (-1 padding) -- for index-level parity checks.
+ * n_outputs is 3 or 4.
+ */
+int odtk_decode_levels(int batch_size, int n_levels, const odtk_level_t *levels,
+                       int num_anchors, int num_classes, int dtype, uint32_t flags,
+                       float score_thresh, int top_n,
+                       void *const *outputs, int n_outputs,
+                       void *workspace, size_t workspace_size, void *stream);
+
+/*
+ * odtk_nms_ex -- odtk_nms / odtk_nms_rotate selected by flags, plus an optional 4th output
+ *   outputs[3] (may be NULL) int32 [batch, detections_per_im]: input position of each kept box.
+ */
+int odtk_nms_ex(int batch_size, const void *const *inputs, void *const *outputs, int n_outputs,
+                size_t count, int detections_per_im, float nms_thresh, uint32_t flags,
+                void *workspace, size_t workspace_size, void *stream);
+
+/*
+ * odtk_detect -- decode_levels + nms back to back on one stream (the whole post-processing of
+ * odtk/model.py:153-165 in 3 launches).  outputs as odtk_nms; workspace holds the candidates.
+ */
+int odtk_detect(int batch_size, int n_levels, const odtk_level_t *levels,
+                int num_anchors, int num_classes, int dtype, uint32_t flags,
+                float score_thresh, int top_n, float nms_thresh, int detections_per_im,
+                void *const *outputs, void *workspace, size_t workspace_size, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ODTK_HIP_H */

@@ -1,0 +1,63 @@
+// common.hpp -- shared device helpers for the gfx950 post-processing kernels.
+//
+// Target: MI355X / gfx950 only (wave64, 256 CUs in 8 XCDs, 160 KiB LDS per CU).
+// Parity rule: every arithmetic expression that feeds an output value is written in the
+// exact operation order of the reference's CPU path (odtk/box.py) and the library is built
+// with -ffp-contract=off so hipcc never fuses a*b+c into an FMA the CPU does not perform.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace odtk {
+
+constexpr int kWave = 64;
+
+// ---------------------------------------------------------------------------------------
+// 64-bit selection key:  (orderable(score) << 32) | ~flat_index
+// Larger key == better candidate: score descending, then flat NCHW index ascending -- the
+// canonical tie rule (stable descending sort of an index-ascending list; box.py:289 with
+// torch.sort(stable=True), equal to the CUDA path's stable radix sort decode.cu:111-112).
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t float_to_ordered(float s) {
+  s = s + 0.0f;  // -0.0 -> +0.0 so both zeros compare equal, as torch.sort does
+  uint32_t b = __float_as_uint(s);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float ordered_to_float(uint32_t o) {
+  uint32_t b = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
+  return __uint_as_float(b);
+}
+__device__ __forceinline__ uint64_t make_key(float score, uint32_t index) {
+  return (static_cast<uint64_t>(float_to_ordered(score)) << 32) | static_cast<uint32_t>(~index);
+}
+__device__ __forceinline__ float key_score(uint64_t k) { return ordered_to_float(static_cast<uint32_t>(k >> 32)); }
+__device__ __forceinline__ uint32_t key_index(uint64_t k) { return ~static_cast<uint32_t>(k); }
+
+// ---------------------------------------------------------------------------------------
+// wave64 helpers
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return static_cast<int>(threadIdx.x) & (kWave - 1); }
+
+// inclusive prefix sum across the 64 lanes of a wave
+__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v) {
+  const int lane = lane_id();
+#pragma unroll
+  for (int d = 1; d < kWave; d <<= 1) {
+    uint32_t n = __shfl_up(v, d, kWave);
+    if (lane >= d) v += n;
+  }
+  return v;
+}
+
+// torch.min / torch.max propagate NaN (box.py:107 `torch.max(m, torch.min(t, M))`)
+__device__ __forceinline__ float clamp_like_torch(float t, float hi) {
+  float mn = (t != t) ? t : (t < hi ? t : hi);
+  return (mn != mn) ? mn : (mn > 0.0f ? mn : 0.0f);
+}
+
+// Correctly rounded fp32 exp (double-precision exp rounded once).  torch's CPU exp is within
+// 1 ulp of this (measured: 1.1 % of inputs differ, by exactly 1 ulp) -- see DESIGN.md "exp".
+__device__ __forceinline__ float exp_cr(float x) { return static_cast<float>(exp(static_cast<double>(x))); }
+
+}  // namespace odtk

@@ -1,0 +1,325 @@
+// odtk_hip.hip -- the C ABI (include/odtk_hip.h) over the gfx950 kernels.  Single translation
+// unit: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared.
+//
+// Host side rules: validate, lay out the workspace, fill kernel-argument structs (level tables and
+// anchors travel BY VALUE in the kernarg segment: nothing is uploaded, so calls are
+// hipGraph-capturable), enqueue on the caller's stream, return.  No allocation, no host sync.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "../../include/odtk_hip.h"
+#include "common.hpp"
+#include "iou.hpp"
+#include "nms.hpp"
+#include "prefilter.hpp"
+#include "select_decode.hpp"
+
+namespace {
+
+thread_local char g_last_error[256] = "";
+
+int hip_fail(hipError_t e, const char *what) {
+  std::snprintf(g_last_error, sizeof g_last_error, "%s: %s", what, hipGetErrorString(e));
+  return ODTK_ERR_HIP;
+}
+#define ODTK_HIP_TRY(expr)                                   \
+  do {                                                       \
+    hipError_t e_ = (expr);                                  \
+    if (e_ != hipSuccess) return hip_fail(e_, #expr);        \
+  } while (0)
+
+constexpr size_t kAlign = 256;
+inline size_t align_up(size_t v) { return (v + kAlign - 1) / kAlign * kAlign; }
+
+// per-segment candidate capacity: min(scores per image, ODTK_CAND_CAP (default 2^20 keys = 8 MiB))
+uint32_t cand_cap_limit() {
+  static const uint32_t v = [] {
+    const char *e = std::getenv("ODTK_CAND_CAP");
+    long long x = e ? std::atoll(e) : (1ll << 20);
+    if (x < ODTK_MAX_TOP_N) x = ODTK_MAX_TOP_N;      // the radix-select path needs cap >= top_n
+    if (x > (1ll << 28)) x = 1ll << 28;
+    return static_cast<uint32_t>(x);
+  }();
+  return v;
+}
+
+struct DecodeLayout {
+  size_t counts_off, cand_off[ODTK_MAX_LEVELS], total;
+  uint32_t cap[ODTK_MAX_LEVELS], n[ODTK_MAX_LEVELS];
+};
+
+int decode_layout(int batch, int n_levels, const odtk_level_t *levels, int A, int C, DecodeLayout *out) {
+  size_t off = 0;
+  out->counts_off = off;
+  off += align_up(sizeof(uint32_t) * static_cast<size_t>(batch) * n_levels);
+  for (int l = 0; l < n_levels; ++l) {
+    const unsigned long long n = 1ull * A * C * levels[l].height * levels[l].width;
+    if (n == 0 || n > 0x7fff0000ull) return ODTK_ERR_INVALID;
+    out->n[l] = static_cast<uint32_t>(n);
+    out->cap[l] = n < cand_cap_limit() ? static_cast<uint32_t>(n) : cand_cap_limit();
+    out->cand_off[l] = off;
+    off += align_up(sizeof(uint64_t) * static_cast<size_t>(batch) * out->cap[l]);
+  }
+  out->total = off;
+  return ODTK_OK;
+}
+
+int decode_levels_impl(int batch, int n_levels, const odtk_level_t *levels, int A, int C, int dtype,
+                       uint32_t flags, float thresh, int top_n, void *const *outputs, int n_outputs,
+                       void *workspace, size_t workspace_size, hipStream_t stream) {
+  if (batch <= 0 || n_levels <= 0 || n_levels > ODTK_MAX_LEVELS || !levels) return ODTK_ERR_INVALID;
+  if (A <= 0 || A > ODTK_MAX_ANCHORS || C <= 0 || top_n <= 0 || top_n > ODTK_MAX_TOP_N) return ODTK_ERR_INVALID;
+  for (int l = 0; l < n_levels; ++l)
+    if (levels[l].height <= 0 || levels[l].width <= 0) return ODTK_ERR_INVALID;
+  if (dtype != ODTK_F32 || (flags & ODTK_FLAG_LOGITS)) return ODTK_ERR_UNSUPPORTED;
+  for (int l = 0; l < n_levels; ++l)
+    if (levels[l].channels_last) return ODTK_ERR_UNSUPPORTED;
+
+  DecodeLayout lay;
+  int rc = decode_layout(batch, n_levels, levels, A, C, &lay);
+  if (rc != ODTK_OK) return rc;
+  if (!workspace || !workspace_size) {
+    if (lay.total > 0x7fffffffull) return ODTK_ERR_INVALID;   // the int return cannot carry it
+    return static_cast<int>(lay.total);
+  }
+  if (workspace_size < lay.total) return ODTK_ERR_WORKSPACE;
+  if (!outputs || n_outputs < 3 || !outputs[0] || !outputs[1] || !outputs[2]) return ODTK_ERR_INVALID;
+  for (int l = 0; l < n_levels; ++l) {
+    if (!levels[l].cls || !levels[l].box || !levels[l].anchors) return ODTK_ERR_INVALID;
+    if (reinterpret_cast<uintptr_t>(levels[l].cls) & 15u) return ODTK_ERR_INVALID;   // 16-B vector loads
+  }
+
+  char *ws = static_cast<char *>(workspace);
+  uint32_t *counts = reinterpret_cast<uint32_t *>(ws + lay.counts_off);
+  uint64_t *cand = reinterpret_cast<uint64_t *>(ws);   // cand_off are byte offsets from ws; converted below
+
+  odtk::ScanArgs sa;
+  std::memset(&sa, 0, sizeof sa);
+  odtk::DecodeArgs da;
+  std::memset(&da, 0, sizeof da);
+  uint32_t tiles = 0;
+  for (int l = 0; l < n_levels; ++l) {
+    const uint64_t total = static_cast<uint64_t>(batch) * lay.n[l];
+    sa.lv[l].cls = levels[l].cls;
+    sa.lv[l].total = total;
+    sa.lv[l].cand_off = lay.cand_off[l] / sizeof(uint64_t);
+    sa.lv[l].n = lay.n[l];
+    sa.lv[l].tile_begin = tiles;
+    sa.lv[l].seg_base = static_cast<uint32_t>(l) * batch;
+    sa.lv[l].cap = lay.cap[l];
+    tiles += static_cast<uint32_t>((total + odtk::kTile - 1) / odtk::kTile);
+
+    da.lv[l].cls = levels[l].cls;
+    da.lv[l].box = levels[l].box;
+    da.lv[l].cand_off = sa.lv[l].cand_off;
+    da.lv[l].n = lay.n[l];
+    da.lv[l].cap = lay.cap[l];
+    da.lv[l].height = levels[l].height;
+    da.lv[l].width = levels[l].width;
+    da.lv[l].stride = static_cast<float>(levels[l].stride);
+    std::memcpy(da.lv[l].anchors, levels[l].anchors, sizeof(float) * 4 * A);
+  }
+  sa.counts = counts;
+  sa.cand = cand;
+  sa.n_levels = n_levels;
+  sa.batch = batch;
+  sa.thresh = thresh;
+
+  da.counts = counts;
+  da.cand = cand;
+  da.out_scores = static_cast<float *>(outputs[0]);
+  da.out_boxes = static_cast<float *>(outputs[1]);
+  da.out_classes = static_cast<float *>(outputs[2]);
+  da.out_indices = n_outputs > 3 ? static_cast<int32_t *>(outputs[3]) : nullptr;
+  da.n_levels = n_levels;
+  da.batch = batch;
+  da.num_anchors = A;
+  da.num_classes = C;
+  da.top_n = top_n;
+  da.thresh = thresh;
+
+  const int n_seg = batch * n_levels;
+  ODTK_HIP_TRY(hipMemsetAsync(counts, 0, sizeof(uint32_t) * n_seg, stream));
+  hipLaunchKernelGGL(odtk::prefilter_scan_kernel, dim3(tiles), dim3(odtk::kScanThreads), 0, stream, sa);
+  ODTK_HIP_TRY(hipGetLastError());
+  if (flags & ODTK_FLAG_ROTATED)
+    hipLaunchKernelGGL(odtk::select_decode_kernel<6>, dim3(n_seg), dim3(odtk::kSelThreads), 0, stream, da);
+  else
+    hipLaunchKernelGGL(odtk::select_decode_kernel<4>, dim3(n_seg), dim3(odtk::kSelThreads), 0, stream, da);
+  ODTK_HIP_TRY(hipGetLastError());
+  return ODTK_OK;
+}
+
+size_t nms_lds_bytes(uint32_t count, uint32_t n_pow2, int nb) {
+  const size_t overlay = static_cast<size_t>(count) * (nb + 1) * 4;
+  const size_t keys_b = static_cast<size_t>(n_pow2) * 8;
+  const size_t bitmap_off = ((overlay > keys_b ? overlay : keys_b) + 15) & ~static_cast<size_t>(15);
+  return bitmap_off + 2 * odtk::kNmsWords * 8 + 16;
+}
+
+template <int NB>
+int nms_launch(const odtk::NmsArgs &na, int batch, size_t lds, hipStream_t stream) {
+  // opt this kernel in to the full 160 KiB of LDS once (thread-safe static initialisation)
+  static const hipError_t attr_err =
+      hipFuncSetAttribute(reinterpret_cast<const void *>(&odtk::nms_kernel<NB>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (attr_err != hipSuccess) return hip_fail(attr_err, "hipFuncSetAttribute(nms_kernel)");
+  hipLaunchKernelGGL(odtk::nms_kernel<NB>, dim3(batch), dim3(odtk::kNmsThreads), lds, stream, na);
+  ODTK_HIP_TRY(hipGetLastError());
+  return ODTK_OK;
+}
+
+int nms_impl(int batch, const void *const *inputs, void *const *outputs, int n_outputs, size_t count,
+             int ndet, float thresh, uint32_t flags, void *workspace, size_t workspace_size, hipStream_t stream) {
+  if (batch <= 0 || count == 0 || count > ODTK_MAX_NMS_COUNT || ndet <= 0) return ODTK_ERR_INVALID;
+  // the kernel needs no global scratch (everything is LDS-resident); a token size keeps the
+  // reference's two-phase calling convention working unchanged.
+  if (!workspace || !workspace_size) return static_cast<int>(kAlign);
+  if (workspace_size < kAlign) return ODTK_ERR_WORKSPACE;
+  if (!inputs || !outputs || n_outputs < 3) return ODTK_ERR_INVALID;
+  for (int i = 0; i < 3; ++i)
+    if (!inputs[i] || !outputs[i]) return ODTK_ERR_INVALID;
+  const int nb = (flags & ODTK_FLAG_ROTATED) ? 6 : 4;
+  odtk::NmsArgs na;
+  std::memset(&na, 0, sizeof na);
+  na.scores = static_cast<const float *>(inputs[0]);
+  na.boxes = static_cast<const float *>(inputs[1]);
+  na.classes = static_cast<const float *>(inputs[2]);
+  na.out_scores = static_cast<float *>(outputs[0]);
+  na.out_boxes = static_cast<float *>(outputs[1]);
+  na.out_classes = static_cast<float *>(outputs[2]);
+  na.out_indices = n_outputs > 3 ? static_cast<int32_t *>(outputs[3]) : nullptr;
+  na.count = static_cast<uint32_t>(count);
+  uint32_t p2 = 1;
+  while (p2 < count) p2 <<= 1;
+  na.n_pow2 = p2;
+  na.ndet = ndet;
+  na.thresh = thresh;
+  na.flags = flags;
+  const size_t lds = nms_lds_bytes(na.count, p2, nb);
+  if (lds > 160 * 1024) return ODTK_ERR_INVALID;
+  return nb == 6 ? nms_launch<6>(na, batch, lds, stream) : nms_launch<4>(na, batch, lds, stream);
+}
+
+int decode_single(bool rotated, int batch, const void *const *inputs, void *const *outputs, size_t height,
+                  size_t width, size_t scale, size_t A, size_t C, const float *anchors, size_t anchors_len,
+                  float thresh, int top_n, void *workspace, size_t workspace_size, void *stream) {
+  if (height == 0 || width == 0 || height > 0x7fffffff || width > 0x7fffffff || scale > 0x7fffffff)
+    return ODTK_ERR_INVALID;
+  if (A == 0 || A > ODTK_MAX_ANCHORS || anchors_len != 4 * A || (!anchors && workspace && workspace_size))
+    return ODTK_ERR_INVALID;
+  const bool query = !workspace || !workspace_size;
+  if (!query && (!inputs || !inputs[0] || !inputs[1])) return ODTK_ERR_INVALID;
+  odtk_level_t lv;
+  std::memset(&lv, 0, sizeof lv);
+  lv.cls = query ? nullptr : inputs[0];
+  lv.box = query ? nullptr : inputs[1];
+  lv.height = static_cast<int32_t>(height);
+  lv.width = static_cast<int32_t>(width);
+  lv.stride = static_cast<int32_t>(scale);
+  lv.anchors = anchors;
+  return decode_levels_impl(batch, 1, &lv, static_cast<int>(A), static_cast<int>(C), ODTK_F32,
+                            rotated ? ODTK_FLAG_ROTATED : 0u, thresh, top_n, outputs, 3, workspace,
+                            workspace_size, static_cast<hipStream_t>(stream));
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *odtk_version(void) { return "odtk-hip 0.1 (gfx950)"; }
+const char *odtk_last_hip_error(void) { return g_last_error; }
+
+int odtk_decode(int batch_size, const void *const *inputs, void *const *outputs, size_t height, size_t width,
+                size_t scale, size_t num_anchors, size_t num_classes, const float *anchors, size_t anchors_len,
+                float score_thresh, int top_n, void *workspace, size_t workspace_size, void *stream) {
+  return decode_single(false, batch_size, inputs, outputs, height, width, scale, num_anchors, num_classes,
+                       anchors, anchors_len, score_thresh, top_n, workspace, workspace_size, stream);
+}
+
+int odtk_decode_rotate(int batch_size, const void *const *inputs, void *const *outputs, size_t height,
+                       size_t width, size_t scale, size_t num_anchors, size_t num_classes, const float *anchors,
+                       size_t anchors_len, float score_thresh, int top_n, void *workspace, size_t workspace_size,
+                       void *stream) {
+  return decode_single(true, batch_size, inputs, outputs, height, width, scale, num_anchors, num_classes,
+                       anchors, anchors_len, score_thresh, top_n, workspace, workspace_size, stream);
+}
+
+int odtk_nms(int batch_size, const void *const *inputs, void *const *outputs, size_t count,
+             int detections_per_im, float nms_thresh, void *workspace, size_t workspace_size, void *stream) {
+  return nms_impl(batch_size, inputs, outputs, 3, count, detections_per_im, nms_thresh, 0u, workspace,
+                  workspace_size, static_cast<hipStream_t>(stream));
+}
+
+int odtk_nms_rotate(int batch_size, const void *const *inputs, void *const *outputs, size_t count,
+                    int detections_per_im, float nms_thresh, void *workspace, size_t workspace_size,
+                    void *stream) {
+  return nms_impl(batch_size, inputs, outputs, 3, count, detections_per_im, nms_thresh, ODTK_FLAG_ROTATED,
+                  workspace, workspace_size, static_cast<hipStream_t>(stream));
+}
+
+int odtk_nms_ex(int batch_size, const void *const *inputs, void *const *outputs, int n_outputs, size_t count,
+                int detections_per_im, float nms_thresh, uint32_t flags, void *workspace,
+                size_t workspace_size, void *stream) {
+  return nms_impl(batch_size, inputs, outputs, n_outputs, count, detections_per_im, nms_thresh, flags,
+                  workspace, workspace_size, static_cast<hipStream_t>(stream));
+}
+
+int odtk_iou(const void *const *inputs, void *const *outputs, int num_boxes, int num_anchors, void *stream) {
+  if (!inputs || !outputs || !inputs[0] || !inputs[1] || !outputs[0]) return ODTK_ERR_INVALID;
+  if (num_boxes < 0 || num_anchors < 0) return ODTK_ERR_INVALID;
+  const long long pairs = 1ll * num_boxes * num_anchors;
+  if (pairs == 0) return ODTK_OK;
+  if (pairs > 0x7fffffffll) return ODTK_ERR_INVALID;
+  const int threads = 256;
+  long long blocks = (pairs + threads - 1) / threads;
+  if (blocks > 256 * 16) blocks = 256 * 16;                  // grid-stride beyond 16 workgroups per CU
+  hipLaunchKernelGGL(odtk::iou_pairs_kernel, dim3(static_cast<unsigned>(blocks)), dim3(threads), 0,
+                     static_cast<hipStream_t>(stream), static_cast<const float *>(inputs[0]),
+                     static_cast<const float *>(inputs[1]), static_cast<float *>(outputs[0]), num_boxes,
+                     num_anchors);
+  ODTK_HIP_TRY(hipGetLastError());
+  return ODTK_OK;
+}
+
+int odtk_decode_levels(int batch_size, int n_levels, const odtk_level_t *levels, int num_anchors,
+                       int num_classes, int dtype, uint32_t flags, float score_thresh, int top_n,
+                       void *const *outputs, int n_outputs, void *workspace, size_t workspace_size,
+                       void *stream) {
+  return decode_levels_impl(batch_size, n_levels, levels, num_anchors, num_classes, dtype, flags,
+                            score_thresh, top_n, outputs, n_outputs, workspace, workspace_size,
+                            static_cast<hipStream_t>(stream));
+}
+
+int odtk_detect(int batch_size, int n_levels, const odtk_level_t *levels, int num_anchors, int num_classes,
+                int dtype, uint32_t flags, float score_thresh, int top_n, float nms_thresh,
+                int detections_per_im, void *const *outputs, void *workspace, size_t workspace_size,
+                void *stream) {
+  if (batch_size <= 0 || n_levels <= 0 || n_levels > ODTK_MAX_LEVELS || top_n <= 0) return ODTK_ERR_INVALID;
+  const int nb = (flags & ODTK_FLAG_ROTATED) ? 6 : 4;
+  const size_t count = static_cast<size_t>(n_levels) * top_n;
+  // workspace = [decode scratch | cat scores | cat boxes | cat classes]
+  const int dec = decode_levels_impl(batch_size, n_levels, levels, num_anchors, num_classes, dtype, flags,
+                                     score_thresh, top_n, nullptr, 0, nullptr, 0, nullptr);
+  if (dec < 0) return dec;
+  const size_t off_s = align_up(static_cast<size_t>(dec));
+  const size_t off_b = off_s + align_up(sizeof(float) * batch_size * count);
+  const size_t off_c = off_b + align_up(sizeof(float) * batch_size * count * nb);
+  const size_t total = off_c + align_up(sizeof(float) * batch_size * count);
+  if (!workspace || !workspace_size) return total > 0x7fffffffull ? ODTK_ERR_INVALID : static_cast<int>(total);
+  if (workspace_size < total) return ODTK_ERR_WORKSPACE;
+  if (!outputs) return ODTK_ERR_INVALID;
+  char *ws = static_cast<char *>(workspace);
+  void *cat[3] = {ws + off_s, ws + off_b, ws + off_c};
+  int rc = decode_levels_impl(batch_size, n_levels, levels, num_anchors, num_classes, dtype, flags, score_thresh,
+                              top_n, cat, 3, workspace, static_cast<size_t>(dec), static_cast<hipStream_t>(stream));
+  if (rc != ODTK_OK) return rc;
+  // nms needs no global scratch: hand it a token region inside the decode scratch (unused by it)
+  return nms_impl(batch_size, cat, outputs, 3, count, detections_per_im, nms_thresh, flags, ws, kAlign,
+                  static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

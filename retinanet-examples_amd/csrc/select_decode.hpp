@@ -1,0 +1,231 @@
+// select_decode.hpp -- kernel 2 of the decode path: one 1024-thread workgroup per
+// (level, image) segment picks the top_n candidates (score desc, flat index asc), sorts them
+// in LDS and decodes their boxes.
+//
+// Replaces reference steps D4-D6 (csrc/cuda/decode.cu:108-167: gather + cub radix sort of all
+// survivors, the box-decode device lambda, the tail fills) for all images and levels at once.
+// Box arithmetic follows odtk/box.py:97-111 + :302 operation by operation (CPU path is
+// normative: two-sided clamp).
+//
+// Selection is exact for ANY input:
+//   K <= kSortCap           : all candidates are sorted (bitonic network in LDS).
+//   kSortCap < K <= cap     : MSD radix-select (11-bit digits, LDS histograms) on the 64-bit
+//                             keys of the candidate list finds the top_n-th key, the keys
+//                             >= it are gathered into LDS and sorted.
+//   K > cap (list overflow) : the same radix-select runs over the segment's RAW scores
+//                             (keys rebuilt on the fly), so correctness never depends on cap.
+// Keys are unique (they embed the index), so "keys >= T" is exactly top_n elements even when
+// every score is equal.
+#pragma once
+
+#include "common.hpp"
+#include "../../include/odtk_hip.h"
+
+namespace odtk {
+
+constexpr int kSelThreads = 1024;
+constexpr int kSortCap = ODTK_MAX_TOP_N;        // keys sortable in LDS (32 KiB)
+constexpr int kRadixBits = 11;
+constexpr int kRadixBins = 1 << kRadixBits;
+
+struct DecodeLevel {
+  const void *cls;
+  const void *box;
+  uint64_t cand_off;
+  uint32_t n;            // A*C*H*W
+  uint32_t cap;
+  int32_t height, width;
+  float stride;
+  float anchors[ODTK_MAX_ANCHORS * 4];
+};
+
+struct DecodeArgs {
+  DecodeLevel lv[ODTK_MAX_LEVELS];
+  const uint32_t *counts;
+  const uint64_t *cand;
+  float *out_scores;     // [batch, n_levels*top_n]
+  float *out_boxes;      // [batch, n_levels*top_n, NB]
+  float *out_classes;    // [batch, n_levels*top_n]
+  int32_t *out_indices;  // optional
+  int n_levels, batch, num_anchors, num_classes, top_n;
+  float thresh;
+};
+
+// ---- key sources -------------------------------------------------------------------------
+struct ListSource {   // the compacted candidate list written by prefilter_scan_kernel
+  const uint64_t *keys;
+  uint32_t count;
+  template <typename F>
+  __device__ __forceinline__ void for_each(F &&f) const {
+    for (uint32_t i = threadIdx.x; i < count; i += kSelThreads) f(keys[i]);
+  }
+};
+struct RawSource {    // the segment's raw scores (overflow path)
+  const float *scores;
+  uint32_t n;
+  float thresh;
+  template <typename F>
+  __device__ __forceinline__ void for_each(F &&f) const {
+    for (uint32_t i = threadIdx.x; i < n; i += kSelThreads) {
+      const float s = scores[i];
+      if (s >= thresh) f(make_key(s, i));
+    }
+  }
+};
+
+// ---- block-wide helpers --------------------------------------------------------------------
+// Bitonic sort, descending, of s_keys[0..n) (n a power of two <= kSortCap), 1024 threads.
+__device__ __forceinline__ void bitonic_sort_desc(uint64_t *s_keys, uint32_t n) {
+  for (uint32_t k = 2; k <= n; k <<= 1) {
+    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+      for (uint32_t t = threadIdx.x; t < (n >> 1); t += kSelThreads) {
+        const uint32_t lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));   // element with bit j clear
+        const uint32_t hi = lo | j;
+        const uint64_t x = s_keys[lo], y = s_keys[hi];
+        const bool desc = (lo & k) == 0;                               // direction of this run
+        if (desc ? (x < y) : (x > y)) { s_keys[lo] = y; s_keys[hi] = x; }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// Finds T such that exactly `want` keys of `src` are >= T (keys unique, count(src) > want).
+template <typename Source>
+__device__ uint64_t radix_select(const Source &src, uint32_t want, uint32_t *s_hist, uint32_t *s_misc) {
+  uint64_t prefix = 0, pmask = 0;
+  uint32_t remaining = want;
+  int hi_bit = 64;
+  while (hi_bit > 0) {
+    const int bits = hi_bit >= kRadixBits ? kRadixBits : hi_bit;
+    const int shift = hi_bit - bits;
+    const uint32_t nb = 1u << bits;
+    for (uint32_t i = threadIdx.x; i < kRadixBins; i += kSelThreads) s_hist[i] = 0;
+    __syncthreads();
+    // histogram, bins reversed so that an ascending scan walks keys from the largest digit down
+    src.for_each([&](uint64_t key) {
+      if ((key & pmask) == prefix) atomicAdd(&s_hist[(nb - 1) - static_cast<uint32_t>((key >> shift) & (nb - 1))], 1u);
+    });
+    __syncthreads();
+    // inclusive scan over kRadixBins bins, 2 per thread
+    const uint32_t h0 = s_hist[2 * threadIdx.x], h1 = s_hist[2 * threadIdx.x + 1];
+    const uint32_t inc = wave_inclusive_sum(h0 + h1);
+    const int w = threadIdx.x >> 6;
+    if (lane_id() == kWave - 1) s_misc[w] = inc;
+    __syncthreads();
+    uint32_t woff = 0;
+    for (int i = 0; i < w; ++i) woff += s_misc[i];
+    const uint32_t excl = woff + inc - (h0 + h1);
+    __syncthreads();                       // s_misc reused below
+    // the unique bin where the running count crosses `remaining`
+    if (excl < remaining && remaining <= excl + h0) { s_misc[0] = 2 * threadIdx.x; s_misc[1] = excl; s_misc[2] = h0; }
+    else if (excl + h0 < remaining && remaining <= excl + h0 + h1) { s_misc[0] = 2 * threadIdx.x + 1; s_misc[1] = excl + h0; s_misc[2] = h1; }
+    __syncthreads();
+    const uint32_t rbin = s_misc[0], above = s_misc[1], in_bin = s_misc[2];
+    __syncthreads();
+    const uint64_t digit = (nb - 1) - rbin;
+    prefix |= digit << shift;
+    pmask |= static_cast<uint64_t>(nb - 1) << shift;
+    remaining -= above;
+    hi_bit = shift;
+    if (in_bin == remaining) break;        // the whole bucket is wanted: undecided low bits stay 0
+  }
+  return prefix;
+}
+
+// ---- the kernel ------------------------------------------------------------------------------
+template <int NB>
+__global__ __launch_bounds__(kSelThreads) void select_decode_kernel(const DecodeArgs a) {
+  __shared__ uint64_t s_keys[kSortCap];
+  __shared__ uint32_t s_hist[kRadixBins];
+  __shared__ uint32_t s_misc[32];
+
+  const int seg = blockIdx.x;
+  const int l = seg / a.batch;
+  const int b = seg - l * a.batch;
+  const DecodeLevel &L = a.lv[l];
+  const uint32_t count = a.counts[seg];
+  const uint32_t top_n = a.top_n;
+  const uint32_t k_out = count < top_n ? count : top_n;
+
+  const uint64_t *list = a.cand + L.cand_off + static_cast<uint64_t>(b) * L.cap;
+  uint32_t n_sort;   // number of valid keys placed in s_keys
+
+  if (count <= kSortCap && count <= L.cap) {
+    for (uint32_t i = threadIdx.x; i < count; i += kSelThreads) s_keys[i] = list[i];
+    n_sort = count;
+  } else {
+    uint64_t T;
+    if (count <= top_n) T = 0;   // everything is wanted (possible only on the overflow path)
+    else if (count <= L.cap) T = radix_select(ListSource{list, count}, top_n, s_hist, s_misc);
+    else T = radix_select(RawSource{static_cast<const float *>(L.cls) + static_cast<uint64_t>(b) * L.n, L.n, a.thresh},
+                          top_n, s_hist, s_misc);
+    if (threadIdx.x == 0) s_misc[8] = 0;
+    __syncthreads();
+    auto take = [&](uint64_t key) {
+      if (key >= T) { const uint32_t p = atomicAdd(&s_misc[8], 1u); if (p < kSortCap) s_keys[p] = key; }
+    };
+    if (count <= L.cap) ListSource{list, count}.for_each(take);
+    else RawSource{static_cast<const float *>(L.cls) + static_cast<uint64_t>(b) * L.n, L.n, a.thresh}.for_each(take);
+    n_sort = k_out;
+  }
+  uint32_t n_pow2 = 1;
+  while (n_pow2 < n_sort) n_pow2 <<= 1;
+  for (uint32_t i = n_sort + threadIdx.x; i < n_pow2; i += kSelThreads) s_keys[i] = 0;   // pad: sorts last
+  __syncthreads();
+  if (n_pow2 > 1) bitonic_sort_desc(s_keys, n_pow2);
+
+  // ---- decode + write this segment's slice of the concatenated outputs ----
+  const int H = L.height, W = L.width, A = a.num_anchors, C = a.num_classes;
+  const uint32_t hw = static_cast<uint32_t>(H) * W;
+  const float stride = L.stride;
+  const float lim_x = static_cast<float>(W) * stride - 1.0f;   // box.py:106  M = size*stride - 1
+  const float lim_y = static_cast<float>(H) * stride - 1.0f;
+  const float *deltas = static_cast<const float *>(L.box) + static_cast<uint64_t>(b) * A * NB * hw;
+  const uint64_t out_row = static_cast<uint64_t>(b) * a.n_levels * top_n + static_cast<uint64_t>(l) * top_n;
+
+  for (uint32_t t = threadIdx.x; t < top_n; t += kSelThreads) {
+    float score = 0.0f, cls = 0.0f;
+    float bx[NB];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) bx[k] = 0.0f;
+    int32_t index = -1;
+    if (t < k_out) {
+      const uint64_t key = s_keys[t];
+      const uint32_t i = key_index(key);
+      // the key canonicalises -0.0 to +0.0 for ordering; emit the stored value itself
+      score = static_cast<const float *>(L.cls)[static_cast<uint64_t>(b) * L.n + i];
+      index = static_cast<int32_t>(i);
+      const uint32_t x = i % W;
+      const uint32_t y = (i / W) % H;
+      const uint32_t c = (i / hw) % C;
+      const uint32_t an = i / (hw * C);
+      cls = static_cast<float>(c);
+      float d[NB];
+#pragma unroll
+      for (int k = 0; k < NB; ++k) d[k] = deltas[(static_cast<uint64_t>(an) * NB + k) * hw + static_cast<uint64_t>(y) * W + x];
+      // box.py:302  grid = [x, y, x, y] * stride + anchors[a]
+      const float *anc = L.anchors + 4 * an;
+      const float fx = static_cast<float>(x) * stride, fy = static_cast<float>(y) * stride;
+      const float ax1 = fx + anc[0], ay1 = fy + anc[1], ax2 = fx + anc[2], ay2 = fy + anc[3];
+      // box.py:100-103
+      const float w = ax2 - ax1 + 1.0f, h = ay2 - ay1 + 1.0f;
+      const float cx = ax1 + 0.5f * w, cy = ay1 + 0.5f * h;
+      const float pcx = d[0] * w + cx, pcy = d[1] * h + cy;
+      const float pw = exp_cr(d[2]) * w, ph = exp_cr(d[3]) * h;
+      // box.py:108-111
+      bx[0] = clamp_like_torch(pcx - 0.5f * pw, lim_x);
+      bx[1] = clamp_like_torch(pcy - 0.5f * ph, lim_y);
+      bx[2] = clamp_like_torch(pcx + 0.5f * pw - 1.0f, lim_x);
+      bx[3] = clamp_like_torch(pcy + 0.5f * ph - 1.0f, lim_y);
+      if constexpr (NB == 6) { bx[4] = d[4]; bx[5] = d[5]; }   // sin, cos pass through (decode_rotate.cu:152-162)
+    }
+    a.out_scores[out_row + t] = score;
+    a.out_classes[out_row + t] = cls;
+#pragma unroll
+    for (int k = 0; k < NB; ++k) a.out_boxes[(out_row + t) * NB + k] = bx[k];
+    if (a.out_indices) a.out_indices[out_row + t] = index;
+  }
+}
+
+}  // namespace odtk

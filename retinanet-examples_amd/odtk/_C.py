@@ -1,0 +1,283 @@
+"""odtk._C -- the operator boundary of the reference (csrc/extensions.cpp:184-201), re-homed on
+the MI355X C ABI (include/odtk_hip.h, libodtk_hip.so) through ctypes.
+
+Exposes the reference's three free functions with the SAME positional signatures and return
+conventions, so `from ._C import decode, nms, iou` in a box.py keeps working:
+
+    decode(cls_head, box_head, anchors, scale, score_thresh, top_n, rotated=False) -> [scores, boxes, classes]
+    nms(scores, boxes, classes, nms_thresh, detections_per_im, rotated=False)     -> [scores, boxes, classes]
+    iou(boxes, anchors)                                                           -> [Tensor[num_anchors, num_boxes]]
+    Engine                                                                        -> placeholder (TensorRT dropped)
+
+plus the MI355X-first batched forms (`decode_levels`, `detect`) that cover all pyramid levels of
+the whole batch in one enqueue.
+
+There is NO CPU fallback: tensors must live on the GPU and the shared library must be present
+(build it with `python __graft_entry__.py` or `make -C retinanet-examples_amd/csrc`); anything
+else raises.  Work is only ENQUEUED on torch's current HIP stream -- no host synchronisation
+(the reference blocks the host once per image per level, csrc/cuda/decode.cu:103).
+"""
+import ctypes
+import os
+
+import torch
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libodtk_hip.so')
+
+OK, ERR_INVALID, ERR_WORKSPACE, ERR_HIP, ERR_UNSUPPORTED = 0, -1, -2, -3, -4
+F32, BF16, F16 = 0, 1, 2
+FLAG_ROTATED, FLAG_LOGITS, FLAG_ROTATED_NMS_FIXED_ANGLE = 1, 2, 4
+MAX_LEVELS, MAX_ANCHORS, MAX_TOP_N, MAX_NMS_COUNT = 8, 32, 4096, 7680
+
+_vp = ctypes.c_void_p
+_vpp = ctypes.POINTER(ctypes.c_void_p)
+_fp = ctypes.POINTER(ctypes.c_float)
+_sz = ctypes.c_size_t
+
+
+class Level(ctypes.Structure):
+    """odtk_level_t"""
+    _fields_ = [('cls', _vp), ('box', _vp), ('height', ctypes.c_int32), ('width', ctypes.c_int32),
+                ('stride', ctypes.c_int32), ('channels_last', ctypes.c_int32), ('anchors', _fp)]
+
+
+_SIGNATURES = {
+    'odtk_version': (ctypes.c_char_p, []),
+    'odtk_last_hip_error': (ctypes.c_char_p, []),
+    'odtk_decode': (ctypes.c_int, [ctypes.c_int, _vpp, _vpp, _sz, _sz, _sz, _sz, _sz, _fp, _sz, ctypes.c_float,
+                                   ctypes.c_int, _vp, _sz, _vp]),
+    'odtk_decode_rotate': (ctypes.c_int, [ctypes.c_int, _vpp, _vpp, _sz, _sz, _sz, _sz, _sz, _fp, _sz,
+                                          ctypes.c_float, ctypes.c_int, _vp, _sz, _vp]),
+    'odtk_nms': (ctypes.c_int, [ctypes.c_int, _vpp, _vpp, _sz, ctypes.c_int, ctypes.c_float, _vp, _sz, _vp]),
+    'odtk_nms_rotate': (ctypes.c_int, [ctypes.c_int, _vpp, _vpp, _sz, ctypes.c_int, ctypes.c_float, _vp, _sz, _vp]),
+    'odtk_iou': (ctypes.c_int, [_vpp, _vpp, ctypes.c_int, ctypes.c_int, _vp]),
+    'odtk_decode_levels': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.POINTER(Level), ctypes.c_int,
+                                          ctypes.c_int, ctypes.c_int, ctypes.c_uint32, ctypes.c_float, ctypes.c_int,
+                                          _vpp, ctypes.c_int, _vp, _sz, _vp]),
+    'odtk_nms_ex': (ctypes.c_int, [ctypes.c_int, _vpp, _vpp, ctypes.c_int, _sz, ctypes.c_int, ctypes.c_float,
+                                   ctypes.c_uint32, _vp, _sz, _vp]),
+    'odtk_detect': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.POINTER(Level), ctypes.c_int, ctypes.c_int,
+                                   ctypes.c_int, ctypes.c_uint32, ctypes.c_float, ctypes.c_int, ctypes.c_float,
+                                   ctypes.c_int, _vpp, _vp, _sz, _vp]),
+}
+
+_lib = None
+
+
+def library():
+    """The loaded libodtk_hip.so (raises -- loudly -- if it has not been built)."""
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(_LIB_PATH):
+            raise ImportError('odtk._C: %s is missing -- build the HIP library first '
+                              '(python __graft_entry__.py, or make -C retinanet-examples_amd/csrc). '
+                              'There is no CPU fallback.' % _LIB_PATH)
+        lib = ctypes.CDLL(_LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(lib, name)      # AttributeError if the ABI lost a symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def exported_symbols():
+    return [n for n in _SIGNATURES]
+
+
+_ERR = {ERR_INVALID: 'invalid argument', ERR_WORKSPACE: 'Workspace is too small!',
+        ERR_HIP: 'HIP error', ERR_UNSUPPORTED: 'unsupported dtype/layout'}
+
+
+def _check(rc, what):
+    if rc < 0:
+        detail = library().odtk_last_hip_error().decode() if rc == ERR_HIP else ''
+        raise RuntimeError('%s failed: %s%s' % (what, _ERR.get(rc, 'error %d' % rc), (' (%s)' % detail) if detail else ''))
+    return rc
+
+
+def _check_input(t, name):
+    # csrc/extensions.cpp:42-44  CHECK_CUDA / CHECK_CONTIGUOUS -> RuntimeError
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError('%s must be a CUDA tensor' % name)
+    if not t.is_contiguous():
+        raise RuntimeError('%s must be contiguous' % name)
+    if t.dtype != torch.float32:
+        raise RuntimeError('%s must be float32' % name)
+
+
+def _ptrs(tensors):
+    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() if t is not None else None for t in tensors])
+
+
+_workspaces = {}
+
+
+def _workspace(device, nbytes):
+    """Scratch owned by the binding, cached per (device, stream): never shared between streams."""
+    stream = torch.cuda.current_stream(device)
+    key = (device.index, stream.cuda_stream)
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws, stream.cuda_stream
+
+
+def _anchor_array(anchors):
+    flat = [float(v) for v in anchors]
+    return (ctypes.c_float * len(flat))(*flat), len(flat)
+
+
+def decode(cls_head, box_head, anchors, scale, score_thresh, top_n, rotated=False):
+    """csrc/extensions.cpp:69-115.  `anchors` is the flat python list the reference passes
+    (anchors.view(-1).tolist(), odtk/box.py:263-264)."""
+    _check_input(cls_head, 'cls_head')
+    _check_input(box_head, 'box_head')
+    lib = library()
+    nb = 6 if rotated else 4
+    batch, channels, height, width = cls_head.shape
+    arr, n = _anchor_array(anchors)
+    num_anchors = n // 4
+    num_classes = channels // num_anchors
+    if box_head.shape != (batch, num_anchors * nb, height, width):
+        raise RuntimeError('box_head shape %s does not match cls_head %s' % (tuple(box_head.shape), tuple(cls_head.shape)))
+    fn = lib.odtk_decode_rotate if rotated else lib.odtk_decode
+    with torch.cuda.device(cls_head.device):
+        scores = torch.empty((batch, top_n), dtype=torch.float32, device=cls_head.device)
+        boxes = torch.empty((batch, top_n, nb), dtype=torch.float32, device=cls_head.device)
+        classes = torch.empty((batch, top_n), dtype=torch.float32, device=cls_head.device)
+        size = _check(fn(batch, None, None, height, width, int(scale), num_anchors, num_classes, arr, n,
+                         float(score_thresh), int(top_n), None, 0, None), 'decode (workspace query)')
+        ws, stream = _workspace(cls_head.device, size)
+        _check(fn(batch, _ptrs([cls_head, box_head]), _ptrs([scores, boxes, classes]), height, width, int(scale),
+                  num_anchors, num_classes, arr, n, float(score_thresh), int(top_n), ws.data_ptr(), ws.numel(),
+                  stream), 'decode')
+    return [scores, boxes, classes]
+
+
+def nms(scores, boxes, classes, nms_thresh, detections_per_im, rotated=False, return_indices=False):
+    """csrc/extensions.cpp:117-158."""
+    _check_input(scores, 'scores')
+    _check_input(boxes, 'boxes')
+    _check_input(classes, 'classes')
+    lib = library()
+    nb = 6 if rotated else 4
+    batch, count = scores.shape
+    if boxes.shape != (batch, count, nb) or classes.shape != (batch, count):
+        raise RuntimeError('nms: inconsistent shapes')
+    dev = scores.device
+    with torch.cuda.device(dev):
+        out = [torch.empty((batch, detections_per_im), dtype=torch.float32, device=dev),
+               torch.empty((batch, detections_per_im, nb), dtype=torch.float32, device=dev),
+               torch.empty((batch, detections_per_im), dtype=torch.float32, device=dev)]
+        if return_indices:
+            out.append(torch.empty((batch, detections_per_im), dtype=torch.int32, device=dev))
+        flags = FLAG_ROTATED if rotated else 0
+        size = _check(lib.odtk_nms_ex(batch, None, None, len(out), count, int(detections_per_im), float(nms_thresh),
+                                      flags, None, 0, None), 'nms (workspace query)')
+        ws, stream = _workspace(dev, size)
+        _check(lib.odtk_nms_ex(batch, _ptrs([scores, boxes, classes]), _ptrs(out), len(out), count,
+                               int(detections_per_im), float(nms_thresh), flags, ws.data_ptr(), ws.numel(), stream),
+               'nms')
+    return out
+
+
+def iou(boxes, anchors):
+    """csrc/extensions.cpp:47-67: flat [N*8] box corners, flat [M*8] anchor corners -> [Tensor[M, N]]."""
+    _check_input(boxes, 'boxes')
+    _check_input(anchors, 'anchors')
+    lib = library()
+    num_boxes = boxes.numel() // 8
+    num_anchors = anchors.numel() // 8
+    with torch.cuda.device(boxes.device):
+        out = torch.empty((num_anchors, num_boxes), dtype=torch.float32, device=boxes.device)
+        stream = torch.cuda.current_stream(boxes.device).cuda_stream
+        _check(lib.odtk_iou(_ptrs([boxes, anchors]), _ptrs([out]), num_boxes, num_anchors, stream), 'iou')
+    return [out]
+
+
+def _levels(cls_heads, box_heads, anchors_list, strides, nb):
+    n = len(cls_heads)
+    if not (n == len(box_heads) == len(anchors_list) == len(strides)) or n == 0 or n > MAX_LEVELS:
+        raise RuntimeError('decode_levels: need 1..%d levels with matching lists' % MAX_LEVELS)
+    batch = cls_heads[0].shape[0]
+    arr = (Level * n)()
+    keep = []
+    num_anchors = None
+    for i, (c, b, a, s) in enumerate(zip(cls_heads, box_heads, anchors_list, strides)):
+        _check_input(c, 'cls_head[%d]' % i)
+        _check_input(b, 'box_head[%d]' % i)
+        flat = a.reshape(-1).tolist() if isinstance(a, torch.Tensor) else list(a)
+        carr, ln = _anchor_array(flat)
+        keep.append(carr)
+        if num_anchors is None:
+            num_anchors = ln // 4
+        if ln != 4 * num_anchors or c.shape[0] != batch or b.shape != (batch, num_anchors * nb, c.shape[2], c.shape[3]):
+            raise RuntimeError('decode_levels: inconsistent level %d' % i)
+        arr[i].cls = c.data_ptr()
+        arr[i].box = b.data_ptr()
+        arr[i].height, arr[i].width = c.shape[2], c.shape[3]
+        arr[i].stride = int(s)
+        arr[i].channels_last = 0
+        arr[i].anchors = ctypes.cast(carr, _fp)
+    num_classes = cls_heads[0].shape[1] // num_anchors
+    return arr, keep, batch, num_anchors, num_classes
+
+
+def decode_levels(cls_heads, box_heads, anchors_list, strides, score_thresh, top_n, rotated=False,
+                  return_indices=False):
+    """All levels x whole batch in one enqueue; returns tensors already in the layout of
+    `torch.cat(per_level, 1)` (odtk/model.py:164): [B, L*top_n], [B, L*top_n, nb], [B, L*top_n]."""
+    lib = library()
+    nb = 6 if rotated else 4
+    arr, keep, batch, num_anchors, num_classes = _levels(cls_heads, box_heads, anchors_list, strides, nb)
+    dev = cls_heads[0].device
+    n = len(cls_heads)
+    with torch.cuda.device(dev):
+        out = [torch.empty((batch, n * top_n), dtype=torch.float32, device=dev),
+               torch.empty((batch, n * top_n, nb), dtype=torch.float32, device=dev),
+               torch.empty((batch, n * top_n), dtype=torch.float32, device=dev)]
+        if return_indices:
+            out.append(torch.empty((batch, n * top_n), dtype=torch.int32, device=dev))
+        flags = FLAG_ROTATED if rotated else 0
+        size = _check(lib.odtk_decode_levels(batch, n, arr, num_anchors, num_classes, F32, flags, float(score_thresh),
+                                             int(top_n), None, 0, None, 0, None), 'decode_levels (workspace query)')
+        ws, stream = _workspace(dev, size)
+        _check(lib.odtk_decode_levels(batch, n, arr, num_anchors, num_classes, F32, flags, float(score_thresh),
+                                      int(top_n), _ptrs(out), len(out), ws.data_ptr(), ws.numel(), stream),
+               'decode_levels')
+    return out
+
+
+def detect(cls_heads, box_heads, anchors_list, strides, score_thresh, top_n, nms_thresh, detections_per_im,
+           rotated=False):
+    """decode_levels + nms back to back (the whole of odtk/model.py:153-165), 3 kernel launches."""
+    lib = library()
+    nb = 6 if rotated else 4
+    arr, keep, batch, num_anchors, num_classes = _levels(cls_heads, box_heads, anchors_list, strides, nb)
+    dev = cls_heads[0].device
+    n = len(cls_heads)
+    with torch.cuda.device(dev):
+        out = [torch.empty((batch, detections_per_im), dtype=torch.float32, device=dev),
+               torch.empty((batch, detections_per_im, nb), dtype=torch.float32, device=dev),
+               torch.empty((batch, detections_per_im), dtype=torch.float32, device=dev)]
+        flags = FLAG_ROTATED if rotated else 0
+        args = (batch, n, arr, num_anchors, num_classes, F32, flags, float(score_thresh), int(top_n),
+                float(nms_thresh), int(detections_per_im))
+        size = _check(lib.odtk_detect(*args, None, None, 0, None), 'detect (workspace query)')
+        ws, stream = _workspace(dev, size)
+        _check(lib.odtk_detect(*args, _ptrs(out), ws.data_ptr(), ws.numel(), stream), 'detect')
+    return out
+
+
+class Engine:
+    """Placeholder for the reference's TensorRT engine class (csrc/engine.h): the TensorRT / DALI /
+    DeepStream deployment path is out of scope on MI355X (BASELINE.json north_star)."""
+
+    def __init__(self, *args, **kwargs):
+        raise NotImplementedError('odtk._C.Engine: the TensorRT engine path is not available on MI355X')
+
+    @staticmethod
+    def load(path):
+        raise NotImplementedError('odtk._C.Engine.load: the TensorRT engine path is not available on MI355X')

@@ -1,0 +1,166 @@
+"""odtk.box -- Python surface of the per-anchor post-processing path, MI355X edition.
+
+Same function names, argument order and return conventions as the reference's odtk/box.py
+(generate_anchors :8, generate_anchors_rotated :23, box2delta :67, delta2box :97, decode :255,
+nms :312, nms_rotated :370), so `odtk.model.Model.forward` and user code keep calling
+`decode(cls, box, stride, threshold, top_n, anchors, rotated)` and `nms(scores, boxes, classes,
+nms, ndetections)` unchanged.
+
+Differences, all deliberate:
+  * decode / nms / nms_rotated ALWAYS run the hand-written HIP kernels (libodtk_hip.so via
+    odtk._C).  There is no CPU fallback: CPU tensors raise.  (The reference's CPU branch is kept,
+    restated, under oracle/ as the test oracle only.)
+  * `decode_levels` / `detect` are additions: all pyramid levels x the whole batch in one
+    enqueue, with no host synchronisation.
+"""
+import math
+
+import torch
+
+from . import _C
+
+
+def _grid_of_shapes(ratio_vals, scales_vals):
+    """(scale, ratio) pairs in the reference's order: scale-major, ratio-minor (box.py:11-13)."""
+    scales = torch.tensor([s for s in scales_vals for _ in ratio_vals], dtype=torch.float32).view(-1, 1)
+    ratios = torch.tensor([r for _ in scales_vals for r in ratio_vals], dtype=torch.float32)
+    return scales, ratios
+
+
+def generate_anchors(stride, ratio_vals, scales_vals, angles_vals=None):
+    """Base anchors [A, 4] = [x1, y1, x2, y2] around one stride x stride cell (reference box.py:8-20)."""
+    scales, ratios = _grid_of_shapes(ratio_vals, scales_vals)
+    cell = torch.full((ratios.numel(), 2), float(stride), dtype=torch.float32)
+    side = torch.sqrt(cell[:, 0] * cell[:, 1] / ratios)
+    extent = torch.stack([side, side * ratios], dim=1) * scales
+    return torch.cat([0.5 * (cell - extent), 0.5 * (cell + extent)], dim=1)
+
+
+def _order_quads(quads):
+    """[Q, 4, 2] corner sets -> [tl, tr, br, bl] per quad (reference utils.py:15-31), batched."""
+    by_x = torch.gather(quads, 1, torch.argsort(quads[:, :, 0], dim=1)[:, :, None].expand(-1, -1, 2))
+    left, right = by_x[:, :2], by_x[:, 2:]
+    left = torch.gather(left, 1, torch.argsort(left[:, :, 1], dim=1)[:, :, None].expand(-1, -1, 2))
+    tl, bl = left[:, 0], left[:, 1]
+    dist = torch.cdist(tl[:, None, :], right)[:, 0]                       # [Q, 2]
+    far_first = torch.argsort(dist, dim=1, descending=True)
+    right = torch.gather(right, 1, far_first[:, :, None].expand(-1, -1, 2))
+    br, tr = right[:, 0], right[:, 1]
+    return torch.stack([tl, tr, br, bl], dim=1)
+
+
+def generate_anchors_rotated(stride, ratio_vals, scales_vals, angles_vals):
+    """(axis-aligned [A, 4], rotated corner [A, 8]) anchors, angle-major (reference box.py:23-64).
+    decode only consumes [0] (box.py:258-259); [1] feeds rotated target assignment."""
+    scales, ratios = _grid_of_shapes(ratio_vals, scales_vals)
+    n_shapes = ratios.numel()
+    cell = torch.full((n_shapes, 2), float(stride), dtype=torch.float32)
+    side = torch.round(torch.sqrt(cell[:, 0] * cell[:, 1] / ratios))
+    extent = torch.stack([side, torch.round(side * ratios)], dim=1) * scales
+    p0 = 0.5 * (cell - extent)
+    p2 = 0.5 * (cell + extent) - 1
+    span = p2 - p0
+    p1 = p0 + span * torch.tensor([0.0, 1.0])
+    p3 = p0 + span * torch.tensor([1.0, 0.0])
+
+    angles = torch.tensor(angles_vals, dtype=torch.float32)
+    n_ang = angles.numel()
+    rot = torch.stack([torch.stack([torch.cos(angles), torch.sin(angles)], dim=1),
+                       torch.stack([-torch.sin(angles), torch.cos(angles)], dim=1)], dim=1)   # [n_ang, 2, 2]
+    half = stride / 2
+
+    def spin(p):   # rotate about the cell centre (box.py:50-53), result [n_ang * n_shapes, 2]
+        r = torch.matmul(rot, p.transpose(1, 0) - half + 0.5) + half - 0.5
+        return r.permute(0, 2, 1).contiguous().view(-1, 2)
+
+    axis = torch.cat([p0.repeat(n_ang, 1), p2.repeat(n_ang, 1)], dim=1)
+    corners = _order_quads(torch.stack([spin(p0), spin(p1), spin(p2), spin(p3)], dim=1)).view(-1, 8)
+    return axis, corners
+
+
+def _split_anchor(anchors):
+    size = anchors[:, 2:4] - anchors[:, :2] + 1
+    return size, anchors[:, :2] + 0.5 * size
+
+
+def box2delta(boxes, anchors):
+    """Regression targets of `boxes` w.r.t. `anchors` (+1 pixel convention; reference box.py:67-78)."""
+    a_size, a_ctr = _split_anchor(anchors)
+    b_size, b_ctr = _split_anchor(boxes)
+    return torch.cat([(b_ctr - a_ctr) / a_size, torch.log(b_size / a_size)], 1)
+
+
+def box2delta_rotated(boxes, anchors):
+    """As box2delta plus pass-through (sin, cos) columns (reference box.py:81-94)."""
+    return torch.cat([box2delta(boxes[:, :4], anchors[:, :4]), boxes[:, 4:6]], 1)
+
+
+def delta2box(deltas, anchors, size, stride):
+    """Inverse of box2delta with the two-sided clamp to [0, size*stride-1] (reference box.py:97-111).
+    Pure torch; the inference path does this inside the HIP decode kernel instead."""
+    a_size, a_ctr = _split_anchor(anchors)
+    ctr = deltas[:, :2] * a_size + a_ctr
+    ext = torch.exp(deltas[:, 2:4]) * a_size
+    upper = torch.tensor([size], device=deltas.device, dtype=deltas.dtype) * stride - 1
+    lower = torch.zeros(2, device=deltas.device, dtype=deltas.dtype)
+    lo = torch.max(lower, torch.min(ctr - 0.5 * ext, upper))
+    hi = torch.max(lower, torch.min(ctr + 0.5 * ext - 1, upper))
+    return torch.cat([lo, hi], 1)
+
+
+def delta2box_rotated(deltas, anchors, size, stride):
+    """delta2box + theta = atan2(sin, cos) (reference box.py:114-131)."""
+    return torch.cat([delta2box(deltas[:, :4], anchors[:, :4], size, stride),
+                      torch.atan2(deltas[:, 4], deltas[:, 5])[:, None]], 1)
+
+
+def _require_gpu(t, what):
+    if not t.is_cuda:
+        raise RuntimeError('odtk.box.%s: tensors must be on the GPU -- the MI355X build has no CPU path '
+                           '(the reference CPU algorithm lives in oracle/ as the test oracle)' % what)
+
+
+def decode(all_cls_head, all_box_head, stride=1, threshold=0.05, top_n=1000, anchors=None, rotated=False):
+    """Box decoding and filtering for one pyramid level (reference box.py:255-309).
+
+    cls [B, A*C, H, W] post-sigmoid, box [B, A*{4|6}, H, W] -> scores [B, top_n],
+    boxes [B, top_n, {4|6}], classes [B, top_n] (score-descending, zero padded)."""
+    if rotated:
+        anchors = anchors[0]
+    _require_gpu(all_cls_head, 'decode')
+    return _C.decode(all_cls_head.float().contiguous(), all_box_head.float().contiguous(),
+                     anchors.reshape(-1).tolist(), stride, threshold, top_n, rotated)
+
+
+def nms(all_scores, all_boxes, all_classes, nms=0.5, ndetections=100):
+    """Batched class-aware greedy NMS (reference box.py:312-367)."""
+    _require_gpu(all_scores, 'nms')
+    return _C.nms(all_scores.float().contiguous(), all_boxes.float().contiguous(),
+                  all_classes.float().contiguous(), nms, ndetections, False)
+
+
+def nms_rotated(all_scores, all_boxes, all_classes, nms=0.5, ndetections=100):
+    """NMS on [x1, y1, x2, y2, sin, cos] boxes with polygon IoU (reference box.py:370-375)."""
+    _require_gpu(all_scores, 'nms_rotated')
+    return _C.nms(all_scores.float().contiguous(), all_boxes.float().contiguous(),
+                  all_classes.float().contiguous(), nms, ndetections, True)
+
+
+def decode_levels(cls_heads, box_heads, strides, threshold, top_n, anchors_per_stride, rotated=False):
+    """All levels at once: equals `[torch.cat(t, 1) for t in zip(*[decode(...) per level])]`
+    (reference model.py:153-164) in one enqueue."""
+    anchors = [anchors_per_stride[s][0] if rotated else anchors_per_stride[s] for s in strides]
+    for t in cls_heads:
+        _require_gpu(t, 'decode_levels')
+    return _C.decode_levels([c.float().contiguous() for c in cls_heads], [b.float().contiguous() for b in box_heads],
+                            anchors, strides, threshold, top_n, rotated)
+
+
+def detect(cls_heads, box_heads, strides, anchors_per_stride, threshold=0.05, top_n=1000, nms=0.5,
+           ndetections=100, rotated=False):
+    """decode (all levels) + nms: the whole inference post-processing (reference model.py:153-165)."""
+    anchors = [anchors_per_stride[s][0] if rotated else anchors_per_stride[s] for s in strides]
+    for t in cls_heads:
+        _require_gpu(t, 'detect')
+    return _C.detect([c.float().contiguous() for c in cls_heads], [b.float().contiguous() for b in box_heads],
+                     anchors, strides, threshold, top_n, nms, ndetections, rotated)

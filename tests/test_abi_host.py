@@ -1,0 +1,111 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports every symbol
+include/odtk_hip.h declares, the two-phase workspace queries and argument validation work without
+a GPU (they never touch HIP), and the Python surface mirrors the reference's."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from odtk import _C, box
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RATIOS = [1.0, 2.0, 0.5]
+SCALES = [4 * 2 ** (i / 3) for i in range(3)]
+
+
+def test_every_declared_symbol_is_exported():
+    header = open(os.path.join(ROOT, 'include', 'odtk_hip.h')).read()
+    declared = set(re.findall(r'\b(odtk_[a-z_]+)\s*\(', header))
+    assert {'odtk_decode', 'odtk_decode_rotate', 'odtk_nms', 'odtk_nms_rotate', 'odtk_iou',
+            'odtk_decode_levels', 'odtk_nms_ex', 'odtk_detect'} <= declared
+    lib = _C.library()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert set(_C.exported_symbols()) == declared
+    assert lib.odtk_version().startswith(b'odtk-hip')
+
+
+def test_decode_workspace_query_and_validation():
+    lib = _C.library()
+    anchors = (ctypes.c_float * 36)(*[0.0] * 36)
+    # two-phase convention of the reference (decode.cu:53-72): NULL workspace -> bytes needed
+    size = lib.odtk_decode(8, None, None, 100, 160, 8, 9, 80, anchors, 36, 0.05, 1000, None, 0, None)
+    assert size > 0
+    # candidate pool: min(n, 2^20) keys of 8 B per image (+ counters), 256-B aligned
+    assert size >= 8 * (1 << 20) * 8 and size % 256 == 0
+    small = lib.odtk_decode(2, None, None, 7, 10, 128, 9, 80, anchors, 36, 0.05, 1000, None, 0, None)
+    assert 0 < small < size
+    # validation (never reaches HIP)
+    assert lib.odtk_decode(8, None, None, 0, 160, 8, 9, 80, anchors, 36, 0.05, 1000, None, 0, None) == _C.ERR_INVALID
+    assert lib.odtk_decode(8, None, None, 100, 160, 8, 9, 80, anchors, 35, 0.05, 1000, None, 0, None) == _C.ERR_INVALID
+    assert lib.odtk_decode(8, None, None, 100, 160, 8, 9, 80, anchors, 36, 0.05, _C.MAX_TOP_N + 1, None, 0, None) == _C.ERR_INVALID
+    assert lib.odtk_decode(0, None, None, 100, 160, 8, 9, 80, anchors, 36, 0.05, 1000, None, 0, None) == _C.ERR_INVALID
+    # a too-small workspace is reported, not written through
+    buf = ctypes.create_string_buffer(1024)
+    ins = (ctypes.c_void_p * 2)(1 << 20, 1 << 20)
+    outs = (ctypes.c_void_p * 3)(1 << 20, 1 << 20, 1 << 20)
+    assert lib.odtk_decode(8, ins, outs, 100, 160, 8, 9, 80, anchors, 36, 0.05, 1000,
+                           ctypes.cast(buf, ctypes.c_void_p), 1024, None) == _C.ERR_WORKSPACE
+
+
+def test_nms_workspace_query_and_limits():
+    lib = _C.library()
+    assert lib.odtk_nms(8, None, None, 5000, 100, 0.5, None, 0, None) > 0
+    assert lib.odtk_nms_rotate(8, None, None, 5000, 100, 0.5, None, 0, None) > 0
+    assert lib.odtk_nms(8, None, None, _C.MAX_NMS_COUNT + 1, 100, 0.5, None, 0, None) == _C.ERR_INVALID
+    assert lib.odtk_nms(8, None, None, 0, 100, 0.5, None, 0, None) == _C.ERR_INVALID
+    assert lib.odtk_iou(None, None, 4, 4, None) == _C.ERR_INVALID
+
+
+def test_detect_workspace_covers_decode_plus_candidates():
+    lib = _C.library()
+    anchors = (ctypes.c_float * 36)(*[0.0] * 36)
+    lv = (_C.Level * 2)()
+    for i, (h, w, s) in enumerate([(25, 40, 32), (13, 20, 64)]):
+        lv[i].height, lv[i].width, lv[i].stride = h, w, s
+        lv[i].anchors = ctypes.cast(anchors, ctypes.POINTER(ctypes.c_float))
+    dec = lib.odtk_decode_levels(4, 2, lv, 9, 80, _C.F32, 0, 0.05, 1000, None, 0, None, 0, None)
+    det = lib.odtk_detect(4, 2, lv, 9, 80, _C.F32, 0, 0.05, 1000, 0.5, 100, None, None, 0, None)
+    assert dec > 0 and det >= dec + 4 * 2000 * 6 * 4
+    assert lib.odtk_decode_levels(4, 2, lv, 9, 80, _C.BF16, 0, 0.05, 1000, None, 0, None, 0, None) == _C.ERR_UNSUPPORTED
+
+
+def test_python_surface_has_no_cpu_fallback():
+    cls = torch.rand(1, 9 * 4, 3, 3)
+    deltas = torch.zeros(1, 36, 3, 3)
+    anchors = box.generate_anchors(8, RATIOS, SCALES)
+    with pytest.raises(RuntimeError, match='no CPU path'):
+        box.decode(cls, deltas, 8, 0.05, 10, anchors)
+    with pytest.raises(RuntimeError, match='no CPU path'):
+        box.nms(torch.rand(1, 5), torch.rand(1, 5, 4), torch.zeros(1, 5))
+    with pytest.raises(RuntimeError, match='must be a CUDA tensor'):
+        _C.decode(cls, deltas, anchors.view(-1).tolist(), 8, 0.05, 10)
+    with pytest.raises(NotImplementedError):
+        _C.Engine()
+
+
+def test_anchors_match_reference_fixture(golden_dir):
+    with np.load(os.path.join(golden_dir, 'anchors.npz')) as g:
+        for s in (8, 16, 32, 64, 128):
+            a = box.generate_anchors(s, RATIOS, SCALES).numpy()
+            assert np.array_equal(a.view(np.uint32), g['s%d' % s].view(np.uint32))
+            ax, rot = box.generate_anchors_rotated(s, RATIOS, SCALES, [-np.pi / 6, 0, np.pi / 6])
+            assert np.array_equal(ax.numpy().view(np.uint32), g['rot_axis_s%d' % s].view(np.uint32))
+            assert np.array_equal(rot.numpy().view(np.uint32), g['rot_pts_s%d' % s].view(np.uint32))
+
+
+def test_delta_roundtrip_matches_oracle():
+    from oracle import box_oracle
+    g = torch.Generator().manual_seed(5)
+    anchors = torch.rand(50, 2, generator=g) * 100
+    anchors = torch.cat([anchors, anchors + torch.rand(50, 2, generator=g) * 60 + 4], 1)
+    deltas = torch.randn(50, 4, generator=g) * 0.3
+    mine = box.delta2box(deltas, anchors, [40, 25], 8)
+    ref = box_oracle.delta2box(deltas, anchors, [40, 25], 8)
+    assert torch.equal(mine, ref)
+    back = box.box2delta(mine, anchors)
+    inside = ((mine > 0) & (mine < torch.tensor([319., 199., 319., 199.]))).all(1)
+    assert torch.allclose(back[inside], deltas[inside], atol=1e-4)
