@@ -163,6 +163,20 @@ int odtk_detect(int batch_size, int n_levels, const odtk_level_t *levels,
                 float score_thresh, int top_n, float nms_thresh, int detections_per_im,
                 void *const *outputs, void *workspace, size_t workspace_size, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Measurement hooks (used by bench.py; off by default, zero cost when off).
+ * While enabled, every kernel launch of this library is bracketed by a hipEvent pair recorded on
+ * the launch stream (asynchronous -- still no host synchronisation).  odtk_profile_collect waits
+ * for the recorded events, accumulates per-kernel elapsed milliseconds and launch counts, and
+ * clears the pool.  Kernel ids: */
+#define ODTK_KERNEL_PREFILTER 0   /* prefilter_scan_kernel                         */
+#define ODTK_KERNEL_SELECT    1   /* select_decode_kernel                          */
+#define ODTK_KERNEL_NMS       2   /* nms_kernel                                    */
+#define ODTK_KERNEL_IOU       3   /* iou_pairs_kernel                              */
+#define ODTK_KERNEL_COUNT     4
+int odtk_profile_enable(int on);
+int odtk_profile_collect(double total_ms[ODTK_KERNEL_COUNT], int launches[ODTK_KERNEL_COUNT]);
+
 #ifdef __cplusplus
 }
 #endif

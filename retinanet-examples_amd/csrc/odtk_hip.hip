@@ -9,6 +9,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <vector>
 
 #include "../../include/odtk_hip.h"
 #include "common.hpp"
@@ -30,6 +32,35 @@ int hip_fail(hipError_t e, const char *what) {
     hipError_t e_ = (expr);                                  \
     if (e_ != hipSuccess) return hip_fail(e_, #expr);        \
   } while (0)
+
+// ---- measurement hooks (odtk_profile_*) ------------------------------------------------------
+struct EventPair { hipEvent_t start, stop; };
+struct Profiler {
+  std::mutex mu;
+  bool on = false;
+  std::vector<EventPair> pending[ODTK_KERNEL_COUNT];
+  std::vector<EventPair> spare;
+};
+Profiler g_prof;
+constexpr size_t kMaxPendingEvents = 1 << 16;
+
+struct KernelTimer {   // RAII: records start now and stop at scope exit, on `stream`
+  int id; hipStream_t stream; EventPair ev; bool active = false;
+  KernelTimer(int id_, hipStream_t s) : id(id_), stream(s) {
+    if (!g_prof.on) return;
+    std::lock_guard<std::mutex> lock(g_prof.mu);
+    if (!g_prof.on || g_prof.pending[id].size() >= kMaxPendingEvents) return;
+    if (!g_prof.spare.empty()) { ev = g_prof.spare.back(); g_prof.spare.pop_back(); }
+    else if (hipEventCreate(&ev.start) != hipSuccess || hipEventCreate(&ev.stop) != hipSuccess) return;
+    active = hipEventRecord(ev.start, stream) == hipSuccess;
+  }
+  ~KernelTimer() {
+    if (!active) return;
+    (void)hipEventRecord(ev.stop, stream);
+    std::lock_guard<std::mutex> lock(g_prof.mu);
+    g_prof.pending[id].push_back(ev);
+  }
+};
 
 constexpr size_t kAlign = 256;
 inline size_t align_up(size_t v) { return (v + kAlign - 1) / kAlign * kAlign; }
@@ -143,12 +174,18 @@ int decode_levels_impl(int batch, int n_levels, const odtk_level_t *levels, int 
 
   const int n_seg = batch * n_levels;
   ODTK_HIP_TRY(hipMemsetAsync(counts, 0, sizeof(uint32_t) * n_seg, stream));
-  hipLaunchKernelGGL(odtk::prefilter_scan_kernel, dim3(tiles), dim3(odtk::kScanThreads), 0, stream, sa);
+  {
+    KernelTimer t(ODTK_KERNEL_PREFILTER, stream);
+    hipLaunchKernelGGL(odtk::prefilter_scan_kernel, dim3(tiles), dim3(odtk::kScanThreads), 0, stream, sa);
+  }
   ODTK_HIP_TRY(hipGetLastError());
-  if (flags & ODTK_FLAG_ROTATED)
-    hipLaunchKernelGGL(odtk::select_decode_kernel<6>, dim3(n_seg), dim3(odtk::kSelThreads), 0, stream, da);
-  else
-    hipLaunchKernelGGL(odtk::select_decode_kernel<4>, dim3(n_seg), dim3(odtk::kSelThreads), 0, stream, da);
+  {
+    KernelTimer t(ODTK_KERNEL_SELECT, stream);
+    if (flags & ODTK_FLAG_ROTATED)
+      hipLaunchKernelGGL(odtk::select_decode_kernel<6>, dim3(n_seg), dim3(odtk::kSelThreads), 0, stream, da);
+    else
+      hipLaunchKernelGGL(odtk::select_decode_kernel<4>, dim3(n_seg), dim3(odtk::kSelThreads), 0, stream, da);
+  }
   ODTK_HIP_TRY(hipGetLastError());
   return ODTK_OK;
 }
@@ -167,7 +204,10 @@ int nms_launch(const odtk::NmsArgs &na, int batch, size_t lds, hipStream_t strea
       hipFuncSetAttribute(reinterpret_cast<const void *>(&odtk::nms_kernel<NB>),
                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (attr_err != hipSuccess) return hip_fail(attr_err, "hipFuncSetAttribute(nms_kernel)");
-  hipLaunchKernelGGL(odtk::nms_kernel<NB>, dim3(batch), dim3(odtk::kNmsThreads), lds, stream, na);
+  {
+    KernelTimer t(ODTK_KERNEL_NMS, stream);
+    hipLaunchKernelGGL(odtk::nms_kernel<NB>, dim3(batch), dim3(odtk::kNmsThreads), lds, stream, na);
+  }
   ODTK_HIP_TRY(hipGetLastError());
   return ODTK_OK;
 }
@@ -233,6 +273,31 @@ extern "C" {
 const char *odtk_version(void) { return "odtk-hip 0.1 (gfx950)"; }
 const char *odtk_last_hip_error(void) { return g_last_error; }
 
+int odtk_profile_enable(int on) {
+  std::lock_guard<std::mutex> lock(g_prof.mu);
+  g_prof.on = on != 0;
+  return ODTK_OK;
+}
+
+int odtk_profile_collect(double total_ms[ODTK_KERNEL_COUNT], int launches[ODTK_KERNEL_COUNT]) {
+  if (!total_ms || !launches) return ODTK_ERR_INVALID;
+  std::lock_guard<std::mutex> lock(g_prof.mu);
+  for (int k = 0; k < ODTK_KERNEL_COUNT; ++k) {
+    total_ms[k] = 0.0;
+    launches[k] = 0;
+    for (const EventPair &ev : g_prof.pending[k]) {
+      ODTK_HIP_TRY(hipEventSynchronize(ev.stop));
+      float ms = 0.0f;
+      ODTK_HIP_TRY(hipEventElapsedTime(&ms, ev.start, ev.stop));
+      total_ms[k] += ms;
+      ++launches[k];
+      g_prof.spare.push_back(ev);
+    }
+    g_prof.pending[k].clear();
+  }
+  return ODTK_OK;
+}
+
 int odtk_decode(int batch_size, const void *const *inputs, void *const *outputs, size_t height, size_t width,
                 size_t scale, size_t num_anchors, size_t num_classes, const float *anchors, size_t anchors_len,
                 float score_thresh, int top_n, void *workspace, size_t workspace_size, void *stream) {
@@ -277,10 +342,13 @@ int odtk_iou(const void *const *inputs, void *const *outputs, int num_boxes, int
   const int threads = 256;
   long long blocks = (pairs + threads - 1) / threads;
   if (blocks > 256 * 16) blocks = 256 * 16;                  // grid-stride beyond 16 workgroups per CU
-  hipLaunchKernelGGL(odtk::iou_pairs_kernel, dim3(static_cast<unsigned>(blocks)), dim3(threads), 0,
-                     static_cast<hipStream_t>(stream), static_cast<const float *>(inputs[0]),
-                     static_cast<const float *>(inputs[1]), static_cast<float *>(outputs[0]), num_boxes,
-                     num_anchors);
+  {
+    KernelTimer t(ODTK_KERNEL_IOU, static_cast<hipStream_t>(stream));
+    hipLaunchKernelGGL(odtk::iou_pairs_kernel, dim3(static_cast<unsigned>(blocks)), dim3(threads), 0,
+                       static_cast<hipStream_t>(stream), static_cast<const float *>(inputs[0]),
+                       static_cast<const float *>(inputs[1]), static_cast<float *>(outputs[0]), num_boxes,
+                       num_anchors);
+  }
   ODTK_HIP_TRY(hipGetLastError());
   return ODTK_OK;
 }

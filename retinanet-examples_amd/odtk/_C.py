@@ -59,7 +59,11 @@ _SIGNATURES = {
     'odtk_detect': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.POINTER(Level), ctypes.c_int, ctypes.c_int,
                                    ctypes.c_int, ctypes.c_uint32, ctypes.c_float, ctypes.c_int, ctypes.c_float,
                                    ctypes.c_int, _vpp, _vp, _sz, _vp]),
+    'odtk_profile_enable': (ctypes.c_int, [ctypes.c_int]),
+    'odtk_profile_collect': (ctypes.c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]),
 }
+
+KERNEL_NAMES = ('prefilter_scan_kernel', 'select_decode_kernel', 'nms_kernel', 'iou_pairs_kernel')
 
 _lib = None
 
@@ -269,6 +273,19 @@ def detect(cls_heads, box_heads, anchors_list, strides, score_thresh, top_n, nms
         ws, stream = _workspace(dev, size)
         _check(lib.odtk_detect(*args, _ptrs(out), ws.data_ptr(), ws.numel(), stream), 'detect')
     return out
+
+
+def profile_enable(on=True):
+    """Bracket every kernel launch of the library with a hipEvent pair on its launch stream."""
+    _check(library().odtk_profile_enable(1 if on else 0), 'profile_enable')
+
+
+def profile_collect():
+    """{kernel name: (total ms, launches)} since the last collect (waits for the recorded events)."""
+    ms = (ctypes.c_double * len(KERNEL_NAMES))()
+    n = (ctypes.c_int * len(KERNEL_NAMES))()
+    _check(library().odtk_profile_collect(ms, n), 'profile_collect')
+    return {name: (ms[i], n[i]) for i, name in enumerate(KERNEL_NAMES)}
 
 
 class Engine:

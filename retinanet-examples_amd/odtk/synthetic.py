@@ -61,24 +61,21 @@ def make_unique_scores(scores, threshold=0.0):
     """Nudge duplicate values among the entries >= threshold (per image) by whole ulps until all
     candidate scores of an image are distinct, so that any correct top-k / sort has exactly one
     answer (the reference's torch.topk / unstable torch.sort tie order is arbitrary)."""
-    scores = scores.clone()
+    assert threshold >= 0.0, 'candidates must be non-negative (their bit patterns are then monotonic)'
+    scores = scores.clone().contiguous()
     flat = scores.view(scores.shape[0], -1)
     for b in range(flat.shape[0]):
         row = flat[b]
         cand = (row >= threshold).nonzero().view(-1)
         if cand.numel() < 2:
             continue
-        for _ in range(64):
-            vals = row[cand]
-            srt, order = torch.sort(vals, stable=True)
-            dup = (srt[1:] == srt[:-1]).nonzero().view(-1)
-            if dup.numel() == 0:
-                break
-            # move the later element of each equal pair up by one ulp
-            tgt = cand[order[dup + 1]]
-            row[tgt] = torch.nextafter(row[tgt], torch.full_like(row[tgt], 2.0))
-        else:
-            raise RuntimeError('could not make scores unique')
+        # sort ascending, then enforce strictly increasing BIT PATTERNS with the smallest bumps:
+        # bits'_i = max_{j<=i}(bits_j - j) + i  (>= bits_i, and bits'_i - bits'_{i-1} >= 1)
+        vals, order = torch.sort(row[cand] + 0.0, stable=True)
+        bits = vals.view(torch.int32).to(torch.int64)
+        ramp = torch.arange(bits.numel(), dtype=torch.int64)
+        bits = torch.cummax(bits - ramp, 0).values + ramp
+        row[cand[order]] = bits.to(torch.int32).view(torch.float32)
     return scores
 
 
