@@ -88,7 +88,11 @@ def main():
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp16', 'fp32'])
     ap.add_argument('--sigma', type=float, default=0.573, help='std of the calibrated cls logits')
     ap.add_argument('--cpu-seconds', type=float, default=20.0, help='budget of the cpu_baseline leg (0 = skip)')
-    ap.add_argument('--miopen-find', action='store_true', help='torch.backends.cudnn.benchmark = True')
+    ap.add_argument('--no-miopen-find', action='store_true',
+                    help='torch.backends.cudnn.benchmark = False (MIOpen immediate mode instead of find mode)')
+    ap.add_argument('--postproc', default='fused', choices=['fused', 'reference'],
+                    help="fused: sigmoid+decode+nms read the bf16 channels_last head tensors in place (3 launches); "
+                         "reference: the reference's op sequence (sigmoid, .contiguous(), .float(), decode x5, cat, nms)")
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -101,7 +105,8 @@ def main():
     assert torch.cuda.is_available(), 'bench.py needs a GPU (the post-processing path has no CPU fallback)'
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    torch.backends.cudnn.benchmark = bool(args.miopen_find)
+    miopen_find = not args.no_miopen_find
+    torch.backends.cudnn.benchmark = miopen_find
 
     from odtk import _C
     from odtk.model import Model
@@ -111,6 +116,7 @@ def main():
     model = Model(backbones=args.backbone, classes=80)
     model.initialize(None)
     model = model.to(dev).to(memory_format=torch.channels_last).eval()
+    model.fused_postprocess = args.postproc == 'fused'
 
     g = torch.Generator(device='cpu').manual_seed(rank)
     x = torch.randn(args.batch, 3, args.height, args.width, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
@@ -160,7 +166,10 @@ def main():
     with torch.no_grad(), torch.autocast('cuda', dtype=amp_dtype, enabled=amp_dtype is not None):
         cls_heads, _ = model.heads(x)
     scores_per_batch = sum(c.numel() for c in cls_heads)
-    alg_bytes = 4 * scores_per_batch                       # fp32 boundary: every score read once
+    # every score is read exactly once, in the dtype the kernel consumes: the head's own dtype on the
+    # fused path, fp32 on the reference-sequence path (after torch's .float())
+    bytes_per_score = cls_heads[0].element_size() if model.fused_postprocess else 4
+    alg_bytes = bytes_per_score * scores_per_batch
     ms, n = prof['prefilter_scan_kernel']
     roofline = None
     if n:
@@ -168,7 +177,7 @@ def main():
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
         roofline = {'kernel': 'prefilter_scan_kernel', 'bound': 'hbm', 'achieved': round(achieved, 1),
                     'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
-                    'traffic': None, 'alg_bytes_per_launch': alg_bytes, 'avg_ms': round(avg_ms, 5), 'launches': n}
+                    'traffic': None, 'alg_bytes_per_launch': alg_bytes, 'bytes_per_score': bytes_per_score, 'avg_ms': round(avg_ms, 5), 'launches': n}
     kernels = {k: {'avg_us': round(v[0] / v[1] * 1e3, 2), 'launches': v[1]} for k, v in prof.items() if v[1]}
     conv_tflops = flops_img * (value / world) / 1e12
     conv_roofline = {'bound': 'mfma', 'achieved': round(conv_tflops, 1), 'peak': MFMA_BF16_PEAK_TFLOPS,
@@ -214,7 +223,7 @@ def main():
                                    % (args.backbone, args.dtype, args.batch, args.height, args.width),
                        'global_batch': args.batch * world, 'image': [args.height, args.width],
                        'parallelism': 'replicas x%d (no data-path collective)' % world,
-                       'memory_format': 'channels_last', 'miopen_find': bool(args.miopen_find)},
+                       'memory_format': 'channels_last', 'miopen_find': miopen_find, 'postproc': args.postproc},
             'roofline': roofline, 'conv_roofline': conv_roofline, 'kernels': kernels,
             'cpu_baseline': cpu_baseline,
         }

@@ -12,6 +12,17 @@
 // position asc, +1 pixel IoU, box j (after i) survives iff IoU(i,j) <= thresh or class differs.
 // IoU arithmetic is written in box.py's operation order (-ffp-contract=off).
 //
+// Structure
+//   phase 1  positive-score candidates are compacted (wave ballot + one LDS atomic per wave) into
+//            64-bit (score, ~position) keys and sorted by a bitonic network over pow2(K) keys.
+//   phase 2  thread t owns sorted positions t, t+1024, ...: box / class / area live in REGISTERS;
+//            a copy of box + class goes to LDS (overlaying the keys) for broadcast reads.
+//   phase 3  per kept box: every wave finds the first alive position from a 128-word LDS bitmap
+//            (redundantly -- no extra barrier), tests its own boxes against it, publishes its
+//            bitmap words into the other buffer, ONE barrier.  No global memory traffic inside
+//            the loop (a global store before a barrier costs a full memory round trip per
+//            iteration); the owners write the outputs after the loop.
+//
 // LDS plan (dynamic, <= 160 KiB): sort keys 8 B x pow2(count) are overlaid, after the sort, by
 // the sorted boxes (16|24 B each) + classes (4 B each); a 2 x 128-word alive bitmap follows.
 #pragma once
@@ -81,45 +92,49 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsArgs a) {
   const float *in_b = a.boxes + static_cast<size_t>(img) * count * NB;
   const float *in_c = a.classes + static_cast<size_t>(img) * count;
 
-  // ---- phase 1: keys of positive-score candidates, sorted descending (ties: position asc) ----
+  // ---- phase 1: compact positive-score candidates into keys, sort descending ----
   if (tid == 0) *s_cnt = 0;
   __syncthreads();
-  uint32_t my_pos = 0;
-  for (uint32_t i = tid; i < a.n_pow2; i += kNmsThreads) {
-    uint64_t key = 0;
-    if (i < count) {
-      const float s = in_s[i];
-      if (s > 0.0f) { key = make_key(s, i); ++my_pos; }     // box.py:328  score > 0 (NaN fails)
+  for (uint32_t base = 0; base < count; base += kNmsThreads) {
+    const uint32_t i = base + tid;
+    const float s = i < count ? in_s[i] : 0.0f;
+    const bool pos = s > 0.0f;                              // box.py:328  score > 0 (NaN fails)
+    const uint64_t m = __ballot(pos);
+    if (m) {                                                // wave-uniform
+      uint32_t wbase = 0;
+      if (lane == 0) wbase = atomicAdd(s_cnt, static_cast<uint32_t>(__popcll(m)));
+      wbase = __shfl(wbase, 0, kWave);
+      if (pos) s_keys[wbase + __popcll(m & ((1ull << lane) - 1ull))] = make_key(s, i);
     }
-    s_keys[i] = key;
   }
-  if (my_pos) atomicAdd(s_cnt, my_pos);
   __syncthreads();
   const uint32_t K = *s_cnt;
-  if (a.n_pow2 > 1) {
-    for (uint32_t k = 2; k <= a.n_pow2; k <<= 1) {
-      for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-        for (uint32_t t = tid; t < (a.n_pow2 >> 1); t += kNmsThreads) {
-          const uint32_t lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-          const uint32_t hi = lo | j;
-          const uint64_t x = s_keys[lo], y = s_keys[hi];
-          const bool desc = (lo & k) == 0;
-          if (desc ? (x < y) : (x > y)) { s_keys[lo] = y; s_keys[hi] = x; }
-        }
-        __syncthreads();
+  uint32_t n_sort = 1;
+  while (n_sort < K) n_sort <<= 1;
+  for (uint32_t i = K + tid; i < n_sort; i += kNmsThreads) s_keys[i] = 0;   // pad: sorts last
+  __syncthreads();
+  for (uint32_t k = 2; k <= n_sort; k <<= 1) {
+    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+      for (uint32_t t = tid; t < (n_sort >> 1); t += kNmsThreads) {
+        const uint32_t lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+        const uint32_t hi = lo | j;
+        const uint64_t x = s_keys[lo], y = s_keys[hi];
+        const bool desc = (lo & k) == 0;
+        if (desc ? (x < y) : (x > y)) { s_keys[lo] = y; s_keys[hi] = x; }
       }
+      __syncthreads();
     }
   }
 
   // ---- phase 2: each thread owns sorted positions p = s*1024 + tid; registers keep its boxes ----
   float r_score[kNmsSlots], r_cls[kNmsSlots], r_area[kNmsSlots];
   BoxT<NB> r_box[kNmsSlots];
-  int32_t r_src[kNmsSlots];
+  int32_t r_src[kNmsSlots], r_rank[kNmsSlots];
   uint32_t alive = 0;   // bit s: position s*1024+tid is a candidate that is neither kept nor suppressed
 #pragma unroll
   for (int s = 0; s < kNmsSlots; ++s) {
     const uint32_t p = s * kNmsThreads + tid;
-    r_score[s] = 0.0f; r_cls[s] = 0.0f; r_area[s] = 0.0f; r_src[s] = -1;
+    r_score[s] = 0.0f; r_cls[s] = 0.0f; r_area[s] = 0.0f; r_src[s] = -1; r_rank[s] = -1;
 #pragma unroll
     for (int k = 0; k < NB; ++k) r_box[s].v[k] = 0.0f;
     if (p < K) {
@@ -154,7 +169,7 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsArgs a) {
   }
   __syncthreads();
 
-  // ---- phase 3: one barrier round per kept box ----
+  // ---- phase 3: one barrier round per kept box, LDS traffic only ----
   int kept = 0;
   int buf = 0;
   const int ndet = a.ndet;
@@ -173,19 +188,11 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsArgs a) {
     const uint32_t m = ms * kNmsThreads + mw * 64 + bit;
     const uint32_t m_tid = mw * 64 + bit;
 
-    // the owner emits box m and retires it
+    // the owner retires box m and remembers its output rank (written out after the loop)
     if (static_cast<uint32_t>(tid) == m_tid) {
-      const size_t o = static_cast<size_t>(img) * ndet + kept;
 #pragma unroll
-      for (int s = 0; s < kNmsSlots; ++s) {
-        if (static_cast<uint32_t>(s) == ms) {
-          a.out_scores[o] = r_score[s];
-          a.out_classes[o] = r_cls[s];
-#pragma unroll
-          for (int k = 0; k < NB; ++k) a.out_boxes[o * NB + k] = r_box[s].v[k];
-          if (a.out_indices) a.out_indices[o] = r_src[s];
-        }
-      }
+      for (int s = 0; s < kNmsSlots; ++s)
+        if (static_cast<uint32_t>(s) == ms) r_rank[s] = kept;
       alive &= ~(1u << ms);
     }
     ++kept;
@@ -221,7 +228,18 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsArgs a) {
     __syncthreads();
   }
 
-  // ---- zero-pad the tail (box.py:322-324 outputs start as zeros) ----
+  // ---- outputs: kept boxes by their owners, then the zero-padded tail (box.py:322-324) ----
+#pragma unroll
+  for (int s = 0; s < kNmsSlots; ++s) {
+    if (r_rank[s] >= 0) {
+      const size_t o = static_cast<size_t>(img) * ndet + r_rank[s];
+      a.out_scores[o] = r_score[s];
+      a.out_classes[o] = r_cls[s];
+#pragma unroll
+      for (int k = 0; k < NB; ++k) a.out_boxes[o * NB + k] = r_box[s].v[k];
+      if (a.out_indices) a.out_indices[o] = r_src[s];
+    }
+  }
   for (int t = kept + tid; t < ndet; t += kNmsThreads) {
     const size_t o = static_cast<size_t>(img) * ndet + t;
     a.out_scores[o] = 0.0f;

@@ -6,6 +6,7 @@
 // hipGraph-capturable), enqueue on the caller's stream, return.  No allocation, no host sync.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -85,16 +86,52 @@ struct DecodeLayout {
 int decode_layout(int batch, int n_levels, const odtk_level_t *levels, int A, int C, DecodeLayout *out) {
   size_t off = 0;
   out->counts_off = off;
-  off += align_up(sizeof(uint32_t) * static_cast<size_t>(batch) * n_levels);
+  off += align_up(sizeof(uint32_t) * static_cast<size_t>(batch) * n_levels * odtk::kSubLists);
   for (int l = 0; l < n_levels; ++l) {
     const unsigned long long n = 1ull * A * C * levels[l].height * levels[l].width;
     if (n == 0 || n > 0x7fff0000ull) return ODTK_ERR_INVALID;
     out->n[l] = static_cast<uint32_t>(n);
-    out->cap[l] = n < cand_cap_limit() ? static_cast<uint32_t>(n) : cand_cap_limit();
+    // per sub-list capacity: the segment's capacity min(n, ODTK_CAND_CAP) split kSubLists ways, but
+    // never less than one full tile's worth for tiny levels (a single tile feeds a single sub-list)
+    const unsigned long long seg_cap = n < cand_cap_limit() ? n : cand_cap_limit();
+    unsigned long long sub = (seg_cap + odtk::kSubLists - 1) / odtk::kSubLists;
+    const unsigned long long one_tile = n < static_cast<unsigned long long>(odtk::kTile) ? n : odtk::kTile;
+    if (sub < one_tile && n <= 4ull * odtk::kTile) sub = one_tile;
+    out->cap[l] = static_cast<uint32_t>((sub + 31) / 32 * 32);
     out->cand_off[l] = off;
-    off += align_up(sizeof(uint64_t) * static_cast<size_t>(batch) * out->cap[l]);
+    off += align_up(sizeof(uint64_t) * static_cast<size_t>(batch) * odtk::kSubLists * out->cap[l]);
   }
   out->total = off;
+  return ODTK_OK;
+}
+
+// Conservative raw-domain prefilter for ODTK_FLAG_LOGITS: every x with score_of(x) >= thresh has
+// x >= logit_lower_bound(thresh).  The margin covers the rounding of the sigmoid to bf16/f16
+// (relative 2^-8) and any non-monotonicity of expf by orders of magnitude; elements that pass it
+// are then tested exactly, so a looser bound only costs a few extra exp() evaluations.
+float logit_lower_bound(float thresh) {
+  if (!(thresh > 0.0f)) return -INFINITY;                 // sigmoid > 0 >= thresh: everything passes
+  const double t = static_cast<double>(thresh) * (1.0 - 1.0 / 64.0);
+  if (t >= 1.0) return 0.0f;                              // only saturated scores can pass
+  return static_cast<float>(std::log(t / (1.0 - t)) - 0.01);
+}
+
+template <typename T, bool kLogits>
+int launch_decode(bool rotated, uint32_t tiles, int n_seg, const odtk::ScanArgs &sa, const odtk::DecodeArgs &da,
+                  hipStream_t stream) {
+  {
+    KernelTimer t(ODTK_KERNEL_PREFILTER, stream);
+    hipLaunchKernelGGL((odtk::prefilter_scan_kernel<T, kLogits>), dim3(tiles), dim3(odtk::kScanThreads), 0, stream, sa);
+  }
+  ODTK_HIP_TRY(hipGetLastError());
+  {
+    KernelTimer t(ODTK_KERNEL_SELECT, stream);
+    if (rotated)
+      hipLaunchKernelGGL((odtk::select_decode_kernel<6, T, kLogits>), dim3(n_seg), dim3(odtk::kSelThreads), 0, stream, da);
+    else
+      hipLaunchKernelGGL((odtk::select_decode_kernel<4, T, kLogits>), dim3(n_seg), dim3(odtk::kSelThreads), 0, stream, da);
+  }
+  ODTK_HIP_TRY(hipGetLastError());
   return ODTK_OK;
 }
 
@@ -105,9 +142,9 @@ int decode_levels_impl(int batch, int n_levels, const odtk_level_t *levels, int 
   if (A <= 0 || A > ODTK_MAX_ANCHORS || C <= 0 || top_n <= 0 || top_n > ODTK_MAX_TOP_N) return ODTK_ERR_INVALID;
   for (int l = 0; l < n_levels; ++l)
     if (levels[l].height <= 0 || levels[l].width <= 0) return ODTK_ERR_INVALID;
-  if (dtype != ODTK_F32 || (flags & ODTK_FLAG_LOGITS)) return ODTK_ERR_UNSUPPORTED;
+  if (dtype != ODTK_F32 && dtype != ODTK_BF16 && dtype != ODTK_F16) return ODTK_ERR_UNSUPPORTED;
   for (int l = 0; l < n_levels; ++l)
-    if (levels[l].channels_last) return ODTK_ERR_UNSUPPORTED;
+    if (levels[l].channels_last != 0 && levels[l].channels_last != 1) return ODTK_ERR_INVALID;
 
   DecodeLayout lay;
   int rc = decode_layout(batch, n_levels, levels, A, C, &lay);
@@ -141,7 +178,12 @@ int decode_levels_impl(int batch, int n_levels, const odtk_level_t *levels, int 
     sa.lv[l].tile_begin = tiles;
     sa.lv[l].seg_base = static_cast<uint32_t>(l) * batch;
     sa.lv[l].cap = lay.cap[l];
-    tiles += static_cast<uint32_t>((total + odtk::kTile - 1) / odtk::kTile);
+    sa.lv[l].channels = static_cast<uint32_t>(A) * C;
+    sa.lv[l].hw = static_cast<uint32_t>(levels[l].height) * levels[l].width;
+    sa.lv[l].channels_last = static_cast<uint32_t>(levels[l].channels_last);
+    sa.lv[l].tiles = static_cast<uint32_t>((total + odtk::kTile - 1) / odtk::kTile);
+    sa.lv[l].chunk = (sa.lv[l].tiles + batch - 1) / batch;
+    tiles += sa.lv[l].chunk * batch;                       // launched workgroups (<= batch-1 idle ones)
 
     da.lv[l].cls = levels[l].cls;
     da.lv[l].box = levels[l].box;
@@ -151,6 +193,7 @@ int decode_levels_impl(int batch, int n_levels, const odtk_level_t *levels, int 
     da.lv[l].height = levels[l].height;
     da.lv[l].width = levels[l].width;
     da.lv[l].stride = static_cast<float>(levels[l].stride);
+    da.lv[l].channels_last = static_cast<uint32_t>(levels[l].channels_last);
     std::memcpy(da.lv[l].anchors, levels[l].anchors, sizeof(float) * 4 * A);
   }
   sa.counts = counts;
@@ -158,6 +201,7 @@ int decode_levels_impl(int batch, int n_levels, const odtk_level_t *levels, int 
   sa.n_levels = n_levels;
   sa.batch = batch;
   sa.thresh = thresh;
+  sa.raw_lo = logit_lower_bound(thresh);
 
   da.counts = counts;
   da.cand = cand;
@@ -173,21 +217,16 @@ int decode_levels_impl(int batch, int n_levels, const odtk_level_t *levels, int 
   da.thresh = thresh;
 
   const int n_seg = batch * n_levels;
-  ODTK_HIP_TRY(hipMemsetAsync(counts, 0, sizeof(uint32_t) * n_seg, stream));
-  {
-    KernelTimer t(ODTK_KERNEL_PREFILTER, stream);
-    hipLaunchKernelGGL(odtk::prefilter_scan_kernel, dim3(tiles), dim3(odtk::kScanThreads), 0, stream, sa);
-  }
-  ODTK_HIP_TRY(hipGetLastError());
-  {
-    KernelTimer t(ODTK_KERNEL_SELECT, stream);
-    if (flags & ODTK_FLAG_ROTATED)
-      hipLaunchKernelGGL(odtk::select_decode_kernel<6>, dim3(n_seg), dim3(odtk::kSelThreads), 0, stream, da);
-    else
-      hipLaunchKernelGGL(odtk::select_decode_kernel<4>, dim3(n_seg), dim3(odtk::kSelThreads), 0, stream, da);
-  }
-  ODTK_HIP_TRY(hipGetLastError());
-  return ODTK_OK;
+  ODTK_HIP_TRY(hipMemsetAsync(counts, 0, sizeof(uint32_t) * n_seg * odtk::kSubLists, stream));
+  const bool rotated = (flags & ODTK_FLAG_ROTATED) != 0, logits = (flags & ODTK_FLAG_LOGITS) != 0;
+  if (dtype == ODTK_F32)
+    return logits ? launch_decode<odtk::F32, true>(rotated, tiles, n_seg, sa, da, stream)
+                  : launch_decode<odtk::F32, false>(rotated, tiles, n_seg, sa, da, stream);
+  if (dtype == ODTK_BF16)
+    return logits ? launch_decode<odtk::BF16, true>(rotated, tiles, n_seg, sa, da, stream)
+                  : launch_decode<odtk::BF16, false>(rotated, tiles, n_seg, sa, da, stream);
+  return logits ? launch_decode<odtk::F16, true>(rotated, tiles, n_seg, sa, da, stream)
+                : launch_decode<odtk::F16, false>(rotated, tiles, n_seg, sa, da, stream);
 }
 
 size_t nms_lds_bytes(uint32_t count, uint32_t n_pow2, int nb) {
@@ -334,10 +373,10 @@ int odtk_nms_ex(int batch_size, const void *const *inputs, void *const *outputs,
 }
 
 int odtk_iou(const void *const *inputs, void *const *outputs, int num_boxes, int num_anchors, void *stream) {
-  if (!inputs || !outputs || !inputs[0] || !inputs[1] || !outputs[0]) return ODTK_ERR_INVALID;
   if (num_boxes < 0 || num_anchors < 0) return ODTK_ERR_INVALID;
   const long long pairs = 1ll * num_boxes * num_anchors;
-  if (pairs == 0) return ODTK_OK;
+  if (pairs == 0) return ODTK_OK;                            // empty side: nothing to write
+  if (!inputs || !outputs || !inputs[0] || !inputs[1] || !outputs[0]) return ODTK_ERR_INVALID;
   if (pairs > 0x7fffffffll) return ODTK_ERR_INVALID;
   const int threads = 256;
   long long blocks = (pairs + threads - 1) / threads;

@@ -4,84 +4,215 @@
 //
 // Replaces reference steps D1-D3 (csrc/cuda/decode.cu:96-104: thrust::transform flags ->
 // cub::DeviceSelect::Flagged -> cudaStreamSynchronize + D2H count) for ALL images and levels in
-// one launch, with the count left on the device.
+// one launch, with the count left on the device.  The templated forms additionally replace the
+// three full passes the reference makes BEFORE its op (odtk/model.py:140 sigmoid, :160
+// .contiguous() NHWC->NCHW copy, odtk/box.py:263 .float()): the kernel reads the head tensor as
+// the convolution wrote it (bf16/fp16/fp32, NCHW or channels_last) and applies the sigmoid only
+// to the few elements that can pass the threshold.
 //
-// Roofline: HBM-bound.  Algorithmic bytes = 4 B per score (read once); writes are 8 B per
+// Roofline: HBM-bound.  Algorithmic bytes = sizeof(T) per score, read once; writes are 8 B per
 // survivor (<1 % of the reads at realistic densities).
 //
-// Work decomposition: a "tile" is kTile consecutive elements of one level's flat
-// [batch * A*C*H*W] tensor; one workgroup (4 waves) per tile, each lane issues kVec independent
-// 16-byte loads before it touches any of them (64 KiB in flight per workgroup).  Survivors are
-// counted per lane, block-scanned, and the workgroup reserves its slots with ONE global atomic
-// per tile (per-candidate atomics would serialise on one L2 word per image: ~88 atomics/us).
+// Work decomposition: a "tile" is kTile consecutive elements of one level's flat tensor; one
+// workgroup (4 waves) per tile.
+//   phase A (unrolled, branch-light): each lane issues all of its 16-byte loads, then builds a
+//            64-bit hit mask with ONE compare per element in the raw domain (for logits: against a
+//            conservative lower bound of the logit), takes block-local slots from an LDS atomic
+//            and stages (raw bits, tile offset) pairs in LDS.
+//   phase B (rolled, one call site): the staged entries get the exact test (sigmoid -> dtype
+//            rounding -> `>= thresh`) and become keys.
+//   copy-out: ONE wave reserves the global slots with ONE atomic per tile and writes the keys out
+//            coalesced; the other three waves have already retired, so the ~1 us round trip of a
+//            returning global atomic under streaming load never idles a whole workgroup.
+//            (Per-candidate global atomics would serialise on one L2 word per image: ~88/us.)
+// Tiles with more than kStageCap raw hits (saturated / adversarial inputs) and the <= 1 tile per
+// image that straddles an image boundary take a rolled multi-round path over the same stage.
 #pragma once
+#ifndef ODTK_ABLATE
+#define ODTK_ABLATE 0
+#endif
+
+#include <type_traits>
 
 #include "common.hpp"
 #include "../../include/odtk_hip.h"
 
 namespace odtk {
 
-typedef float vfloat4 __attribute__((ext_vector_type(4)));
+typedef uint32_t vuint4 __attribute__((ext_vector_type(4)));
 
 constexpr int kScanThreads = 256;
-constexpr int kVec = 16;                                  // float4 loads per lane per tile
-constexpr int kTile = kScanThreads * kVec * 4;            // 16384 scores = 64 KiB per workgroup
+constexpr int kTile = 16384;                     // elements per workgroup (64 per lane)
+constexpr int kStageCap = 1024;                  // hits staged in LDS per round (8 KiB)
+constexpr int kSubLists = 16;                    // candidate sub-lists (and counters) per segment
 
 struct ScanLevel {
-  const void *cls;       // level tensor, flat [batch * n]
+  const void *cls;       // level tensor, flat [batch * n] in its own layout
   uint64_t total;        // batch * n
   uint64_t cand_off;     // first key of this level's segment 0 in the candidate pool
   uint32_t n;            // scores per image = A*C*H*W
   uint32_t tile_begin;   // first workgroup of this level
   uint32_t seg_base;     // segment id of (level, image 0) = level * batch
-  uint32_t cap;          // candidate capacity per segment
+  uint32_t cap;          // candidate capacity per SUB-LIST (kSubLists sub-lists per segment)
+  uint32_t channels;     // A*C   (channels_last index mapping)
+  uint32_t hw;           // H*W
+  uint32_t channels_last;
+  uint32_t tiles;        // tiles in this level = ceil(total / kTile)
+  uint32_t chunk;        // tiles per interleave chunk = ceil(tiles / batch)
+  uint32_t pad_;
 };
 
 struct ScanArgs {
   ScanLevel lv[ODTK_MAX_LEVELS];
-  uint32_t *counts;      // [n_levels * batch] survivors per segment (exact, may exceed cap)
+  uint32_t *counts;      // [n_levels * batch][kSubLists] survivors per sub-list (exact, may exceed cap)
   uint64_t *cand;        // candidate pool
   int n_levels;
   int batch;
-  float thresh;
+  float thresh;          // threshold on the SCORE
+  float raw_lo;          // kLogits: conservative lower bound on the raw logit of any survivor
 };
 
+// ---- element types ------------------------------------------------------------------------------
+struct F32 { static constexpr int kPerLoad = 4; using storage = float; };
+struct BF16 { static constexpr int kPerLoad = 8; using storage = uint16_t; };
+struct F16 { static constexpr int kPerLoad = 8; using storage = uint16_t; };
+
+__device__ __forceinline__ float bf16_bits_to_float(uint32_t h) { return __uint_as_float(h << 16); }
+__device__ __forceinline__ float f16_bits_to_float(uint32_t h) {
+  return static_cast<float>(__builtin_bit_cast(_Float16, static_cast<uint16_t>(h)));
+}
+__device__ __forceinline__ float round_to_bf16(float f) {   // round-to-nearest-even, as torch's cast
+  uint32_t b = __float_as_uint(f);
+  if ((b & 0x7fffffffu) > 0x7f800000u) return f;            // NaN
+  b += 0x7fffu + ((b >> 16) & 1u);
+  return __uint_as_float(b & 0xffff0000u);
+}
+__device__ __forceinline__ float round_to_f16(float f) { return static_cast<float>(static_cast<_Float16>(f)); }
+
+// The score the op sees for a raw head value.  kLogits: torch's sigmoid formula
+// (1 / (1 + exp(-x)) in fp32, ATen sigmoid_kernel_cuda) rounded to the tensor's own dtype, i.e.
+// what `cls_head.sigmoid()` followed by `.float()` yields in the reference (model.py:140, box.py:263).
+template <typename T, bool kLogits>
+__device__ __forceinline__ float score_of(float raw) {
+  if constexpr (!kLogits) {
+    return raw;
+  } else {
+    const float s = 1.0f / (1.0f + expf(-raw));
+    if constexpr (std::is_same_v<T, F32>) return s;
+    else if constexpr (std::is_same_v<T, BF16>) return round_to_bf16(s);
+    else return round_to_f16(s);
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ float load_raw(const void *base, uint64_t idx) {
+  if constexpr (std::is_same_v<T, F32>) {
+    return static_cast<const float *>(base)[idx];
+  } else {
+    const uint32_t h = static_cast<const uint16_t *>(base)[idx];
+    return std::is_same_v<T, BF16> ? bf16_bits_to_float(h) : f16_bits_to_float(h);
+  }
+}
+
+// memory offset inside one image -> canonical flat NCHW index (the tie-break order, box.py:291-297)
+__device__ __forceinline__ uint32_t canonical_index(uint32_t r, const ScanLevel &L) {
+  if (!L.channels_last) return r;
+  const uint32_t pix = r / L.channels, ch = r - pix * L.channels;
+  return ch * L.hw + pix;
+}
+// canonical flat NCHW index -> memory offset inside one image
+__device__ __forceinline__ uint32_t memory_offset(uint32_t i, uint32_t channels, uint32_t hw, uint32_t channels_last) {
+  if (!channels_last) return i;
+  const uint32_t ch = i / hw, pix = i - ch * hw;
+  return pix * channels + ch;
+}
+
+template <typename T, bool kLogits>
 __global__ __launch_bounds__(kScanThreads) void prefilter_scan_kernel(const ScanArgs a) {
-  __shared__ uint32_t s_wave_tot[kScanThreads / kWave];
-  __shared__ uint32_t s_base;
+  constexpr int kPer = T::kPerLoad;                        // elements per 16-byte load
+  constexpr int kVec = kTile / (kScanThreads * kPer);      // loads per lane: 16 (f32) or 8 (16-bit)
+  __shared__ uint64_t s_stage[kStageCap];
+  __shared__ uint32_t s_cnt;                               // raw hits staged this round
+  __shared__ uint32_t s_ok;                                // of which pass the exact test
 
   const int tid = threadIdx.x;
+  const int lane = tid & (kWave - 1);
   int l = 0;
 #pragma unroll
   for (int i = 1; i < ODTK_MAX_LEVELS; ++i)
     if (i < a.n_levels && blockIdx.x >= a.lv[i].tile_begin) l = i;
   const ScanLevel &L = a.lv[l];
 
-  const uint64_t tile_base = static_cast<uint64_t>(blockIdx.x - L.tile_begin) * kTile;
-  const uint64_t total = L.total;
+  // Consecutive workgroups take tiles from DIFFERENT images (chunk c ~ image c of the flat level
+  // tensor): workgroups that run together then reserve slots on `batch` different counters.  One
+  // counter word sustains only ~88 returning atomics/us, and walking the tensor front to back keeps
+  // a single image's counter hot at a time (measured: +40 us on a 78 us scan at bs=8).
+  const uint32_t j = blockIdx.x - L.tile_begin;
+  const uint32_t chunk_id = j % static_cast<uint32_t>(a.batch), in_chunk = j / static_cast<uint32_t>(a.batch);
+  const uint32_t tile = chunk_id * L.chunk + in_chunk;
+  if (tile >= L.tiles) return;                            // padding workgroup (block-uniform exit)
+  const uint64_t tile_base = static_cast<uint64_t>(tile) * kTile;
   const uint32_t n = L.n;
   const float thr = a.thresh;
-  const vfloat4 *src = reinterpret_cast<const vfloat4 *>(static_cast<const float *>(L.cls) + tile_base);
-  const uint64_t left = total - tile_base;                 // > 0 by construction
+  const float raw_thr = kLogits ? a.raw_lo : a.thresh;
+  const typename T::storage *tile_ptr = static_cast<const typename T::storage *>(L.cls) + tile_base;
+  const vuint4 *src = reinterpret_cast<const vuint4 *>(tile_ptr);
+  const uint64_t left = L.total - tile_base;               // > 0 by construction
   const uint32_t tile_len = left < kTile ? static_cast<uint32_t>(left) : kTile;
-  const uint32_t n_vec = tile_len >> 2;                    // whole float4s in this tile
+  const uint32_t n_vec = tile_len / kPer;                  // whole 16-byte groups in this tile
 
-  // ---- issue all loads first (kVec x 16 B per lane, fully coalesced: lane-contiguous) ----
-  vfloat4 v[kVec];
+  if (tid == 0) { s_cnt = 0; s_ok = 0; }
+
+  // Every tile appends to ONE of the segment's kSubLists sub-lists (tile % kSubLists): a counter
+  // word sustains only ~88 returning atomics/us and ~30 k tiles per launch all want one, so the
+  // reservations are spread over 16x more words (measured: 116 -> see DESIGN.md us at bs=8).
+  const uint32_t sub = tile % kSubLists;
+  auto counter_of = [&](uint32_t b) -> uint32_t * { return a.counts + (static_cast<size_t>(L.seg_base + b) * kSubLists + sub); };
+  auto list_of = [&](uint32_t b) -> uint64_t * {
+    return a.cand + L.cand_off + (static_cast<uint64_t>(b) * kSubLists + sub) * L.cap;
+  };
+
+  // ---- phase A: issue all loads first (kVec x 16 B per lane, lane-contiguous => coalesced) ----
+  vuint4 v[kVec];
 #pragma unroll
   for (int u = 0; u < kVec; ++u) {
     const uint32_t q = u * kScanThreads + tid;
     if (q < n_vec) v[u] = __builtin_nontemporal_load(src + q);     // streamed once: keep it out of L2's way
-    else v[u] = vfloat4{__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")};
+    else v[u] = std::is_same_v<T, F32> ? vuint4{0x7fc00000u, 0x7fc00000u, 0x7fc00000u, 0x7fc00000u}
+                                       : vuint4{0x7fc07fc0u, 0x7fc07fc0u, 0x7fc07fc0u, 0x7fc07fc0u};   // NaNs
   }
+  __syncthreads();                                         // s_cnt = 0 visible; overlaps the load latency
 
-  // ---- survivor mask: bit (4u+e) <-> element 4*(u*256+tid)+e of the tile (NaN fails >=) ----
+  // element e of load u  <->  tile element kPer*(u*256+tid)+e
+  auto raw_at = [&](int u, int e) -> float {
+    if constexpr (std::is_same_v<T, F32>) {
+      return __uint_as_float(v[u][e]);
+    } else {
+      const uint32_t w = v[u][e >> 1];
+      const uint32_t h = (e & 1) ? (w >> 16) : (w & 0xffffu);
+      return std::is_same_v<T, BF16> ? bf16_bits_to_float(h) : f16_bits_to_float(h);
+    }
+  };
+
+  // storage bits of an element (integer ops only: keeps the converted floats out of registers)
+  auto bits_at = [&](int u, int e) -> uint32_t {
+    if constexpr (std::is_same_v<T, F32>) return v[u][e];
+    else return (v[u][e >> 1] >> (16 * (e & 1))) & 0xffffu;
+  };
+  auto bits_to_raw = [](uint32_t bits) -> float {
+    if constexpr (std::is_same_v<T, F32>) return __uint_as_float(bits);
+    else if constexpr (std::is_same_v<T, BF16>) return bf16_bits_to_float(bits);
+    else return f16_bits_to_float(bits);
+  };
+
+  // hit mask over the lane's 64 elements: bit (kPer*u + e); one compare each, NaN fails >=
   uint64_t mask = 0;
 #pragma unroll
   for (int u = 0; u < kVec; ++u) {
-    uint32_t m = (v[u].x >= thr ? 1u : 0u) | (v[u].y >= thr ? 2u : 0u) | (v[u].z >= thr ? 4u : 0u) |
-                 (v[u].w >= thr ? 8u : 0u);
-    mask |= static_cast<uint64_t>(m) << (4 * u);
+    uint32_t m = 0;
+#pragma unroll
+    for (int e = 0; e < kPer; ++e) m |= (raw_at(u, e) >= raw_thr ? 1u : 0u) << e;
+    mask |= static_cast<uint64_t>(m) << (kPer * u);
   }
   const uint32_t cnt = __popcll(mask);
 
@@ -90,72 +221,117 @@ __global__ __launch_bounds__(kScanThreads) void prefilter_scan_kernel(const Scan
   const uint32_t r0 = static_cast<uint32_t>(tile_base - static_cast<uint64_t>(b0) * n);
   const bool one_image = static_cast<uint64_t>(r0) + tile_len <= n;
 
-  if (__syncthreads_or(cnt != 0)) {
-    if (one_image) {
-      // block-exclusive scan of cnt -> one atomic per tile
-      const uint32_t inc = wave_inclusive_sum(cnt);
-      const int w = tid >> 6;
-      if (lane_id() == kWave - 1) s_wave_tot[w] = inc;
-      __syncthreads();
-      uint32_t wave_off = 0, block_tot = 0;
+  uint32_t off = 0;
+  if (cnt) off = atomicAdd(&s_cnt, cnt);                   // block-local slots (order is irrelevant)
+  if (cnt && off + cnt <= kStageCap) {
+    uint32_t o = off;
 #pragma unroll
-      for (int i = 0; i < kScanThreads / kWave; ++i) {
-        const uint32_t t = s_wave_tot[i];
-        if (i < w) wave_off += t;
-        block_tot += t;
-      }
-      if (tid == 0) s_base = atomicAdd(a.counts + L.seg_base + b0, block_tot);
-      __syncthreads();
-      uint32_t slot = s_base + wave_off + inc - cnt;
-      uint64_t *dst = a.cand + L.cand_off + static_cast<uint64_t>(b0) * L.cap;
+    for (int u = 0; u < kVec; ++u) {
+      const uint32_t m = static_cast<uint32_t>(mask >> (kPer * u)) & ((1u << kPer) - 1u);
+      if (m) {
 #pragma unroll
-      for (int u = 0; u < kVec; ++u) {
-        const uint32_t m = static_cast<uint32_t>(mask >> (4 * u)) & 15u;
-        if (m) {
-          const float e[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
-          const uint32_t idx0 = r0 + 4u * (u * kScanThreads + tid);
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            if (m & (1u << k)) {
-              if (slot < L.cap) dst[slot] = make_key(e[k], idx0 + k);
-              ++slot;
-            }
-          }
-        }
-      }
-    } else {
-      // tile straddles an image boundary (at most once per image per level): per-survivor atomics
-#pragma unroll
-      for (int u = 0; u < kVec; ++u) {
-        const uint32_t m = static_cast<uint32_t>(mask >> (4 * u)) & 15u;
-        if (m) {
-          const float e[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            if (m & (1u << k)) {
-              const uint32_t r = r0 + 4u * (u * kScanThreads + tid) + k;
-              const uint32_t b = b0 + r / n;
-              const uint32_t idx = r % n;
-              const uint32_t slot = atomicAdd(a.counts + L.seg_base + b, 1u);
-              if (slot < L.cap) a.cand[L.cand_off + static_cast<uint64_t>(b) * L.cap + slot] = make_key(e[k], idx);
-            }
-          }
-        }
+        for (int e = 0; e < kPer; ++e)
+          if (m & (1u << e))
+            s_stage[o++] = (static_cast<uint64_t>(bits_at(u, e)) << 32) |
+                           static_cast<uint32_t>(kPer * (u * kScanThreads + tid) + e);
       }
     }
   }
+  __syncthreads();
+  const uint32_t raw_tot = s_cnt;
 
-  // ---- scalar tail of the level (total % 4 elements, last tile only) ----
-  const uint32_t tail = tile_len & 3u;
-  if (tail && tid < tail) {
-    const uint32_t off = (n_vec << 2) + tid;
-    const float s = static_cast<const float *>(L.cls)[tile_base + off];
+  // ---- phase B + copy-out over `cnt_staged` staged (raw bits, tile offset) entries ----
+  // last_round: waves 1..3 may retire before the copy-out (no barrier follows).
+  auto drain = [&](uint32_t cnt_staged, bool last_round) {
+    uint32_t ok_here = 0;
+    for (uint32_t i = tid; i < cnt_staged; i += kScanThreads) {        // exact test, one call site
+      const uint64_t ent = s_stage[i];
+      const float s = score_of<T, kLogits>(bits_to_raw(static_cast<uint32_t>(ent >> 32)));
+      uint64_t key = 0;
+      if (!kLogits || s >= thr) {
+        const uint32_t rr = r0 + static_cast<uint32_t>(ent);            // offset from image b0's start
+        if (one_image) {
+          key = make_key(s, canonical_index(rr, L));
+          ++ok_here;
+        } else {                                                        // boundary tile: own atomics
+          const uint32_t b = b0 + rr / n;
+          const uint32_t slot = atomicAdd(counter_of(b), 1u);
+          if (slot < L.cap) list_of(b)[slot] = make_key(s, canonical_index(rr % n, L));
+        }
+      }
+      s_stage[i] = key;                                                 // 0 = dropped / already written
+    }
+    if (one_image) {
+      const uint64_t bal = __ballot(ok_here != 0);
+      if (bal) {                                                        // wave-uniform
+        uint32_t w = ok_here;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) w += __shfl_xor(w, d, kWave);
+        if (lane == 0) atomicAdd(&s_ok, w);
+      }
+    }
+    __syncthreads();
+    if (!one_image) return;
+    const uint32_t ok_tot = s_ok;
+#if ODTK_ABLATE == 1
+    return;
+#endif
+    if (tid < kWave && ok_tot) {
+      uint32_t base = 0;
+      if (tid == 0) base = atomicAdd(counter_of(b0), ok_tot);
+      base = __shfl(base, 0, kWave);
+      uint64_t *dst = list_of(b0);
+      uint32_t run = base;
+      for (uint32_t i0 = 0; i0 < cnt_staged; i0 += kWave) {
+        const uint64_t key = (i0 + lane < cnt_staged) ? s_stage[i0 + lane] : 0;
+        const uint64_t m = __ballot(key != 0);
+        const uint32_t pos = run + __popcll(m & ((1ull << lane) - 1ull));
+        if (key != 0 && pos < L.cap) dst[pos] = key;
+        run += __popcll(m);
+      }
+    }
+    (void)last_round;
+  };
+
+#if ODTK_ABLATE == 2
+  return;
+#endif
+  if (raw_tot != 0 && raw_tot <= kStageCap) {
+    drain(raw_tot, true);
+  } else if (raw_tot > kStageCap) {
+    // saturated tile: re-walk it in rounds of kStageCap elements (4 per lane), rolled
+    for (uint32_t c0 = 0; c0 < tile_len; c0 += kStageCap) {
+      __syncthreads();
+      if (tid == 0) { s_cnt = 0; s_ok = 0; }
+      __syncthreads();
+#pragma unroll 1
+      for (int k = 0; k < kStageCap / kScanThreads; ++k) {
+        const uint32_t t = c0 + k * kScanThreads + tid;
+        if (t < n_vec * kPer) {
+          const float raw = load_raw<T>(tile_ptr, t);
+          if (raw >= raw_thr) {
+            uint32_t bits;
+            if constexpr (std::is_same_v<T, F32>) bits = __float_as_uint(raw);
+            else bits = static_cast<const uint16_t *>(static_cast<const void *>(tile_ptr))[t];
+            s_stage[atomicAdd(&s_cnt, 1u)] = (static_cast<uint64_t>(bits) << 32) | t;
+          }
+        }
+      }
+      __syncthreads();
+      drain(s_cnt, false);
+    }
+  }
+
+  // ---- scalar tail of the level (total % kPer elements, last tile only) ----
+  const uint32_t tail = tile_len - n_vec * kPer;
+  if (tail && static_cast<uint32_t>(tid) < tail) {
+    const uint32_t toff = n_vec * kPer + tid;
+    const float s = score_of<T, kLogits>(load_raw<T>(tile_ptr, toff));
     if (s >= thr) {
-      const uint64_t r = static_cast<uint64_t>(r0) + off;
+      const uint64_t r = static_cast<uint64_t>(r0) + toff;
       const uint32_t b = b0 + static_cast<uint32_t>(r / n);
-      const uint32_t idx = static_cast<uint32_t>(r % n);
-      const uint32_t slot = atomicAdd(a.counts + L.seg_base + b, 1u);
-      if (slot < L.cap) a.cand[L.cand_off + static_cast<uint64_t>(b) * L.cap + slot] = make_key(s, idx);
+      const uint32_t slot = atomicAdd(counter_of(b), 1u);
+      if (slot < L.cap) list_of(b)[slot] = make_key(s, canonical_index(static_cast<uint32_t>(r % n), L));
     }
   }
 }

@@ -19,6 +19,7 @@
 #pragma once
 
 #include "common.hpp"
+#include "prefilter.hpp"
 #include "../../include/odtk_hip.h"
 
 namespace odtk {
@@ -33,9 +34,10 @@ struct DecodeLevel {
   const void *box;
   uint64_t cand_off;
   uint32_t n;            // A*C*H*W
-  uint32_t cap;
+  uint32_t cap;          // per sub-list
   int32_t height, width;
   float stride;
+  uint32_t channels_last;
   float anchors[ODTK_MAX_ANCHORS * 4];
 };
 
@@ -52,23 +54,34 @@ struct DecodeArgs {
 };
 
 // ---- key sources -------------------------------------------------------------------------
-struct ListSource {   // the compacted candidate list written by prefilter_scan_kernel
-  const uint64_t *keys;
-  uint32_t count;
+struct ListSource {   // the kSubLists compacted candidate sub-lists written by prefilter_scan_kernel
+  const uint64_t *keys;      // sub-list s starts at keys + s * cap
+  const uint32_t *counts;    // [kSubLists]
+  uint32_t cap;
   template <typename F>
   __device__ __forceinline__ void for_each(F &&f) const {
-    for (uint32_t i = threadIdx.x; i < count; i += kSelThreads) f(keys[i]);
+#pragma unroll 1
+    for (int s = 0; s < kSubLists; ++s) {
+      const uint32_t c = counts[s];
+      const uint64_t *k = keys + static_cast<uint64_t>(s) * cap;
+      for (uint32_t i = threadIdx.x; i < c; i += kSelThreads) f(k[i]);
+    }
   }
 };
-struct RawSource {    // the segment's raw scores (overflow path)
-  const float *scores;
-  uint32_t n;
+template <typename T, bool kLogits>
+struct RawSource {    // the segment's raw head values (overflow path); walks memory order
+  const void *image;  // first element of this image
+  uint32_t n, channels, hw, channels_last;
   float thresh;
   template <typename F>
   __device__ __forceinline__ void for_each(F &&f) const {
-    for (uint32_t i = threadIdx.x; i < n; i += kSelThreads) {
-      const float s = scores[i];
-      if (s >= thresh) f(make_key(s, i));
+    for (uint32_t r = threadIdx.x; r < n; r += kSelThreads) {
+      const float s = score_of<T, kLogits>(load_raw<T>(image, r));
+      if (s >= thresh) {
+        uint32_t i = r;
+        if (channels_last) { const uint32_t pix = r / channels, ch = r - pix * channels; i = ch * hw + pix; }
+        f(make_key(s, i));
+      }
     }
   }
 };
@@ -134,7 +147,9 @@ __device__ uint64_t radix_select(const Source &src, uint32_t want, uint32_t *s_h
 }
 
 // ---- the kernel ------------------------------------------------------------------------------
-template <int NB>
+// NB: box parameters (4 axis-aligned, 6 rotated); T: element type of BOTH head tensors;
+// kLogits: cls holds logits (sigmoid fused, see prefilter.hpp score_of).
+template <int NB, typename T, bool kLogits>
 __global__ __launch_bounds__(kSelThreads) void select_decode_kernel(const DecodeArgs a) {
   __shared__ uint64_t s_keys[kSortCap];
   __shared__ uint32_t s_hist[kRadixBins];
@@ -144,29 +159,44 @@ __global__ __launch_bounds__(kSelThreads) void select_decode_kernel(const Decode
   const int l = seg / a.batch;
   const int b = seg - l * a.batch;
   const DecodeLevel &L = a.lv[l];
-  const uint32_t count = a.counts[seg];
+  // exact survivor count = sum over the sub-lists; the lists are complete iff none overflowed
+  const uint32_t *sub_counts = a.counts + static_cast<size_t>(seg) * kSubLists;
+  uint32_t count = 0;
+  bool complete = true;
+#pragma unroll
+  for (int s = 0; s < kSubLists; ++s) {
+    const uint32_t c = sub_counts[s];
+    count += c;
+    complete = complete && c <= L.cap;
+  }
   const uint32_t top_n = a.top_n;
   const uint32_t k_out = count < top_n ? count : top_n;
+  const int H = L.height, W = L.width, A = a.num_anchors, C = a.num_classes;
+  const uint32_t hw = static_cast<uint32_t>(H) * W;
+  const uint32_t channels = static_cast<uint32_t>(A) * C;
+  const typename T::storage *cls_image = static_cast<const typename T::storage *>(L.cls) + static_cast<uint64_t>(b) * L.n;
 
-  const uint64_t *list = a.cand + L.cand_off + static_cast<uint64_t>(b) * L.cap;
+  const ListSource lists{a.cand + L.cand_off + static_cast<uint64_t>(b) * kSubLists * L.cap, sub_counts, L.cap};
   uint32_t n_sort;   // number of valid keys placed in s_keys
 
-  if (count <= kSortCap && count <= L.cap) {
-    for (uint32_t i = threadIdx.x; i < count; i += kSelThreads) s_keys[i] = list[i];
+  if (count <= kSortCap && complete) {
+    if (threadIdx.x == 0) s_misc[8] = 0;
+    __syncthreads();
+    lists.for_each([&](uint64_t key) { s_keys[atomicAdd(&s_misc[8], 1u)] = key; });   // order is irrelevant
     n_sort = count;
   } else {
-    uint64_t T;
-    if (count <= top_n) T = 0;   // everything is wanted (possible only on the overflow path)
-    else if (count <= L.cap) T = radix_select(ListSource{list, count}, top_n, s_hist, s_misc);
-    else T = radix_select(RawSource{static_cast<const float *>(L.cls) + static_cast<uint64_t>(b) * L.n, L.n, a.thresh},
-                          top_n, s_hist, s_misc);
+    const RawSource<T, kLogits> raw{cls_image, L.n, channels, hw, L.channels_last, a.thresh};
+    uint64_t T64;
+    if (count <= top_n) T64 = 0;   // everything is wanted (possible only on the overflow path)
+    else if (complete) T64 = radix_select(lists, top_n, s_hist, s_misc);
+    else T64 = radix_select(raw, top_n, s_hist, s_misc);
     if (threadIdx.x == 0) s_misc[8] = 0;
     __syncthreads();
     auto take = [&](uint64_t key) {
-      if (key >= T) { const uint32_t p = atomicAdd(&s_misc[8], 1u); if (p < kSortCap) s_keys[p] = key; }
+      if (key >= T64) { const uint32_t p = atomicAdd(&s_misc[8], 1u); if (p < kSortCap) s_keys[p] = key; }
     };
-    if (count <= L.cap) ListSource{list, count}.for_each(take);
-    else RawSource{static_cast<const float *>(L.cls) + static_cast<uint64_t>(b) * L.n, L.n, a.thresh}.for_each(take);
+    if (complete) lists.for_each(take);
+    else raw.for_each(take);
     n_sort = k_out;
   }
   uint32_t n_pow2 = 1;
@@ -176,12 +206,10 @@ __global__ __launch_bounds__(kSelThreads) void select_decode_kernel(const Decode
   if (n_pow2 > 1) bitonic_sort_desc(s_keys, n_pow2);
 
   // ---- decode + write this segment's slice of the concatenated outputs ----
-  const int H = L.height, W = L.width, A = a.num_anchors, C = a.num_classes;
-  const uint32_t hw = static_cast<uint32_t>(H) * W;
   const float stride = L.stride;
   const float lim_x = static_cast<float>(W) * stride - 1.0f;   // box.py:106  M = size*stride - 1
   const float lim_y = static_cast<float>(H) * stride - 1.0f;
-  const float *deltas = static_cast<const float *>(L.box) + static_cast<uint64_t>(b) * A * NB * hw;
+  const typename T::storage *box_image = static_cast<const typename T::storage *>(L.box) + static_cast<uint64_t>(b) * A * NB * hw;
   const uint64_t out_row = static_cast<uint64_t>(b) * a.n_levels * top_n + static_cast<uint64_t>(l) * top_n;
 
   for (uint32_t t = threadIdx.x; t < top_n; t += kSelThreads) {
@@ -193,17 +221,24 @@ __global__ __launch_bounds__(kSelThreads) void select_decode_kernel(const Decode
     if (t < k_out) {
       const uint64_t key = s_keys[t];
       const uint32_t i = key_index(key);
-      // the key canonicalises -0.0 to +0.0 for ordering; emit the stored value itself
-      score = static_cast<const float *>(L.cls)[static_cast<uint64_t>(b) * L.n + i];
       index = static_cast<int32_t>(i);
-      const uint32_t x = i % W;
-      const uint32_t y = (i / W) % H;
+      const uint32_t pix = i % hw;
+      const uint32_t x = pix % W, y = pix / W;
       const uint32_t c = (i / hw) % C;
       const uint32_t an = i / (hw * C);
       cls = static_cast<float>(c);
+      if (!kLogits && sizeof(typename T::storage) == 4)
+        // the key canonicalises -0.0 to +0.0 for ordering; emit the stored value itself
+        score = load_raw<T>(cls_image, memory_offset(i, channels, hw, L.channels_last));
+      else
+        score = key_score(key);
       float d[NB];
 #pragma unroll
-      for (int k = 0; k < NB; ++k) d[k] = deltas[(static_cast<uint64_t>(an) * NB + k) * hw + static_cast<uint64_t>(y) * W + x];
+      for (int k = 0; k < NB; ++k) {
+        const uint64_t off = L.channels_last ? static_cast<uint64_t>(pix) * (A * NB) + an * NB + k
+                                             : (static_cast<uint64_t>(an) * NB + k) * hw + pix;
+        d[k] = load_raw<T>(box_image, off);
+      }
       // box.py:302  grid = [x, y, x, y] * stride + anchors[a]
       const float *anc = L.anchors + 4 * an;
       const float fx = static_cast<float>(x) * stride, fy = static_cast<float>(y) * stride;

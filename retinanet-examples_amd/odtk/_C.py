@@ -22,7 +22,7 @@ import os
 
 import torch
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libodtk_hip.so')
+_LIB_PATH = os.environ.get('ODTK_HIP_LIBRARY') or os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libodtk_hip.so')
 
 OK, ERR_INVALID, ERR_WORKSPACE, ERR_HIP, ERR_UNSUPPORTED = 0, -1, -2, -3, -4
 F32, BF16, F16 = 0, 1, 2
@@ -201,17 +201,43 @@ def iou(boxes, anchors):
     return [out]
 
 
+_DTYPES = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
+
+
+def _layout(t, name):
+    """0: NCHW-contiguous, 1: channels_last (NHWC-contiguous).  Anything else is rejected, like the
+    reference's CHECK_CONTIGUOUS (csrc/extensions.cpp:43) -- callers decide where copies happen."""
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError('%s must be a CUDA tensor' % name)
+    if t.dim() != 4:
+        raise RuntimeError('%s must be 4-d [B, C, H, W]' % name)
+    if t.is_contiguous():
+        return 0
+    if t.is_contiguous(memory_format=torch.channels_last):
+        return 1
+    raise RuntimeError('%s must be contiguous (NCHW or channels_last)' % name)
+
+
 def _levels(cls_heads, box_heads, anchors_list, strides, nb):
+    """Fill the odtk_level_t table.  Head tensors are taken AS THE CONVOLUTION WROTE THEM: float32 /
+    bfloat16 / float16, NCHW or channels_last -- no .float(), no .contiguous() (reference
+    model.py:160, box.py:263 make both copies)."""
     n = len(cls_heads)
     if not (n == len(box_heads) == len(anchors_list) == len(strides)) or n == 0 or n > MAX_LEVELS:
         raise RuntimeError('decode_levels: need 1..%d levels with matching lists' % MAX_LEVELS)
     batch = cls_heads[0].shape[0]
+    dtype = cls_heads[0].dtype
+    if dtype not in _DTYPES:
+        raise RuntimeError('decode_levels: unsupported dtype %s' % dtype)
     arr = (Level * n)()
     keep = []
     num_anchors = None
     for i, (c, b, a, s) in enumerate(zip(cls_heads, box_heads, anchors_list, strides)):
-        _check_input(c, 'cls_head[%d]' % i)
-        _check_input(b, 'box_head[%d]' % i)
+        lay = _layout(c, 'cls_head[%d]' % i)
+        if _layout(b, 'box_head[%d]' % i) != lay and b.shape[2] * b.shape[3] > 1:
+            raise RuntimeError('cls_head[%d] and box_head[%d] must share one memory format' % (i, i))
+        if c.dtype != dtype or b.dtype != dtype:
+            raise RuntimeError('decode_levels: all head tensors must share one dtype')
         flat = a.reshape(-1).tolist() if isinstance(a, torch.Tensor) else list(a)
         carr, ln = _anchor_array(flat)
         keep.append(carr)
@@ -223,19 +249,20 @@ def _levels(cls_heads, box_heads, anchors_list, strides, nb):
         arr[i].box = b.data_ptr()
         arr[i].height, arr[i].width = c.shape[2], c.shape[3]
         arr[i].stride = int(s)
-        arr[i].channels_last = 0
+        arr[i].channels_last = lay
         arr[i].anchors = ctypes.cast(carr, _fp)
     num_classes = cls_heads[0].shape[1] // num_anchors
-    return arr, keep, batch, num_anchors, num_classes
+    return arr, keep, batch, num_anchors, num_classes, _DTYPES[dtype]
 
 
 def decode_levels(cls_heads, box_heads, anchors_list, strides, score_thresh, top_n, rotated=False,
-                  return_indices=False):
+                  return_indices=False, logits=False):
     """All levels x whole batch in one enqueue; returns tensors already in the layout of
-    `torch.cat(per_level, 1)` (odtk/model.py:164): [B, L*top_n], [B, L*top_n, nb], [B, L*top_n]."""
+    `torch.cat(per_level, 1)` (odtk/model.py:164): [B, L*top_n], [B, L*top_n, nb], [B, L*top_n].
+    logits=True: cls_heads hold raw logits and the sigmoid is fused into the prefilter."""
     lib = library()
     nb = 6 if rotated else 4
-    arr, keep, batch, num_anchors, num_classes = _levels(cls_heads, box_heads, anchors_list, strides, nb)
+    arr, keep, batch, num_anchors, num_classes, dtype = _levels(cls_heads, box_heads, anchors_list, strides, nb)
     dev = cls_heads[0].device
     n = len(cls_heads)
     with torch.cuda.device(dev):
@@ -244,30 +271,30 @@ def decode_levels(cls_heads, box_heads, anchors_list, strides, score_thresh, top
                torch.empty((batch, n * top_n), dtype=torch.float32, device=dev)]
         if return_indices:
             out.append(torch.empty((batch, n * top_n), dtype=torch.int32, device=dev))
-        flags = FLAG_ROTATED if rotated else 0
-        size = _check(lib.odtk_decode_levels(batch, n, arr, num_anchors, num_classes, F32, flags, float(score_thresh),
+        flags = (FLAG_ROTATED if rotated else 0) | (FLAG_LOGITS if logits else 0)
+        size = _check(lib.odtk_decode_levels(batch, n, arr, num_anchors, num_classes, dtype, flags, float(score_thresh),
                                              int(top_n), None, 0, None, 0, None), 'decode_levels (workspace query)')
         ws, stream = _workspace(dev, size)
-        _check(lib.odtk_decode_levels(batch, n, arr, num_anchors, num_classes, F32, flags, float(score_thresh),
+        _check(lib.odtk_decode_levels(batch, n, arr, num_anchors, num_classes, dtype, flags, float(score_thresh),
                                       int(top_n), _ptrs(out), len(out), ws.data_ptr(), ws.numel(), stream),
                'decode_levels')
     return out
 
 
 def detect(cls_heads, box_heads, anchors_list, strides, score_thresh, top_n, nms_thresh, detections_per_im,
-           rotated=False):
-    """decode_levels + nms back to back (the whole of odtk/model.py:153-165), 3 kernel launches."""
+           rotated=False, logits=False):
+    """decode_levels + nms back to back (the whole of odtk/model.py:140-165), 3 kernel launches."""
     lib = library()
     nb = 6 if rotated else 4
-    arr, keep, batch, num_anchors, num_classes = _levels(cls_heads, box_heads, anchors_list, strides, nb)
+    arr, keep, batch, num_anchors, num_classes, dtype = _levels(cls_heads, box_heads, anchors_list, strides, nb)
     dev = cls_heads[0].device
     n = len(cls_heads)
     with torch.cuda.device(dev):
         out = [torch.empty((batch, detections_per_im), dtype=torch.float32, device=dev),
                torch.empty((batch, detections_per_im, nb), dtype=torch.float32, device=dev),
                torch.empty((batch, detections_per_im), dtype=torch.float32, device=dev)]
-        flags = FLAG_ROTATED if rotated else 0
-        args = (batch, n, arr, num_anchors, num_classes, F32, flags, float(score_thresh), int(top_n),
+        flags = (FLAG_ROTATED if rotated else 0) | (FLAG_LOGITS if logits else 0)
+        args = (batch, n, arr, num_anchors, num_classes, dtype, flags, float(score_thresh), int(top_n),
                 float(nms_thresh), int(detections_per_im))
         size = _check(lib.odtk_detect(*args, None, None, 0, None), 'detect (workspace query)')
         ws, stream = _workspace(dev, size)

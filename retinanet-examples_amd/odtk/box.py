@@ -146,21 +146,43 @@ def nms_rotated(all_scores, all_boxes, all_classes, nms=0.5, ndetections=100):
                   all_classes.float().contiguous(), nms, ndetections, True)
 
 
-def decode_levels(cls_heads, box_heads, strides, threshold, top_n, anchors_per_stride, rotated=False):
+def _as_written(t):
+    """Hand a head tensor to the HIP path as the convolution wrote it: float32 / bfloat16 / float16 in
+    NCHW or channels_last need NO copy; anything else is converted once."""
+    if t.dtype not in (torch.float32, torch.bfloat16, torch.float16):
+        t = t.float()
+    if not (t.is_contiguous() or t.is_contiguous(memory_format=torch.channels_last)):
+        t = t.contiguous()
+    return t
+
+
+def _pair(c, b):
+    c, b = _as_written(c), _as_written(b)
+    if b.dtype != c.dtype:
+        b = b.to(c.dtype)
+    if c.is_contiguous() != b.is_contiguous():      # one memory format per level
+        b = b.contiguous() if c.is_contiguous() else b.contiguous(memory_format=torch.channels_last)
+    return c, b
+
+
+def decode_levels(cls_heads, box_heads, strides, threshold, top_n, anchors_per_stride, rotated=False, logits=False):
     """All levels at once: equals `[torch.cat(t, 1) for t in zip(*[decode(...) per level])]`
-    (reference model.py:153-164) in one enqueue."""
+    (reference model.py:153-164) in one enqueue.  logits=True fuses the sigmoid (model.py:140)."""
     anchors = [anchors_per_stride[s][0] if rotated else anchors_per_stride[s] for s in strides]
     for t in cls_heads:
         _require_gpu(t, 'decode_levels')
-    return _C.decode_levels([c.float().contiguous() for c in cls_heads], [b.float().contiguous() for b in box_heads],
-                            anchors, strides, threshold, top_n, rotated)
+    pairs = [_pair(c, b) for c, b in zip(cls_heads, box_heads)]
+    return _C.decode_levels([p[0] for p in pairs], [p[1] for p in pairs], anchors, strides, threshold, top_n,
+                            rotated, logits=logits)
 
 
 def detect(cls_heads, box_heads, strides, anchors_per_stride, threshold=0.05, top_n=1000, nms=0.5,
-           ndetections=100, rotated=False):
-    """decode (all levels) + nms: the whole inference post-processing (reference model.py:153-165)."""
+           ndetections=100, rotated=False, logits=False):
+    """sigmoid (logits=True) + decode of all levels + nms: the whole inference post-processing of the
+    reference (model.py:140-165) in three kernel launches, reading the head tensors in place."""
     anchors = [anchors_per_stride[s][0] if rotated else anchors_per_stride[s] for s in strides]
     for t in cls_heads:
         _require_gpu(t, 'detect')
-    return _C.detect([c.float().contiguous() for c in cls_heads], [b.float().contiguous() for b in box_heads],
-                     anchors, strides, threshold, top_n, nms, ndetections, rotated)
+    pairs = [_pair(c, b) for c, b in zip(cls_heads, box_heads)]
+    return _C.detect([p[0] for p in pairs], [p[1] for p in pairs], anchors, strides, threshold, top_n, nms,
+                     ndetections, rotated, logits=logits)

@@ -33,6 +33,7 @@ class Model(nn.Module):
         for b in backbones:
             self.unused_modules.extend(getattr(self.backbones, b).features.unused_modules)
         self.exporting = False
+        self.fused_postprocess = True      # False: the reference's op sequence (sigmoid, decode x5, cat, nms)
         self.rotated_bbox = rotated_bbox
         self.anchor_ious = anchor_ious
 
@@ -120,16 +121,26 @@ class Model(nn.Module):
         if self.training:
             return self._compute_loss(x, cls_heads, box_heads, targets.float())
 
-        cls_heads = [c.sigmoid() for c in cls_heads]
-        if self.exporting:
-            self.strides = [x.shape[-1] // c.shape[-1] for c in cls_heads]
-            return cls_heads, box_heads
-
         strides = [x.shape[-1] // c.shape[-1] for c in cls_heads]
+        if self.exporting:
+            self.strides = strides
+            return [c.sigmoid() for c in cls_heads], box_heads
         for s in strides:
             self.level_anchors(s)
-        return box_ops.detect(cls_heads, box_heads, strides, self.anchors, self.threshold, self.top_n,
-                              self.nms, self.detections, self.rotated_bbox)
+
+        if self.fused_postprocess:
+            # sigmoid + decode x5 + nms on the raw head tensors (bf16/fp16/fp32, NCHW or
+            # channels_last) in three launches: no sigmoid pass, no .contiguous(), no .float()
+            return box_ops.detect(cls_heads, box_heads, strides, self.anchors, self.threshold, self.top_n,
+                                  self.nms, self.detections, self.rotated_bbox, logits=True)
+
+        # the reference's sequence, call for call (model.py:140, :153-165)
+        cls_heads = [c.sigmoid() for c in cls_heads]
+        nms_fn = box_ops.nms_rotated if self.rotated_bbox else box_ops.nms
+        decoded = [box_ops.decode(c.contiguous(), b.contiguous(), s, self.threshold, self.top_n, self.anchors[s],
+                                  self.rotated_bbox) for c, b, s in zip(cls_heads, box_heads, strides)]
+        decoded = [torch.cat(t, 1) for t in zip(*decoded)]
+        return nms_fn(*decoded, self.nms, self.detections)
 
     def _extract_targets(self, targets, stride, size):
         snap = box_ops.snap_to_anchors_rotated if self.rotated_bbox else box_ops.snap_to_anchors

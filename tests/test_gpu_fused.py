@@ -1,0 +1,122 @@
+"""The fused fast path: sigmoid + dtype/layout handling inside the prefilter.
+
+Parity argument in two steps, both checked here:
+  (1) SAME BITS AS THE STRICT OP.  detect(raw logits in bf16/fp16/fp32, NCHW or channels_last,
+      logits=True) must equal -- bit for bit, indices included -- the strict-parity fp32/NCHW op fed
+      with what the reference pipeline materialises first: `cls_head.sigmoid()` (model.py:140) ->
+      `.contiguous()` (:160) -> `.float()` (box.py:263), all done by torch on the GPU.
+  (2) THE STRICT OP == THE ORACLE on those same materialised scores (as in test_gpu_parity.py).
+So fused == reference-CPU semantics on the scores torch's own sigmoid kernel produces.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import box_oracle
+from odtk import _C, box, synthetic
+
+pytestmark = pytest.mark.gpu
+
+RATIOS = [1.0, 2.0, 0.5]
+SCALES = [4 * 2 ** (i / 3) for i in range(3)]
+
+
+def head_logits(batch, classes, height, width, kind, seed, dtype, channels_last):
+    strides = (8, 16, 32, 64, 128)
+    cls, dl = [], []
+    for i, (h, w) in enumerate(synthetic.level_shapes(height, width, strides)):
+        lg, d = synthetic.make_level(batch, 9, classes, h, w, kind, seed + i)
+        lg, d = lg.cuda().to(dtype), d.cuda().to(dtype)
+        if channels_last:
+            lg = lg.contiguous(memory_format=torch.channels_last)
+            d = d.contiguous(memory_format=torch.channels_last)
+        cls.append(lg)
+        dl.append(d)
+    return cls, dl, list(strides)
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16, torch.float32], ids=['bf16', 'fp16', 'fp32'])
+@pytest.mark.parametrize('channels_last', [False, True], ids=['nchw', 'nhwc'])
+@pytest.mark.parametrize('kind,seed', [('sparse', 71), ('dense', 72)])
+def test_fused_equals_strict_on_torch_materialised_scores(dtype, channels_last, kind, seed):
+    cls, dl, strides = head_logits(2, 40, 192, 256, kind, seed, dtype, channels_last)
+    anchors = {s: box.generate_anchors(s, RATIOS, SCALES) for s in strides}
+    fused = _C.decode_levels(cls, dl, [anchors[s] for s in strides], strides, 0.05, 400, False,
+                             return_indices=True, logits=True)
+    # the reference pipeline's three passes, by torch
+    scores = [c.sigmoid().contiguous().float() for c in cls]
+    deltas = [d.contiguous().float() for d in dl]
+    strict = _C.decode_levels(scores, deltas, [anchors[s] for s in strides], strides, 0.05, 400, False,
+                              return_indices=True)
+    for f, s, name in zip(fused, strict, ('scores', 'boxes', 'classes', 'indices')):
+        assert torch.equal(f, s), name
+    # (2) strict == oracle on the materialised scores
+    ref = [box_oracle.decode(c.cpu(), d.cpu(), s, 0.05, 400, anchors[s], return_indices=True)
+           for c, d, s in zip(scores, deltas, strides)]
+    ref = [torch.cat(t, 1) for t in zip(*ref)]
+    assert torch.equal(fused[3].cpu().long(), ref[3])
+    assert torch.equal(fused[0].cpu(), ref[0]) and torch.equal(fused[2].cpu(), ref[2])
+    assert (fused[1].cpu() - ref[1]).abs().max() <= 1.3e-4
+    # full detect
+    det = box.detect(cls, dl, strides, anchors, 0.05, 400, 0.5, 100, logits=True)
+    det_ref = box_oracle.nms(ref[0], ref[1], ref[2], 0.5, 100)
+    assert torch.equal(det[0].cpu(), det_ref[0]) and torch.equal(det[2].cpu(), det_ref[2])
+
+
+def test_scores_without_logits_in_16bit_and_nhwc():
+    """dtype / layout generality without the sigmoid: bf16 scores, channels_last."""
+    cls, dl, strides = head_logits(3, 20, 128, 160, 'dense', 81, torch.float32, False)
+    anchors = {s: box.generate_anchors(s, RATIOS, SCALES) for s in strides}
+    scores16 = [c.sigmoid().bfloat16().contiguous(memory_format=torch.channels_last) for c in cls]
+    dl16 = [d.bfloat16().contiguous(memory_format=torch.channels_last) for d in dl]
+    out = _C.decode_levels(scores16, dl16, [anchors[s] for s in strides], strides, 0.05, 300, False, return_indices=True)
+    ref = [box_oracle.decode(c.float().cpu().contiguous(), d.float().cpu().contiguous(), s, 0.05, 300, anchors[s],
+                             return_indices=True) for c, d, s in zip(scores16, dl16, strides)]
+    ref = [torch.cat(t, 1) for t in zip(*ref)]
+    assert torch.equal(out[3].cpu().long(), ref[3])
+    assert torch.equal(out[0].cpu(), ref[0]) and torch.equal(out[2].cpu(), ref[2])
+    assert (out[1].cpu() - ref[1]).abs().max() <= 1.3e-4
+
+
+def test_fused_threshold_edges_and_saturation():
+    """thresholds <= 0 (everything passes), >= 1 (only saturated scores), huge |logits|."""
+    g = torch.Generator().manual_seed(5)
+    lg = (torch.randn(2, 36, 9, 13, generator=g) * 6).cuda().bfloat16().contiguous(memory_format=torch.channels_last)
+    lg[0, 0, 0, :4] = torch.tensor([80.0, -80.0, float('inf'), float('nan')]).cuda().bfloat16()
+    d = (torch.randn(2, 36, 9, 13, generator=g) * 0.2).cuda().bfloat16().contiguous(memory_format=torch.channels_last)
+    anchors = {16: box.generate_anchors(16, RATIOS, SCALES)}
+    for thr in (0.0, -1.0, 0.5, 0.999, 1.0, 1.5):
+        fused = _C.decode_levels([lg], [d], [anchors[16]], [16], thr, 64, False, return_indices=True, logits=True)
+        strict = _C.decode_levels([lg.sigmoid().contiguous().float()], [d.contiguous().float()], [anchors[16]], [16],
+                                  thr, 64, False, return_indices=True)
+        for f, s in zip(fused, strict):
+            assert torch.equal(f, s), thr
+
+
+def test_model_fused_equals_reference_sequence():
+    """Model.forward: the fused 3-launch path == the reference's op sequence (sigmoid, .contiguous(),
+    decode x5, cat, nms) on the same weights, under bf16 autocast + channels_last (config 2 style)."""
+    from odtk.model import Model
+    torch.manual_seed(0)
+    model = Model('ResNet18FPN', classes=20)
+    model.initialize(None)
+    model = model.cuda().to(memory_format=torch.channels_last).eval()
+    x = torch.randn(2, 3, 256, 320, device='cuda').contiguous(memory_format=torch.channels_last)
+    with torch.no_grad(), torch.autocast('cuda', dtype=torch.bfloat16):
+        cls_heads, _ = model.heads(x)
+        sigma = torch.cat([(c.float() - model.cls_head[-1].bias.view(1, -1, 1, 1)).flatten() for c in cls_heads]).std()
+    with torch.no_grad():
+        model.cls_head[-1].weight.mul_(1.0 / sigma)          # make detections exist (class prior = 0.01)
+    with torch.no_grad(), torch.autocast('cuda', dtype=torch.bfloat16):   # fresh context: autocast caches casts
+        # two forward passes of the backbone are not bit-reproducible run to run (library conv
+        # kernels), so both post-processing paths get the SAME head tensors
+        cached = model.heads(x)
+        model.heads = lambda _x: cached
+        assert cached[0][0].dtype == torch.bfloat16 and not cached[0][0].is_contiguous()
+        model.fused_postprocess = True
+        fused = model(x)
+        model.fused_postprocess = False
+        plain = model(x)
+    assert int((fused[0] > 0).sum()) > 50
+    for f, p in zip(fused, plain):
+        assert torch.equal(f, p)

@@ -1,0 +1,93 @@
+"""The C restatement (oracle/c/odtk_oracle.c) against the pinned torch oracle (axis-aligned) and an
+independent float64 polygon clipper (rotated) -- CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import box_oracle, c_oracle
+from odtk import box, synthetic
+
+RATIOS = [1.0, 2.0, 0.5]
+SCALES = [4 * 2 ** (i / 3) for i in range(3)]
+
+
+def random_box6(rng, n, spread=60.0, max_angle=1.5):
+    ctr = rng.uniform(40, 40 + spread, (n, 2))
+    wh = rng.uniform(8, 70, (n, 2))
+    th = rng.uniform(-max_angle, max_angle, n)
+    return np.concatenate([ctr - wh / 2, ctr + wh / 2, np.sin(th)[:, None], np.cos(th)[:, None]], 1).astype(np.float32)
+
+
+@pytest.mark.parametrize('kind,seed', [('dense', 5), ('clustered', 6)])
+def test_c_decode_and_nms_equal_torch_oracle(kind, seed):
+    cls, dl, strides = synthetic.pyramid(2, 9, 20, 128, 192, kind, seed)
+    anchors = {s: box.generate_anchors(s, RATIOS, SCALES) for s in strides}
+    dec = []
+    for c, d, s in zip(cls, dl, strides):
+        t = box_oracle.decode(c, d, s, 0.05, 300, anchors[s], return_indices=True)
+        n = c_oracle.decode(c.numpy(), d.numpy(), s, 0.05, 300, anchors[s].numpy())
+        assert np.array_equal(t[3].numpy(), n[3])                       # selection + order
+        assert np.array_equal(t[0].numpy().view(np.uint32), n[0].view(np.uint32))
+        assert np.array_equal(t[2].numpy(), n[2])
+        # only exp() differs: correctly rounded (C, = HIP) vs torch's vectorised expf -> <= 1 ulp
+        assert np.abs(t[1].numpy() - n[1]).max() <= np.spacing(np.float32(2048.0))
+        dec.append(t[:3])
+    cat = [torch.cat(t, 1) for t in zip(*dec)]
+    t = box_oracle.nms(*cat, 0.5, 100, return_indices=True)
+    n = c_oracle.nms(cat[0].numpy(), cat[1].numpy(), cat[2].numpy(), 0.5, 100)
+    for a, b in zip(t, n):
+        assert np.array_equal(a.numpy(), b)
+
+
+def test_rotated_iou_matches_float64_clipper():
+    rng = np.random.default_rng(0)
+    a, b = random_box6(rng, 2000), random_box6(rng, 2000)
+    worst = 0.0
+    for x, y in zip(a, b):
+        got = c_oracle.rotated_overlap(x, y, own_angle=True)
+        ref = c_oracle.convex_iou_f64(c_oracle.box6_to_quad(y), c_oracle.box6_to_quad(x))
+        worst = max(worst, abs(got - ref))
+    assert worst < 1e-4
+    # the reference's quirk (nms_iou.cu:192): the kept box is rotated by the OTHER box's angle
+    for x, y in zip(a[:300], b[:300]):
+        got = c_oracle.rotated_overlap(x, y, own_angle=False)
+        ref = c_oracle.convex_iou_f64(c_oracle.box6_to_quad(y), c_oracle.box6_to_quad(x, s=y[4], c=y[5]))
+        assert abs(got - ref) < 1e-4
+
+
+def test_rotated_iou_known_answers():
+    sq = np.array([10, 10, 30, 30, 0, 1], np.float32)                 # 20 x 20, angle 0
+    assert abs(c_oracle.rotated_overlap(sq, sq, True) - 1.0) < 1e-3     # identical (0.001 pad path)
+    far = np.array([100, 100, 120, 120, 0, 1], np.float32)
+    assert c_oracle.rotated_overlap(sq, far, True) == 0.0
+    half = np.array([20, 10, 40, 30, 0, 1], np.float32)               # overlap 10x20 of 20x20 each
+    assert abs(c_oracle.rotated_overlap(sq, half, True) - 200.0 / 600.0) < 1e-3
+    rot45 = np.array([10, 10, 30, 30, np.sin(np.pi / 4), np.cos(np.pi / 4)], np.float32)
+    # square vs itself rotated 45 deg about the same centre: octagon area = 2(sqrt2 - 1) * 400
+    inter = 2 * (np.sqrt(2) - 1) * 400
+    assert abs(c_oracle.rotated_overlap(sq, rot45, True) - inter / (800 - inter)) < 1e-3
+
+
+def test_pairwise_iou_layout_and_values():
+    rng = np.random.default_rng(1)
+    gt = np.stack([c_oracle.box6_to_quad(b) for b in random_box6(rng, 5)]).reshape(5, 8).astype(np.float32)
+    an = np.stack([c_oracle.box6_to_quad(b) for b in random_box6(rng, 7)]).reshape(7, 8).astype(np.float32)
+    out = c_oracle.iou_pairs(gt, an)
+    assert out.shape == (7, 5)                                          # [num_anchors, num_boxes]
+    for i in range(7):
+        for j in range(5):
+            assert abs(out[i, j] - c_oracle.convex_iou_f64(an[i].reshape(4, 2), gt[j].reshape(4, 2))) < 1e-4
+
+
+def test_rotated_nms_is_greedy_and_class_aware():
+    rng = np.random.default_rng(2)
+    boxes = random_box6(rng, 400, spread=120.0)[None]
+    scores = rng.permutation(400).astype(np.float32)[None] / 400 + 0.001
+    classes = rng.integers(0, 3, (1, 400)).astype(np.float32)
+    s, b, c, idx = c_oracle.nms(scores, boxes, classes, 0.3, 50, rotated=True)
+    kept = idx[0][idx[0] >= 0]
+    assert len(kept) > 5 and np.all(np.diff(s[0][:len(kept)]) < 0)
+    for a in range(len(kept)):
+        for e in range(a):
+            if classes[0, kept[a]] == classes[0, kept[e]]:
+                assert c_oracle.rotated_overlap(boxes[0, kept[e]], boxes[0, kept[a]], False) <= 0.3
