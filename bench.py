@@ -95,12 +95,8 @@ def main():
                          "reference: the reference's op sequence (sigmoid, .contiguous(), .float(), decode x5, cat, nms)")
     args = ap.parse_args()
 
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', init_method='env://')
+    from odtk import parallel
+    rank, local_rank, world = parallel.init_from_env('nccl')     # "nccl" IS RCCL on ROCm
     assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
     assert torch.cuda.is_available(), 'bench.py needs a GPU (the post-processing path has no CPU fallback)'
     torch.cuda.set_device(local_rank)
@@ -137,27 +133,13 @@ def main():
         torch.cuda.synchronize()
     n_det = int((out[0] > 0).sum().item())
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-
     _C.profile_enable(True)
     _C.profile_collect()
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    # EXACTLY `steps` steps between barrier + device-sync brackets, MAX over ranks (tested on CPU with
+    # gloo, world_size 2: tests/test_parallel_gloo.py)
+    elapsed, out = parallel.timed_steps(step, args.steps, torch.cuda.synchronize, dev)
     _C.profile_enable(False)
     prof = _C.profile_collect()
-
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
 
     images = args.batch * world * args.steps
     value = images / elapsed

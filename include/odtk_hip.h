@@ -47,6 +47,7 @@ extern "C" {
 #define ODTK_MAX_ANCHORS   32      /* anchors per cell (9 axis-aligned, 27 rotated)       */
 #define ODTK_MAX_TOP_N     4096    /* per-level top_n                                     */
 #define ODTK_MAX_NMS_COUNT 7680    /* candidates per image into nms (5 x 1000 by default) */
+#define ODTK_MAX_NMS_DETECTIONS 2048 /* detections_per_im (100 by default)                */
 
 /* element types of the head tensors */
 #define ODTK_F32   0

@@ -1,41 +1,41 @@
-// nms.hpp -- batched greedy class-aware NMS: one 1024-thread workgroup per image, every
-// candidate LDS-resident, at most `detections_per_im` iterations.
+// nms.hpp -- batched greedy class-aware NMS: one 1024-thread workgroup per image, everything
+// LDS-resident, work proportional to the number of boxes actually EXAMINED (not to count^2).
 //
 // Replaces reference steps N1-N7 (csrc/cuda/nms.cu:115-157: flag/select/sync, two radix sorts,
 // nms_kernel<<<1,1024>>> with K serial __syncthreads rounds, gathers) for the whole batch in one
-// launch with no host synchronisation.  The reference kernel runs K (<= 5000) barrier rounds per
-// image although only the first `detections_per_im` survivors are emitted (nms.cu:49-79, :150);
-// the CPU path (box.py:342-361) stops after `ndetections` kept boxes -- so does this kernel: one
-// barrier round per KEPT box.
+// launch with no host synchronisation.
 //
 // Semantics are the CPU path's (box.py:326-365): candidates `score > 0`, ordered score desc /
-// position asc, +1 pixel IoU, box j (after i) survives iff IoU(i,j) <= thresh or class differs.
+// position asc, +1 pixel IoU, a box survives iff no higher-ranked KEPT box of the same class has
+// IoU > thresh with it (`!(iou <= thresh)`), stop after `ndetections` kept boxes.
 // IoU arithmetic is written in box.py's operation order (-ffp-contract=off).
 //
-// Structure
-//   phase 1  positive-score candidates are compacted (wave ballot + one LDS atomic per wave) into
-//            64-bit (score, ~position) keys and sorted by a bitonic network over pow2(K) keys.
-//   phase 2  thread t owns sorted positions t, t+1024, ...: box / class / area live in REGISTERS;
-//            a copy of box + class goes to LDS (overlaying the keys) for broadcast reads.
-//   phase 3  per kept box: every wave finds the first alive position from a 128-word LDS bitmap
-//            (redundantly -- no extra barrier), tests its own boxes against it, publishes its
-//            bitmap words into the other buffer, ONE barrier.  No global memory traffic inside
-//            the loop (a global store before a barrier costs a full memory round trip per
-//            iteration); the owners write the outputs after the loop.
-//
-// LDS plan (dynamic, <= 160 KiB): sort keys 8 B x pow2(count) are overlaid, after the sort, by
-// the sorted boxes (16|24 B each) + classes (4 B each); a 2 x 128-word alive bitmap follows.
+// Why this shape.  The reference (and a straightforward port) lets every kept box "push"
+// suppression onto all later boxes: count x kept IoU evaluations and one barrier per kept box, even
+// though only the first `ndetections` survivors are emitted.  Here the boxes are consumed lazily, in
+// score order, and each candidate "pulls" against the boxes kept so far:
+//   round    : the next 1024 best keys are radix-selected out of the LDS-resident key list and
+//              sorted (bitonic, 1 key per thread) -- a full sort of all candidates never happens
+//              unless the greedy scan really needs them all.
+//   chunk    : 256 candidates.  (1) their threads test them, in parallel, against every box kept
+//              before the chunk; (2) wave 0 walks the chunk's survivors in order, 64 at a time:
+//              pull against the boxes kept earlier in this chunk, then resolve the 64 sequentially
+//              with ballot / readlane -- no barrier inside.
+// Typical inputs (100 detections found among the first few hundred candidates) finish in one round
+// and one or two chunks; the worst case (all one class, heavy suppression) is bounded by
+// count/256 chunks x (<= ndetections parallel IoU tests + 2 barriers).
 #pragma once
 
 #include "common.hpp"
 #include "rotated_iou.hpp"
+#include "select_decode.hpp"   // radix_threshold, bitonic_sort_desc
 #include "../../include/odtk_hip.h"
 
 namespace odtk {
 
 constexpr int kNmsThreads = 1024;
-constexpr int kNmsSlots = 8;                        // sorted positions per thread (8192 max)
-constexpr int kNmsWords = kNmsThreads * kNmsSlots / 64;   // 128 alive words
+constexpr int kNmsRound = 1024;        // keys selected + sorted per round (one per thread)
+constexpr int kNmsChunk = 256;         // candidates resolved per chunk (4 groups of 64)
 
 struct NmsArgs {
   const float *scores;     // [batch, count]
@@ -46,20 +46,36 @@ struct NmsArgs {
   float *out_classes;      // [batch, ndet]
   int32_t *out_indices;    // optional [batch, ndet]
   uint32_t count;
-  uint32_t n_pow2;         // pow2 >= count
   int ndet;
   float thresh;
   uint32_t flags;
 };
 
-template <int NB>
-struct BoxT { float v[NB]; };
+// LDS carve-up shared by host (size) and device (pointers); every offset is 16-byte aligned.
+struct NmsLds {
+  size_t keys, sel, box, cls, kbox, kcls, kscore, ksrc, hist, misc, total;
+  __host__ __device__ NmsLds(uint32_t count, int ndet, int nb) {
+    auto up = [](size_t v) { return (v + 15) & ~static_cast<size_t>(15); };
+    size_t o = 0;
+    keys = o;   o += up(static_cast<size_t>(count) * 8);
+    sel = o;    o += up(kNmsRound * 8);
+    box = o;    o += up(static_cast<size_t>(kNmsRound) * nb * 4);
+    cls = o;    o += up(kNmsRound * 4);
+    kbox = o;   o += up(static_cast<size_t>(ndet) * nb * 4);
+    kcls = o;   o += up(static_cast<size_t>(ndet) * 4);
+    kscore = o; o += up(static_cast<size_t>(ndet) * 4);
+    ksrc = o;   o += up(static_cast<size_t>(ndet) * 4);
+    hist = o;   o += up(kRadixBins * 4);
+    misc = o;   o += up(64 * 4);
+    total = o;
+  }
+};
 
 __device__ __forceinline__ float tmax(float a, float b) { return (a > b || a != a) ? a : b; }
 __device__ __forceinline__ float tmin(float a, float b) { return (a < b || a != a) ? a : b; }
 
-// IoU of the reference's CPU path, box.py:339 + :346-350, in its operation order.
-__device__ __forceinline__ bool axis_suppresses(const float *m, float marea, const float *j, float jarea, float thr) {
+// Does kept box m suppress the lower-ranked box j?  box.py:339 + :346-350, in its operation order.
+__device__ __forceinline__ bool axis_suppresses(const float *m, const float *j, float thr) {
   // torch.max / torch.min / clamp propagate NaN
   const float x1 = tmax(j[0], m[0]), y1 = tmax(j[1], m[1]);
   const float x2 = tmin(j[2], m[2]), y2 = tmin(j[3], m[3]);
@@ -67,33 +83,63 @@ __device__ __forceinline__ bool axis_suppresses(const float *m, float marea, con
   w = w < 0.0f ? 0.0f : w;  // clamp(0)
   h = h < 0.0f ? 0.0f : h;
   const float inter = w * h;
+  const float jarea = (j[2] - j[0] + 1.0f) * (j[3] - j[1] + 1.0f);
+  const float marea = (m[2] - m[0] + 1.0f) * (m[3] - m[1] + 1.0f);
   const float iou = inter / (jarea + marea - inter);
   return !(iou <= thr);
 }
 
 template <int NB>
+__device__ __forceinline__ bool box_suppresses(const float *m, const float *j, float thr, bool own_angle) {
+  if constexpr (NB == 4) return axis_suppresses(m, j, thr);
+  else return rotated_suppresses(m, j, thr, own_angle);
+}
+
+struct LdsKeySource {   // keys of this image that rank below `upper` (exclusive)
+  const uint64_t *keys;
+  uint32_t count;
+  uint64_t upper;
+  template <typename F>
+  __device__ __forceinline__ void for_each(F &&f) const {
+    for (uint32_t i = threadIdx.x; i < count; i += kNmsThreads) {
+      const uint64_t k = keys[i];
+      if (k < upper) f(k);
+    }
+  }
+};
+
+template <int NB>
 __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  uint64_t *s_keys = reinterpret_cast<uint64_t *>(smem);                       // phase 1
-  float *s_box = reinterpret_cast<float *>(smem);                              // phase 2 (overlay)
-  float *s_cls = s_box + static_cast<size_t>(a.count) * NB;
-  const size_t overlay = static_cast<size_t>(a.count) * (NB + 1) * 4;
-  const size_t keys_b = static_cast<size_t>(a.n_pow2) * 8;
-  const size_t bitmap_off = ((overlay > keys_b ? overlay : keys_b) + 15) & ~static_cast<size_t>(15);
-  uint64_t *s_alive = reinterpret_cast<uint64_t *>(smem + bitmap_off);         // [2][kNmsWords]
-  uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_alive + 2 * kNmsWords);
+  const NmsLds lay(a.count, a.ndet, NB);
+  uint64_t *s_keys = reinterpret_cast<uint64_t *>(smem + lay.keys);
+  uint64_t *s_sel = reinterpret_cast<uint64_t *>(smem + lay.sel);
+  float *s_box = reinterpret_cast<float *>(smem + lay.box);
+  float *s_cls = reinterpret_cast<float *>(smem + lay.cls);
+  float *s_kbox = reinterpret_cast<float *>(smem + lay.kbox);
+  float *s_kcls = reinterpret_cast<float *>(smem + lay.kcls);
+  float *s_kscore = reinterpret_cast<float *>(smem + lay.kscore);
+  int32_t *s_ksrc = reinterpret_cast<int32_t *>(smem + lay.ksrc);
+  uint32_t *s_hist = reinterpret_cast<uint32_t *>(smem + lay.hist);
+  uint32_t *s_misc = reinterpret_cast<uint32_t *>(smem + lay.misc);
+  // s_misc: [0..31] radix_select scratch, [32] key count, [33] gather cursor, [34] kept count,
+  //         [40..47] alive words of the current chunk (4 x 64 bits)
+  uint64_t *s_alive = reinterpret_cast<uint64_t *>(s_misc + 40);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int img = blockIdx.x;
   const uint32_t count = a.count;
+  const int ndet = a.ndet;
+  const float thr = a.thresh;
+  const bool own_angle = (a.flags & ODTK_FLAG_ROTATED_NMS_FIXED_ANGLE) != 0;
   const float *in_s = a.scores + static_cast<size_t>(img) * count;
   const float *in_b = a.boxes + static_cast<size_t>(img) * count * NB;
   const float *in_c = a.classes + static_cast<size_t>(img) * count;
 
-  // ---- phase 1: compact positive-score candidates into keys, sort descending ----
-  if (tid == 0) *s_cnt = 0;
+  // ---- compact positive-score candidates into 64-bit (score, ~position) keys ----
+  if (tid == 0) { s_misc[32] = 0; s_misc[34] = 0; }
   __syncthreads();
   for (uint32_t base = 0; base < count; base += kNmsThreads) {
     const uint32_t i = base + tid;
@@ -102,151 +148,131 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsArgs a) {
     const uint64_t m = __ballot(pos);
     if (m) {                                                // wave-uniform
       uint32_t wbase = 0;
-      if (lane == 0) wbase = atomicAdd(s_cnt, static_cast<uint32_t>(__popcll(m)));
+      if (lane == 0) wbase = atomicAdd(&s_misc[32], static_cast<uint32_t>(__popcll(m)));
       wbase = __shfl(wbase, 0, kWave);
       if (pos) s_keys[wbase + __popcll(m & ((1ull << lane) - 1ull))] = make_key(s, i);
     }
   }
   __syncthreads();
-  const uint32_t K = *s_cnt;
-  uint32_t n_sort = 1;
-  while (n_sort < K) n_sort <<= 1;
-  for (uint32_t i = K + tid; i < n_sort; i += kNmsThreads) s_keys[i] = 0;   // pad: sorts last
-  __syncthreads();
-  for (uint32_t k = 2; k <= n_sort; k <<= 1) {
-    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-      for (uint32_t t = tid; t < (n_sort >> 1); t += kNmsThreads) {
-        const uint32_t lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-        const uint32_t hi = lo | j;
-        const uint64_t x = s_keys[lo], y = s_keys[hi];
-        const bool desc = (lo & k) == 0;
-        if (desc ? (x < y) : (x > y)) { s_keys[lo] = y; s_keys[hi] = x; }
-      }
-      __syncthreads();
-    }
-  }
+  const uint32_t K = s_misc[32];
 
-  // ---- phase 2: each thread owns sorted positions p = s*1024 + tid; registers keep its boxes ----
-  float r_score[kNmsSlots], r_cls[kNmsSlots], r_area[kNmsSlots];
-  BoxT<NB> r_box[kNmsSlots];
-  int32_t r_src[kNmsSlots], r_rank[kNmsSlots];
-  uint32_t alive = 0;   // bit s: position s*1024+tid is a candidate that is neither kept nor suppressed
-#pragma unroll
-  for (int s = 0; s < kNmsSlots; ++s) {
-    const uint32_t p = s * kNmsThreads + tid;
-    r_score[s] = 0.0f; r_cls[s] = 0.0f; r_area[s] = 0.0f; r_src[s] = -1; r_rank[s] = -1;
-#pragma unroll
-    for (int k = 0; k < NB; ++k) r_box[s].v[k] = 0.0f;
-    if (p < K) {
-      const uint64_t key = s_keys[p];
-      const uint32_t src = key_index(key);
-      r_src[s] = static_cast<int32_t>(src);
-      r_score[s] = in_s[src];
-      r_cls[s] = in_c[src];
-#pragma unroll
-      for (int k = 0; k < NB; ++k) r_box[s].v[k] = in_b[static_cast<size_t>(src) * NB + k];
-      // box.py:339  areas = (x2 - x1 + 1) * (y2 - y1 + 1)
-      r_area[s] = (r_box[s].v[2] - r_box[s].v[0] + 1.0f) * (r_box[s].v[3] - r_box[s].v[1] + 1.0f);
-      alive |= 1u << s;
-    }
-  }
-  __syncthreads();   // every key has been consumed: the overlay may be written
-#pragma unroll
-  for (int s = 0; s < kNmsSlots; ++s) {
-    const uint32_t p = s * kNmsThreads + tid;
-    if (p < K) {
-#pragma unroll
-      for (int k = 0; k < NB; ++k) s_box[static_cast<size_t>(p) * NB + k] = r_box[s].v[k];
-      s_cls[p] = r_cls[s];
-    }
-  }
-  // alive bitmap: word (s*16 + wave) bit lane  <->  position s*1024 + wave*64 + lane
-  const uint32_t n_slots = (K + kNmsThreads - 1) / kNmsThreads;   // slots that can be alive
-#pragma unroll
-  for (int s = 0; s < kNmsSlots; ++s) {
-    const uint64_t word = __ballot((alive >> s) & 1u);
-    if (lane == 0) { s_alive[s * 16 + wave] = word; s_alive[kNmsWords + s * 16 + wave] = 0; }
-  }
-  __syncthreads();
+  uint32_t consumed = 0;             // candidates handed to earlier rounds
+  uint64_t upper = ~0ull;            // keys >= upper were consumed
+  int kept = 0;                      // block-uniform copy of s_misc[34]
 
-  // ---- phase 3: one barrier round per kept box, LDS traffic only ----
-  int kept = 0;
-  int buf = 0;
-  const int ndet = a.ndet;
-  while (kept < ndet) {
-    // every wave finds the first alive position redundantly (no extra barrier)
-    const uint64_t w0 = s_alive[buf * kNmsWords + lane];
-    const uint64_t w1 = s_alive[buf * kNmsWords + 64 + lane];
-    const uint64_t nz0 = __ballot(w0 != 0), nz1 = __ballot(w1 != 0);
-    if ((nz0 | nz1) == 0) break;
-    uint32_t widx; uint64_t wval;
-    if (nz0) { widx = __ffsll(static_cast<unsigned long long>(nz0)) - 1; wval = __shfl(w0, widx, kWave); }
-    else { widx = __ffsll(static_cast<unsigned long long>(nz1)) - 1; wval = __shfl(w1, widx, kWave); widx += 64; }
-    const uint32_t bit = __ffsll(static_cast<unsigned long long>(wval)) - 1;
-    // word widx = s*16 + w  ->  position s*1024 + w*64 + bit
-    const uint32_t ms = widx >> 4, mw = widx & 15;
-    const uint32_t m = ms * kNmsThreads + mw * 64 + bit;
-    const uint32_t m_tid = mw * 64 + bit;
+  while (consumed < K && kept < ndet) {
+    // ---- round: select + sort the next (up to) 1024 best keys ----
+    const uint32_t left = K - consumed;
+    uint32_t n_round = left;
+    const LdsKeySource src{s_keys, K, upper};
+    uint64_t lower = 0;
+    // any top-prefix of 256..1024 keys will do for a round: stop the radix descent early
+    if (left > kNmsRound) lower = radix_threshold(src, kNmsChunk, kNmsRound, s_hist, s_misc, &n_round);
+    if (tid == 0) s_misc[33] = 0;
+    __syncthreads();
+    src.for_each([&](uint64_t key) { if (key >= lower) s_sel[atomicAdd(&s_misc[33], 1u)] = key; });
+    for (uint32_t i = n_round + tid; i < kNmsRound; i += kNmsThreads) s_sel[i] = 0;   // pad: sorts last
+    __syncthreads();
+    bitonic_sort_desc(s_sel, kNmsRound);
+    upper = lower;
+    consumed += n_round;
 
-    // the owner retires box m and remembers its output rank (written out after the loop)
-    if (static_cast<uint32_t>(tid) == m_tid) {
+    // thread t <-> rank `t` of this round: stage its box + class in LDS
+    if (static_cast<uint32_t>(tid) < n_round) {
+      const uint32_t p = key_index(s_sel[tid]);
 #pragma unroll
-      for (int s = 0; s < kNmsSlots; ++s)
-        if (static_cast<uint32_t>(s) == ms) r_rank[s] = kept;
-      alive &= ~(1u << ms);
-    }
-    ++kept;
-    if (kept == ndet) break;
-
-    // everyone tests its still-alive later boxes against box m (LDS broadcast reads)
-    float mb[NB];
-#pragma unroll
-    for (int k = 0; k < NB; ++k) mb[k] = s_box[static_cast<size_t>(m) * NB + k];
-    const float mcls = s_cls[m];
-    const float marea = (mb[2] - mb[0] + 1.0f) * (mb[3] - mb[1] + 1.0f);
-#pragma unroll
-    for (int s = 0; s < kNmsSlots; ++s) {
-      if ((alive >> s) & 1u) {
-        const uint32_t p = s * kNmsThreads + tid;
-        if (p > m && r_cls[s] == mcls) {          // box.py:351  classes != classes[i] keeps
-          bool sup;
-          if (NB == 4) sup = axis_suppresses(mb, marea, r_box[s].v, r_area[s], a.thresh);
-          else sup = rotated_suppresses(mb, r_box[s].v, a.thresh, (a.flags & ODTK_FLAG_ROTATED_NMS_FIXED_ANGLE) != 0);
-          if (sup) alive &= ~(1u << s);
-        }
-      }
-    }
-    // publish the new bitmap into the other buffer
-    buf ^= 1;
-#pragma unroll
-    for (int s = 0; s < kNmsSlots; ++s) {
-      if (static_cast<uint32_t>(s) < n_slots) {
-        const uint64_t word = __ballot((alive >> s) & 1u);
-        if (lane == 0) s_alive[buf * kNmsWords + s * 16 + wave] = word;
-      }
+      for (int k = 0; k < NB; ++k) s_box[tid * NB + k] = in_b[static_cast<size_t>(p) * NB + k];
+      s_cls[tid] = in_c[p];
     }
     __syncthreads();
-  }
 
-  // ---- outputs: kept boxes by their owners, then the zero-padded tail (box.py:322-324) ----
+    // ---- chunks of 256 candidates ----
+    for (uint32_t c0 = 0; c0 < n_round && kept < ndet; c0 += kNmsChunk) {
+      const int kept_before = kept;
+      // (1) the chunk's own threads pull against everything kept before the chunk
+      if (static_cast<uint32_t>(tid) >= c0 && static_cast<uint32_t>(tid) < c0 + kNmsChunk) {
+        bool alive = static_cast<uint32_t>(tid) < n_round;
+        if (alive) {
+          float jb[NB];
 #pragma unroll
-  for (int s = 0; s < kNmsSlots; ++s) {
-    if (r_rank[s] >= 0) {
-      const size_t o = static_cast<size_t>(img) * ndet + r_rank[s];
-      a.out_scores[o] = r_score[s];
-      a.out_classes[o] = r_cls[s];
+          for (int k = 0; k < NB; ++k) jb[k] = s_box[tid * NB + k];
+          const float jc = s_cls[tid];
+          for (int q = 0; q < kept_before && alive; ++q) {
+            if (s_kcls[q] == jc) {                              // box.py:351 class != keeps
+              float mb[NB];
 #pragma unroll
-      for (int k = 0; k < NB; ++k) a.out_boxes[o * NB + k] = r_box[s].v[k];
-      if (a.out_indices) a.out_indices[o] = r_src[s];
+              for (int k = 0; k < NB; ++k) mb[k] = s_kbox[q * NB + k];
+              if (box_suppresses<NB>(mb, jb, thr, own_angle)) alive = false;
+            }
+          }
+        }
+        const uint64_t word = __ballot(alive);
+        if (lane == 0) s_alive[(tid - c0) >> 6] = word;
+      }
+      __syncthreads();
+
+      // (2) wave 0 resolves the chunk in order, 64 candidates at a time, no barrier inside
+      if (wave == 0) {
+        int k_cnt = kept_before;
+        for (int g = 0; g < kNmsChunk / kWave && k_cnt < ndet; ++g) {
+          const uint32_t r = c0 + g * kWave + lane;             // rank inside the round
+          uint64_t mask = s_alive[g];
+          bool alive = (mask >> lane) & 1ull;
+          if (mask == 0) continue;
+          float jb[NB];
+#pragma unroll
+          for (int k = 0; k < NB; ++k) jb[k] = s_box[(r < kNmsRound ? r : 0) * NB + k];
+          const float jc = s_cls[r < kNmsRound ? r : 0];
+          // pull against the boxes kept earlier in THIS chunk
+          for (int q = kept_before; q < k_cnt; ++q) {
+            const float kc = s_kcls[q];
+            if (alive && kc == jc) {
+              float mb[NB];
+#pragma unroll
+              for (int k = 0; k < NB; ++k) mb[k] = s_kbox[q * NB + k];
+              if (box_suppresses<NB>(mb, jb, thr, own_angle)) alive = false;
+            }
+          }
+          // sequential greedy inside the group
+          mask = __ballot(alive);
+          while (mask) {
+            // mask is wave-uniform: keep l0 in an SGPR so the broadcasts are v_readlane, not LDS permutes
+            const int l0 = __builtin_amdgcn_readfirstlane(__ffsll(static_cast<unsigned long long>(mask)) - 1);
+            float mb[NB];
+#pragma unroll
+            for (int k = 0; k < NB; ++k) mb[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(jb[k]), l0));
+            const float mc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(jc), l0));
+            if (lane == l0) {                                   // keep it
+              const uint64_t key = s_sel[r];
+#pragma unroll
+              for (int k = 0; k < NB; ++k) s_kbox[k_cnt * NB + k] = jb[k];
+              s_kcls[k_cnt] = jc;
+              s_kscore[k_cnt] = key_score(key);
+              s_ksrc[k_cnt] = static_cast<int32_t>(key_index(key));
+              alive = false;
+            }
+            ++k_cnt;
+            if (k_cnt == ndet) break;
+            if (alive && lane > l0 && jc == mc && box_suppresses<NB>(mb, jb, thr, own_angle)) alive = false;
+            mask = __ballot(alive);
+          }
+        }
+        if (lane == 0) s_misc[34] = static_cast<uint32_t>(k_cnt);
+      }
+      __syncthreads();
+      kept = static_cast<int>(s_misc[34]);
     }
   }
-  for (int t = kept + tid; t < ndet; t += kNmsThreads) {
+
+  // ---- outputs: kept boxes, then the zero-padded tail (box.py:322-324) ----
+  for (int t = tid; t < ndet; t += kNmsThreads) {
     const size_t o = static_cast<size_t>(img) * ndet + t;
-    a.out_scores[o] = 0.0f;
-    a.out_classes[o] = 0.0f;
+    const bool v = t < kept;
+    a.out_scores[o] = v ? s_kscore[t] : 0.0f;
+    a.out_classes[o] = v ? s_kcls[t] : 0.0f;
 #pragma unroll
-    for (int k = 0; k < NB; ++k) a.out_boxes[o * NB + k] = 0.0f;
-    if (a.out_indices) a.out_indices[o] = -1;
+    for (int k = 0; k < NB; ++k) a.out_boxes[o * NB + k] = v ? s_kbox[t * NB + k] : 0.0f;
+    if (a.out_indices) a.out_indices[o] = v ? s_ksrc[t] : -1;
   }
 }
 

@@ -229,13 +229,6 @@ int decode_levels_impl(int batch, int n_levels, const odtk_level_t *levels, int 
                 : launch_decode<odtk::F16, false>(rotated, tiles, n_seg, sa, da, stream);
 }
 
-size_t nms_lds_bytes(uint32_t count, uint32_t n_pow2, int nb) {
-  const size_t overlay = static_cast<size_t>(count) * (nb + 1) * 4;
-  const size_t keys_b = static_cast<size_t>(n_pow2) * 8;
-  const size_t bitmap_off = ((overlay > keys_b ? overlay : keys_b) + 15) & ~static_cast<size_t>(15);
-  return bitmap_off + 2 * odtk::kNmsWords * 8 + 16;
-}
-
 template <int NB>
 int nms_launch(const odtk::NmsArgs &na, int batch, size_t lds, hipStream_t stream) {
   // opt this kernel in to the full 160 KiB of LDS once (thread-safe static initialisation)
@@ -253,7 +246,8 @@ int nms_launch(const odtk::NmsArgs &na, int batch, size_t lds, hipStream_t strea
 
 int nms_impl(int batch, const void *const *inputs, void *const *outputs, int n_outputs, size_t count,
              int ndet, float thresh, uint32_t flags, void *workspace, size_t workspace_size, hipStream_t stream) {
-  if (batch <= 0 || count == 0 || count > ODTK_MAX_NMS_COUNT || ndet <= 0) return ODTK_ERR_INVALID;
+  if (batch <= 0 || count == 0 || count > ODTK_MAX_NMS_COUNT || ndet <= 0 || ndet > ODTK_MAX_NMS_DETECTIONS)
+    return ODTK_ERR_INVALID;
   // the kernel needs no global scratch (everything is LDS-resident); a token size keeps the
   // reference's two-phase calling convention working unchanged.
   if (!workspace || !workspace_size) return static_cast<int>(kAlign);
@@ -272,13 +266,10 @@ int nms_impl(int batch, const void *const *inputs, void *const *outputs, int n_o
   na.out_classes = static_cast<float *>(outputs[2]);
   na.out_indices = n_outputs > 3 ? static_cast<int32_t *>(outputs[3]) : nullptr;
   na.count = static_cast<uint32_t>(count);
-  uint32_t p2 = 1;
-  while (p2 < count) p2 <<= 1;
-  na.n_pow2 = p2;
   na.ndet = ndet;
   na.thresh = thresh;
   na.flags = flags;
-  const size_t lds = nms_lds_bytes(na.count, p2, nb);
+  const size_t lds = odtk::NmsLds(na.count, ndet, nb).total;   // same carve-up the kernel computes
   if (lds > 160 * 1024) return ODTK_ERR_INVALID;
   return nb == 6 ? nms_launch<6>(na, batch, lds, stream) : nms_launch<4>(na, batch, lds, stream);
 }

@@ -9,9 +9,10 @@
 //
 // Selection is exact for ANY input:
 //   K <= kSortCap           : all candidates are sorted (bitonic network in LDS).
-//   kSortCap < K <= cap     : MSD radix-select (11-bit digits, LDS histograms) on the 64-bit
-//                             keys of the candidate list finds the top_n-th key, the keys
-//                             >= it are gathered into LDS and sorted.
+//   kSortCap < K <= cap     : MSD radix descent (11-bit digits, LDS histograms) on the 64-bit
+//                             keys of the candidate lists narrows down the bin of the top_n-th
+//                             key until "everything >= that bin" fits the LDS sort buffer
+//                             (usually 2 passes); those keys are gathered and sorted.
 //   K > cap (list overflow) : the same radix-select runs over the segment's RAW scores
 //                             (keys rebuilt on the fly), so correctness never depends on cap.
 // Keys are unique (they embed the index), so "keys >= T" is exactly top_n elements even when
@@ -55,17 +56,43 @@ struct DecodeArgs {
 
 // ---- key sources -------------------------------------------------------------------------
 struct ListSource {   // the kSubLists compacted candidate sub-lists written by prefilter_scan_kernel
-  const uint64_t *keys;      // sub-list s starts at keys + s * cap
-  const uint32_t *counts;    // [kSubLists]
+  const uint64_t *keys;              // sub-list s starts at keys + s * cap
   uint32_t cap;
+  uint32_t start[kSubLists + 1];     // exclusive prefix of the (clamped) sub-list lengths: wave-uniform
+  __device__ ListSource(const uint64_t *k, const uint32_t *counts, uint32_t cap_) : keys(k), cap(cap_) {
+    uint32_t acc = 0;
+#pragma unroll
+    for (int s = 0; s < kSubLists; ++s) {
+      start[s] = acc;
+      const uint32_t c = counts[s];
+      acc += c < cap_ ? c : cap_;
+    }
+    start[kSubLists] = acc;
+  }
+  // one flat, fully occupied loop over all sub-lists (walking them one after the other would leave
+  // most of the 1024 threads idle on the short lists and serialise 16 dependent count loads)
   template <typename F>
   __device__ __forceinline__ void for_each(F &&f) const {
-#pragma unroll 1
-    for (int s = 0; s < kSubLists; ++s) {
-      const uint32_t c = counts[s];
-      const uint64_t *k = keys + static_cast<uint64_t>(s) * cap;
-      for (uint32_t i = threadIdx.x; i < c; i += kSelThreads) f(k[i]);
+    const uint32_t total = start[kSubLists];
+    auto address = [&](uint32_t i) -> const uint64_t * {
+      uint32_t s = 0, base = 0;
+#pragma unroll
+      for (int q = 1; q < kSubLists; ++q)
+        if (i >= start[q]) { s = q; base = start[q]; }
+      return keys + static_cast<uint64_t>(s) * cap + (i - base);
+    };
+    // 4 independent loads in flight per lane: the lists live in L2, a dependent one-load-per-trip
+    // loop would pay the full latency 20+ times per pass
+    constexpr int kBatch = 4;
+    uint32_t i = threadIdx.x;
+    for (; i + (kBatch - 1) * kSelThreads < total; i += kBatch * kSelThreads) {
+      uint64_t k[kBatch];
+#pragma unroll
+      for (int u = 0; u < kBatch; ++u) k[u] = *address(i + u * kSelThreads);
+#pragma unroll
+      for (int u = 0; u < kBatch; ++u) f(k[u]);
     }
+    for (; i < total; i += kSelThreads) f(*address(i));
   }
 };
 template <typename T, bool kLogits>
@@ -103,11 +130,16 @@ __device__ __forceinline__ void bitonic_sort_desc(uint64_t *s_keys, uint32_t n) 
   }
 }
 
-// Finds T such that exactly `want` keys of `src` are >= T (keys unique, count(src) > want).
+// MSD radix descent (11-bit digits, LDS histogram) on the bin that holds the `want`-th largest key.
+// Returns a threshold T and *n_out = #{key >= T} with  want <= *n_out <= max_take : the descent
+// stops as soon as everything above the boundary bin plus the bin itself fits `max_take`, so the
+// caller sorts a few extra keys instead of paying for more passes.  Keys are unique; the source
+// must hold at least `want` keys and max_take >= want.  s_misc: [0..15] wave totals, [16..18] result.
 template <typename Source>
-__device__ uint64_t radix_select(const Source &src, uint32_t want, uint32_t *s_hist, uint32_t *s_misc) {
+__device__ uint64_t radix_threshold(const Source &src, uint32_t want, uint32_t max_take, uint32_t *s_hist,
+                                    uint32_t *s_misc, uint32_t *n_out) {
   uint64_t prefix = 0, pmask = 0;
-  uint32_t remaining = want;
+  uint32_t remaining = want, taken_above = 0, in_bin = 0;
   int hi_bit = 64;
   while (hi_bit > 0) {
     const int bits = hi_bit >= kRadixBits ? kRadixBits : hi_bit;
@@ -129,21 +161,22 @@ __device__ uint64_t radix_select(const Source &src, uint32_t want, uint32_t *s_h
     uint32_t woff = 0;
     for (int i = 0; i < w; ++i) woff += s_misc[i];
     const uint32_t excl = woff + inc - (h0 + h1);
-    __syncthreads();                       // s_misc reused below
     // the unique bin where the running count crosses `remaining`
-    if (excl < remaining && remaining <= excl + h0) { s_misc[0] = 2 * threadIdx.x; s_misc[1] = excl; s_misc[2] = h0; }
-    else if (excl + h0 < remaining && remaining <= excl + h0 + h1) { s_misc[0] = 2 * threadIdx.x + 1; s_misc[1] = excl + h0; s_misc[2] = h1; }
+    if (excl < remaining && remaining <= excl + h0) { s_misc[16] = 2 * threadIdx.x; s_misc[17] = excl; s_misc[18] = h0; }
+    else if (excl + h0 < remaining && remaining <= excl + h0 + h1) { s_misc[16] = 2 * threadIdx.x + 1; s_misc[17] = excl + h0; s_misc[18] = h1; }
     __syncthreads();
-    const uint32_t rbin = s_misc[0], above = s_misc[1], in_bin = s_misc[2];
-    __syncthreads();
+    const uint32_t rbin = s_misc[16], above = s_misc[17];
+    in_bin = s_misc[18];
     const uint64_t digit = (nb - 1) - rbin;
     prefix |= digit << shift;
     pmask |= static_cast<uint64_t>(nb - 1) << shift;
     remaining -= above;
+    taken_above += above;
     hi_bit = shift;
-    if (in_bin == remaining) break;        // the whole bucket is wanted: undecided low bits stay 0
+    if (taken_above + in_bin <= max_take) break;   // at the last digit in_bin == remaining == 1
   }
-  return prefix;
+  *n_out = taken_above + in_bin;
+  return prefix;                                    // undecided low bits are 0 = start of the boundary bin
 }
 
 // ---- the kernel ------------------------------------------------------------------------------
@@ -176,28 +209,28 @@ __global__ __launch_bounds__(kSelThreads) void select_decode_kernel(const Decode
   const uint32_t channels = static_cast<uint32_t>(A) * C;
   const typename T::storage *cls_image = static_cast<const typename T::storage *>(L.cls) + static_cast<uint64_t>(b) * L.n;
 
-  const ListSource lists{a.cand + L.cand_off + static_cast<uint64_t>(b) * kSubLists * L.cap, sub_counts, L.cap};
+  const ListSource lists(a.cand + L.cand_off + static_cast<uint64_t>(b) * kSubLists * L.cap, sub_counts, L.cap);
   uint32_t n_sort;   // number of valid keys placed in s_keys
 
   if (count <= kSortCap && complete) {
-    if (threadIdx.x == 0) s_misc[8] = 0;
+    if (threadIdx.x == 0) s_misc[20] = 0;
     __syncthreads();
-    lists.for_each([&](uint64_t key) { s_keys[atomicAdd(&s_misc[8], 1u)] = key; });   // order is irrelevant
+    lists.for_each([&](uint64_t key) { s_keys[atomicAdd(&s_misc[20], 1u)] = key; });   // order is irrelevant
     n_sort = count;
   } else {
     const RawSource<T, kLogits> raw{cls_image, L.n, channels, hw, L.channels_last, a.thresh};
-    uint64_t T64;
-    if (count <= top_n) T64 = 0;   // everything is wanted (possible only on the overflow path)
-    else if (complete) T64 = radix_select(lists, top_n, s_hist, s_misc);
-    else T64 = radix_select(raw, top_n, s_hist, s_misc);
-    if (threadIdx.x == 0) s_misc[8] = 0;
+    uint64_t T64 = 0;
+    n_sort = count;                // count <= top_n: everything is wanted (overflow path only)
+    if (count > top_n)
+      T64 = complete ? radix_threshold(lists, top_n, kSortCap, s_hist, s_misc, &n_sort)
+                     : radix_threshold(raw, top_n, kSortCap, s_hist, s_misc, &n_sort);
+    if (threadIdx.x == 0) s_misc[20] = 0;
     __syncthreads();
     auto take = [&](uint64_t key) {
-      if (key >= T64) { const uint32_t p = atomicAdd(&s_misc[8], 1u); if (p < kSortCap) s_keys[p] = key; }
+      if (key >= T64) { const uint32_t p = atomicAdd(&s_misc[20], 1u); if (p < kSortCap) s_keys[p] = key; }
     };
     if (complete) lists.for_each(take);
     else raw.for_each(take);
-    n_sort = k_out;
   }
   uint32_t n_pow2 = 1;
   while (n_pow2 < n_sort) n_pow2 <<= 1;
