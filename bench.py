@@ -90,6 +90,9 @@ def main():
     ap.add_argument('--cpu-seconds', type=float, default=20.0, help='budget of the cpu_baseline leg (0 = skip)')
     ap.add_argument('--no-miopen-find', action='store_true',
                     help='torch.backends.cudnn.benchmark = False (MIOpen immediate mode instead of find mode)')
+    ap.add_argument('--no-fuse', action='store_true',
+                    help='run the eager nn.Module graph under autocast instead of the BN-folded graph with the HIP '
+                         'bias/skip/ReLU epilogue (odtk/fused.py)')
     ap.add_argument('--postproc', default='fused', choices=['fused', 'reference'],
                     help="fused: sigmoid+decode+nms read the bf16 channels_last head tensors in place (3 launches); "
                          "reference: the reference's op sequence (sigmoid, .contiguous(), .float(), decode x5, cat, nms)")
@@ -120,9 +123,17 @@ def main():
     flops_img = conv_flops_per_image(model, x[:1])
     sigma0 = calibrate_cls_head(model, x, args.sigma, amp_dtype)
 
-    def step():
-        with torch.no_grad(), torch.autocast('cuda', dtype=amp_dtype, enabled=amp_dtype is not None):
-            return model(x)
+    fuse_graph = not args.no_fuse and args.postproc == 'fused'
+    if fuse_graph:
+        from odtk.fused import FusedRetinaNet
+        engine = FusedRetinaNet(model, dtype=amp_dtype or torch.float32).to(dev)
+
+        def step():
+            return engine(x)
+    else:
+        def step():
+            with torch.no_grad(), torch.autocast('cuda', dtype=amp_dtype, enabled=amp_dtype is not None):
+                return model(x)
 
     out = None
     for _ in range(args.warmup):
@@ -205,7 +216,9 @@ def main():
                                    % (args.backbone, args.dtype, args.batch, args.height, args.width),
                        'global_batch': args.batch * world, 'image': [args.height, args.width],
                        'parallelism': 'replicas x%d (no data-path collective)' % world,
-                       'memory_format': 'channels_last', 'miopen_find': miopen_find, 'postproc': args.postproc},
+                       'memory_format': 'channels_last', 'miopen_find': miopen_find, 'postproc': args.postproc,
+                       'graph': 'BN folded into conv weights + HIP bias/skip/ReLU epilogue' if fuse_graph
+                                else 'eager nn.Module under autocast'},
             'roofline': roofline, 'conv_roofline': conv_roofline, 'kernels': kernels,
             'cpu_baseline': cpu_baseline,
         }

@@ -164,6 +164,18 @@ int odtk_detect(int batch_size, int n_levels, const odtk_level_t *levels,
                 float score_thresh, int top_n, float nms_thresh, int detections_per_im,
                 void *const *outputs, void *workspace, size_t workspace_size, void *stream);
 
+/*
+ * odtk_bias_act -- fused convolution epilogue, in place, on a channels_last (NHWC) activation:
+ *     y[p][c] = act( y[p][c] + bias[c] (+ residual[p][c]) ),   act = ReLU if relu != 0
+ * y, residual: device [n_pixels, channels] of `dtype` (ODTK_F32/BF16/F16), 16-byte aligned;
+ * bias: DEVICE float32 [channels].  No reference kernel equivalent: it replaces the separate
+ * conv-bias / frozen-batch-norm / residual-add / ReLU passes of the reference's PyTorch graph
+ * (odtk/backbones/layers.py:5-16, torchvision Bottleneck.forward, odtk/model.py:57-62) once the
+ * frozen BN scale is folded into the convolution weights (see odtk/fused.py).
+ */
+int odtk_bias_act(void *y, const float *bias, const void *residual, size_t n_pixels, int channels,
+                  int dtype, int relu, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * Measurement hooks (used by bench.py; off by default, zero cost when off).
  * While enabled, every kernel launch of this library is bracketed by a hipEvent pair recorded on
@@ -174,7 +186,8 @@ int odtk_detect(int batch_size, int n_levels, const odtk_level_t *levels,
 #define ODTK_KERNEL_SELECT    1   /* select_decode_kernel                          */
 #define ODTK_KERNEL_NMS       2   /* nms_kernel                                    */
 #define ODTK_KERNEL_IOU       3   /* iou_pairs_kernel                              */
-#define ODTK_KERNEL_COUNT     4
+#define ODTK_KERNEL_EPILOGUE  4   /* bias_act_kernel                               */
+#define ODTK_KERNEL_COUNT     5
 int odtk_profile_enable(int on);
 int odtk_profile_collect(double total_ms[ODTK_KERNEL_COUNT], int launches[ODTK_KERNEL_COUNT]);
 

@@ -1,0 +1,105 @@
+// epilogue.hpp -- fused per-channel bias (+ residual) (+ ReLU) over a channels_last activation, in
+// place: the inference-time epilogue of every convolution of the ResNet/FPN/head stack.
+//
+// No reference equivalent as a kernel: in the reference (odtk/backbones/resnet.py via torchvision
+// blocks, odtk/backbones/layers.py:5-16 FixedBatchNorm2d, odtk/model.py:57-62 heads) each of
+// conv-bias, batch-norm, residual add and ReLU is its own full read+write pass over the activation
+// (measured on MI355X: those passes cost MORE than the MIOpen convolutions between them:
+// 1x1 64->256 @200x320 bs8: conv 71 us, +bias+relu 280 us).  With the frozen BN folded into the
+// convolution weights (scale) and this epilogue (shift), a conv->BN->(+skip)->ReLU group reads the
+// conv output once (+ the skip once) and writes once.
+//
+// HBM-bound: algorithmic bytes = 2 x sizeof(T) per element (+ sizeof(T) with a residual).
+// 16-byte vector accesses, kUnroll independent vectors in flight per lane, fp32 arithmetic,
+// round-to-nearest-even to the storage type.  In the fast form the grid stride is a multiple of the
+// row length, so each lane's channel offset never changes: its bias values are loaded ONCE into
+// registers and the loop has no integer division.
+#pragma once
+
+#include "common.hpp"
+#include "prefilter.hpp"   // element types, bf16/f16 conversions
+
+namespace odtk {
+
+template <typename T>
+__device__ __forceinline__ uint32_t float_to_storage(float f) {
+  if constexpr (std::is_same_v<T, BF16>) return __float_as_uint(round_to_bf16(f)) >> 16;
+  else return static_cast<uint32_t>(__builtin_bit_cast(uint16_t, static_cast<_Float16>(f)));
+}
+
+template <typename T, bool kResidual, bool kRelu>
+__device__ __forceinline__ vuint4 bias_act_vec(vuint4 v, vuint4 r, const float *b) {
+  constexpr int kPer = T::kPerLoad;
+  float f[kPer];
+#pragma unroll
+  for (int e = 0; e < kPer; ++e) {
+    float x, s = 0.0f;
+    if constexpr (std::is_same_v<T, F32>) {
+      x = __uint_as_float(v[e]);
+      if (kResidual) s = __uint_as_float(r[e]);
+    } else {
+      const uint32_t hx = (v[e >> 1] >> (16 * (e & 1))) & 0xffffu, hr = (r[e >> 1] >> (16 * (e & 1))) & 0xffffu;
+      x = std::is_same_v<T, BF16> ? bf16_bits_to_float(hx) : f16_bits_to_float(hx);
+      if (kResidual) s = std::is_same_v<T, BF16> ? bf16_bits_to_float(hr) : f16_bits_to_float(hr);
+    }
+    float o = x + b[e];
+    if (kResidual) o += s;
+    if (kRelu) o = o > 0.0f ? o : 0.0f;
+    f[e] = o;
+  }
+  if constexpr (std::is_same_v<T, F32>) {
+#pragma unroll
+    for (int e = 0; e < kPer; ++e) v[e] = __float_as_uint(f[e]);
+  } else {
+#pragma unroll
+    for (int e = 0; e < kPer; e += 2) v[e >> 1] = float_to_storage<T>(f[e]) | (float_to_storage<T>(f[e + 1]) << 16);
+  }
+  return v;
+}
+
+// Fast form.  Requires channels % kPer == 0 and (gridDim.x * blockDim.x) % (channels / kPer) == 0.
+template <typename T, bool kResidual, bool kRelu>
+__global__ __launch_bounds__(256) void bias_act_kernel(void *y, const float *__restrict__ bias, const void *res,
+                                                       uint64_t n_vec, uint32_t vec_per_row) {
+  constexpr int kPer = T::kPerLoad;
+  constexpr int kUnroll = 4;
+  vuint4 *yv = static_cast<vuint4 *>(y);
+  const vuint4 *rv = static_cast<const vuint4 *>(res);
+  const uint64_t step = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+  const uint64_t q0 = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+  float b[kPer];
+  {
+    const uint32_t c0 = static_cast<uint32_t>(q0 % vec_per_row) * kPer;       // loop-invariant
+#pragma unroll
+    for (int e = 0; e < kPer; ++e) b[e] = bias[c0 + e];
+  }
+  uint64_t q = q0;
+  for (; q + (kUnroll - 1) * step < n_vec; q += kUnroll * step) {
+    vuint4 v[kUnroll], r[kUnroll];
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      v[u] = yv[q + u * step];
+      r[u] = kResidual ? rv[q + u * step] : vuint4{0, 0, 0, 0};
+    }
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) yv[q + u * step] = bias_act_vec<T, kResidual, kRelu>(v[u], r[u], b);
+  }
+  for (; q < n_vec; q += step)
+    yv[q] = bias_act_vec<T, kResidual, kRelu>(yv[q], kResidual ? rv[q] : vuint4{0, 0, 0, 0}, b);
+}
+
+// General form (channel count not a multiple of the vector width, tiny tensors, tails): scalar.
+template <typename T, bool kResidual, bool kRelu>
+__global__ void bias_act_scalar_kernel(void *y, const float *bias, const void *res, uint64_t begin, uint64_t n,
+                                       uint32_t channels) {
+  const uint64_t step = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+  for (uint64_t i = begin + static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += step) {
+    float o = load_raw<T>(y, i) + bias[i % channels];
+    if (kResidual) o += load_raw<T>(res, i);
+    if (kRelu) o = o > 0.0f ? o : 0.0f;
+    if constexpr (std::is_same_v<T, F32>) static_cast<float *>(y)[i] = o;
+    else static_cast<uint16_t *>(y)[i] = static_cast<uint16_t>(float_to_storage<T>(o));
+  }
+}
+
+}  // namespace odtk

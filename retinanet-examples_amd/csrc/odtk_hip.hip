@@ -15,6 +15,7 @@
 
 #include "../../include/odtk_hip.h"
 #include "common.hpp"
+#include "epilogue.hpp"
 #include "iou.hpp"
 #include "nms.hpp"
 #include "prefilter.hpp"
@@ -274,6 +275,47 @@ int nms_impl(int batch, const void *const *inputs, void *const *outputs, int n_o
   return nb == 6 ? nms_launch<6>(na, batch, lds, stream) : nms_launch<4>(na, batch, lds, stream);
 }
 
+template <typename T, bool kRes, bool kRelu>
+int bias_act_launch(void *y, const float *bias, const void *res, uint64_t n, uint32_t channels, hipStream_t stream) {
+  constexpr int per = T::kPerLoad;
+  KernelTimer t(ODTK_KERNEL_EPILOGUE, stream);
+  uint64_t done = 0;
+  if (channels % per == 0 && n / per >= 256) {
+    // fast form: grid stride (blocks * 256 lanes) must be a multiple of the row length in vectors
+    const uint32_t vpr = channels / per;
+    const uint64_t n_vec = n / per;                         // n is a multiple of channels, hence of per
+    uint32_t g = vpr, m = 256;                              // unit = vpr / gcd(vpr, 256) blocks
+    while (m) { const uint32_t r_ = g % m; g = m; m = r_; }
+    const uint32_t unit = vpr / g;
+    uint64_t blocks = (n_vec + 256ull * 4 - 1) / (256ull * 4);          // ~4 vectors per lane
+    if (blocks > 256 * 16) blocks = 256 * 16;                            // <= 16 workgroups per CU
+    blocks = (blocks + unit - 1) / unit * unit;
+    hipLaunchKernelGGL((odtk::bias_act_kernel<T, kRes, kRelu>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0,
+                       stream, y, bias, res, n_vec, vpr);
+    done = n_vec * per;
+  }
+  if (done < n) {
+    uint64_t blocks = (n - done + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL((odtk::bias_act_scalar_kernel<T, kRes, kRelu>), dim3(static_cast<unsigned>(blocks)), dim3(256),
+                       0, stream, y, bias, res, done, n, channels);
+  }
+  return hipGetLastError() == hipSuccess ? ODTK_OK : ODTK_ERR_HIP;
+}
+
+template <typename T>
+int bias_act_typed(void *y, const float *bias, const void *res, uint64_t n, uint32_t c, bool relu, hipStream_t s) {
+  if (res) return relu ? bias_act_launch<T, true, true>(y, bias, res, n, c, s) : bias_act_launch<T, true, false>(y, bias, res, n, c, s);
+  return relu ? bias_act_launch<T, false, true>(y, bias, res, n, c, s) : bias_act_launch<T, false, false>(y, bias, res, n, c, s);
+}
+
+int bias_act_dispatch(void *y, const float *bias, const void *res, uint64_t n, uint32_t c, int dtype, bool relu,
+                      hipStream_t s) {
+  if (dtype == ODTK_F32) return bias_act_typed<odtk::F32>(y, bias, res, n, c, relu, s);
+  if (dtype == ODTK_BF16) return bias_act_typed<odtk::BF16>(y, bias, res, n, c, relu, s);
+  return bias_act_typed<odtk::F16>(y, bias, res, n, c, relu, s);
+}
+
 int decode_single(bool rotated, int batch, const void *const *inputs, void *const *outputs, size_t height,
                   size_t width, size_t scale, size_t A, size_t C, const float *anchors, size_t anchors_len,
                   float thresh, int top_n, void *workspace, size_t workspace_size, void *stream) {
@@ -381,6 +423,17 @@ int odtk_iou(const void *const *inputs, void *const *outputs, int num_boxes, int
   }
   ODTK_HIP_TRY(hipGetLastError());
   return ODTK_OK;
+}
+
+int odtk_bias_act(void *y, const float *bias, const void *residual, size_t n_pixels, int channels, int dtype,
+                  int relu, void *stream) {
+  if (!y || !bias || channels <= 0) return ODTK_ERR_INVALID;
+  if (dtype != ODTK_F32 && dtype != ODTK_BF16 && dtype != ODTK_F16) return ODTK_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(y) & 15u) || (reinterpret_cast<uintptr_t>(residual) & 15u)) return ODTK_ERR_INVALID;
+  const uint64_t n = static_cast<uint64_t>(n_pixels) * channels;
+  if (n == 0) return ODTK_OK;
+  return bias_act_dispatch(y, bias, residual, n, static_cast<uint32_t>(channels), dtype, relu != 0,
+                           static_cast<hipStream_t>(stream));
 }
 
 int odtk_decode_levels(int batch_size, int n_levels, const odtk_level_t *levels, int num_anchors,

@@ -59,11 +59,12 @@ _SIGNATURES = {
     'odtk_detect': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.POINTER(Level), ctypes.c_int, ctypes.c_int,
                                    ctypes.c_int, ctypes.c_uint32, ctypes.c_float, ctypes.c_int, ctypes.c_float,
                                    ctypes.c_int, _vpp, _vp, _sz, _vp]),
+    'odtk_bias_act': (ctypes.c_int, [_vp, _vp, _vp, _sz, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp]),
     'odtk_profile_enable': (ctypes.c_int, [ctypes.c_int]),
     'odtk_profile_collect': (ctypes.c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]),
 }
 
-KERNEL_NAMES = ('prefilter_scan_kernel', 'select_decode_kernel', 'nms_kernel', 'iou_pairs_kernel')
+KERNEL_NAMES = ('prefilter_scan_kernel', 'select_decode_kernel', 'nms_kernel', 'iou_pairs_kernel', 'bias_act_kernel')
 
 _lib = None
 
@@ -300,6 +301,26 @@ def detect(cls_heads, box_heads, anchors_list, strides, score_thresh, top_n, nms
         ws, stream = _workspace(dev, size)
         _check(lib.odtk_detect(*args, _ptrs(out), ws.data_ptr(), ws.numel(), stream), 'detect')
     return out
+
+
+def bias_act_(y, bias, residual=None, relu=True):
+    """In place on a channels_last activation: y = act(y + bias[c] (+ residual)).  `bias` is a float32
+    device vector [C].  Replaces the separate bias / frozen-BN / residual-add / ReLU passes."""
+    if not y.is_cuda or y.dim() != 4 or y.dtype not in _DTYPES:
+        raise RuntimeError('bias_act_: y must be a 4-d CUDA tensor of float32/bfloat16/float16')
+    n, c, h, w = y.shape
+    if not (y.is_contiguous(memory_format=torch.channels_last) or h * w == 1):
+        raise RuntimeError('bias_act_: y must be channels_last')
+    if bias.dtype != torch.float32 or bias.numel() != c or not bias.is_cuda:
+        raise RuntimeError('bias_act_: bias must be a float32 CUDA vector of length C')
+    if residual is not None and (residual.shape != y.shape or residual.dtype != y.dtype or not (
+            residual.is_contiguous(memory_format=torch.channels_last) or h * w == 1)):
+        raise RuntimeError('bias_act_: residual must match y (shape, dtype, channels_last)')
+    with torch.cuda.device(y.device):
+        stream = torch.cuda.current_stream(y.device).cuda_stream
+        _check(library().odtk_bias_act(y.data_ptr(), bias.data_ptr(), residual.data_ptr() if residual is not None else None,
+                                       n * h * w, c, _DTYPES[y.dtype], 1 if relu else 0, stream), 'bias_act')
+    return y
 
 
 def profile_enable(on=True):

@@ -1,0 +1,140 @@
+"""Inference-time fusion of the RetinaNet graph for MI355X.
+
+The convolutions stay on PyTorch-ROCm / MIOpen (MFMA); what changes is everything BETWEEN them.
+In the reference graph (torchvision blocks, FixedBatchNorm2d reference odtk/backbones/layers.py:5-16,
+heads reference odtk/model.py:57-62) conv-bias, frozen batch-norm, residual add and ReLU are each a
+full read+write pass over the activation, and under autocast every weight is re-cast every step.
+Measured on MI355X those passes cost more than the convolutions between them.  Here
+
+  * frozen BN is folded into the convolution: w' = w * gamma/sqrt(var+eps) (the scale), and the
+    shift becomes a per-channel bias;
+  * weights are stored once in the inference dtype (bf16), channels_last;
+  * ONE hand-written HIP epilogue (`odtk_bias_act`, csrc/epilogue.hpp) applies bias (+ skip) (+ ReLU)
+    in place on the convolution output;
+  * the post-processing reads the raw head tensors in place (odtk.box.detect(..., logits=True)).
+
+`FusedRetinaNet(model)` is a drop-in for `model.eval()` inference: same outputs up to the rounding of
+the folded weights (tests/test_gpu_fused_model.py).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _C
+from . import box as box_ops
+from .backbones.resnet import BasicBlock, Bottleneck
+
+
+def fold_conv_bn(conv, bn=None):
+    """(weight, bias) in float32 such that conv2d(x, weight) + bias == bn(conv(x)) in eval mode."""
+    w = conv.weight.detach().float()
+    b = conv.bias.detach().float() if conv.bias is not None else torch.zeros(w.shape[0], device=w.device)
+    if bn is not None:
+        eps = getattr(bn, 'eps', 1e-5)
+        scale = bn.weight.detach().float() / torch.sqrt(bn.running_var.detach().float() + eps)
+        w = w * scale.view(-1, 1, 1, 1)
+        b = (b - bn.running_mean.detach().float()) * scale + bn.bias.detach().float()
+    return w, b
+
+
+class _Conv(nn.Module):
+    """Convolution without bias (MIOpen) + fused epilogue bias (+ residual) (+ ReLU) (HIP)."""
+
+    def __init__(self, conv, bn=None, relu=False, dtype=torch.bfloat16):
+        super().__init__()
+        w, b = fold_conv_bn(conv, bn)
+        self.register_buffer('weight', w.to(dtype).contiguous(memory_format=torch.channels_last))
+        self.register_buffer('bias', b.contiguous())
+        self.stride, self.padding, self.relu = conv.stride, conv.padding, relu
+
+    def forward(self, x, residual=None):
+        y = F.conv2d(x, self.weight, None, self.stride, self.padding)
+        if not y.is_contiguous(memory_format=torch.channels_last):
+            y = y.contiguous(memory_format=torch.channels_last)
+        return _C.bias_act_(y, self.bias, residual, self.relu)
+
+
+class _Block(nn.Module):
+    def __init__(self, block, dtype):
+        super().__init__()
+        if isinstance(block, Bottleneck):
+            self.convs = nn.ModuleList([_Conv(block.conv1, block.bn1, True, dtype), _Conv(block.conv2, block.bn2, True, dtype)])
+            self.last = _Conv(block.conv3, block.bn3, True, dtype)        # ReLU after the skip add
+        elif isinstance(block, BasicBlock):
+            self.convs = nn.ModuleList([_Conv(block.conv1, block.bn1, True, dtype)])
+            self.last = _Conv(block.conv2, block.bn2, True, dtype)
+        else:
+            raise TypeError('unsupported block %r' % type(block))
+        self.down = None if block.downsample is None else _Conv(block.downsample[0], block.downsample[1], False, dtype)
+
+    def forward(self, x):
+        skip = x if self.down is None else self.down(x)
+        y = x
+        for c in self.convs:
+            y = c(y)
+        return self.last(y, skip)                                       # relu(conv + shift + skip), one pass
+
+
+class FusedRetinaNet(nn.Module):
+    def __init__(self, model, dtype=torch.bfloat16):
+        super().__init__()
+        if len(model.backbones) != 1:
+            raise ValueError('FusedRetinaNet supports a single FPN backbone')
+        fpn = next(iter(model.backbones.values()))
+        net = fpn.features
+        self.dtype = dtype
+        self.model = [model]                                            # not a submodule: shares anchors / config
+        self.stem = _Conv(net.conv1, net.bn1, True, dtype)
+        self.layers = nn.ModuleList([nn.ModuleList([_Block(b, dtype) for b in layer])
+                                     for layer in (net.layer1, net.layer2, net.layer3, net.layer4)])
+        self.outputs = list(net.outputs)
+        self.lateral = nn.ModuleList([_Conv(fpn.lateral3, None, False, dtype), _Conv(fpn.lateral4, None, False, dtype),
+                                      _Conv(fpn.lateral5, None, False, dtype)])
+        self.smooth = nn.ModuleList([_Conv(fpn.smooth3, None, False, dtype), _Conv(fpn.smooth4, None, False, dtype),
+                                     _Conv(fpn.smooth5, None, False, dtype)])
+        self.pyramid6 = _Conv(fpn.pyramid6, None, False, dtype)
+        self.pyramid7 = _Conv(fpn.pyramid7, None, False, dtype)
+
+        def head(seq):
+            convs = [m for m in seq if isinstance(m, nn.Conv2d)]
+            return nn.ModuleList([_Conv(c, None, i + 1 < len(convs), dtype) for i, c in enumerate(convs)])
+
+        self.cls_head = head(model.cls_head)
+        self.box_head = head(model.box_head)
+
+    def features(self, x):
+        x = F.max_pool2d(self.stem(x), 3, 2, 1)
+        feats = []
+        for level, layer in enumerate(self.layers, start=2):
+            for block in layer:
+                x = block(x)
+            if level in self.outputs:
+                feats.append(x)
+        c3, c4, c5 = feats
+        p5 = self.lateral[2](c5)
+        p4 = self.lateral[1](c4, F.interpolate(p5, scale_factor=2))     # lateral + upsampled, one pass
+        p3 = self.lateral[0](c3, F.interpolate(p4, scale_factor=2))
+        p6 = self.pyramid6(c5)
+        p7 = self.pyramid7(F.relu(p6))
+        return [self.smooth[0](p3), self.smooth[1](p4), self.smooth[2](p5), p6, p7]
+
+    @staticmethod
+    def _run(seq, t):
+        for c in seq:
+            t = c(t)
+        return t
+
+    def heads(self, x):
+        x = x.to(self.dtype).contiguous(memory_format=torch.channels_last)
+        feats = self.features(x)
+        return [self._run(self.cls_head, t) for t in feats], [self._run(self.box_head, t) for t in feats]
+
+    @torch.no_grad()
+    def forward(self, x):
+        m = self.model[0]
+        cls_heads, box_heads = self.heads(x)
+        strides = [x.shape[-1] // c.shape[-1] for c in cls_heads]
+        for s in strides:
+            m.level_anchors(s)
+        return box_ops.detect(cls_heads, box_heads, strides, m.anchors, m.threshold, m.top_n, m.nms, m.detections,
+                              m.rotated_bbox, logits=True)

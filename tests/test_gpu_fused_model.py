@@ -1,0 +1,74 @@
+"""Inference fusion (odtk/fused.py + csrc/epilogue.hpp): the HIP epilogue against torch, and the
+BN-folded fused graph against the eager model."""
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from odtk import _C
+from odtk.fused import FusedRetinaNet, fold_conv_bn
+from odtk.model import Model
+
+
+def test_fold_conv_bn_is_exact_in_fp32_cpu():
+    torch.manual_seed(0)
+    conv = nn.Conv2d(8, 12, 3, padding=1, bias=True)
+    bn = nn.BatchNorm2d(12).eval()
+    bn.weight.data.uniform_(0.5, 1.5); bn.bias.data.normal_()
+    bn.running_mean.normal_(); bn.running_var.uniform_(0.5, 2.0)
+    x = torch.randn(2, 8, 9, 7)
+    w, b = fold_conv_bn(conv, bn)
+    ref = bn(conv(x))
+    got = F.conv2d(x, w, None, 1, 1) + b.view(1, -1, 1, 1)
+    assert torch.allclose(ref, got, atol=1e-5, rtol=1e-5)
+    w2, b2 = fold_conv_bn(conv, None)
+    assert torch.equal(w2, conv.weight) and torch.equal(b2, conv.bias)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16, torch.float32], ids=['bf16', 'fp16', 'fp32'])
+@pytest.mark.parametrize('shape', [(2, 64, 17, 23), (1, 36, 7, 10), (3, 720, 5, 3), (2, 7, 3, 3), (1, 256, 1, 1)],
+                         ids=lambda s: 'x'.join(map(str, s)))
+def test_bias_act_matches_torch(dtype, shape):
+    g = torch.Generator().manual_seed(sum(shape))
+    y = torch.randn(*shape, generator=g).cuda().to(dtype).contiguous(memory_format=torch.channels_last)
+    r = torch.randn(*shape, generator=g).cuda().to(dtype).contiguous(memory_format=torch.channels_last)
+    bias = torch.randn(shape[1], generator=g).cuda()
+    for res in (None, r):
+        for relu in (False, True):
+            ref = y.float() + bias.view(1, -1, 1, 1) + (res.float() if res is not None else 0)
+            ref = (F.relu(ref) if relu else ref).to(dtype)
+            out = _C.bias_act_(y.clone(memory_format=torch.preserve_format), bias, res, relu)
+            assert out.dtype == dtype and out.shape == y.shape
+            assert torch.equal(out, ref), (res is not None, relu)       # fp32 math, one rounding: exact
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('backbone', ['ResNet18FPN', 'ResNet50FPN'])
+def test_fused_graph_matches_eager_fp32(backbone):
+    torch.manual_seed(0)
+    model = Model(backbone, classes=20)
+    model.initialize(None)
+    for m in model.modules():                       # non-trivial frozen statistics
+        if isinstance(m, nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.1); m.running_var.uniform_(0.5, 1.5)
+            m.weight.data.uniform_(0.8, 1.2); m.bias.data.normal_(0, 0.1)
+    model = model.cuda().to(memory_format=torch.channels_last).eval()
+    x = torch.randn(2, 3, 256, 320, device='cuda').contiguous(memory_format=torch.channels_last)
+    fused = FusedRetinaNet(model, dtype=torch.float32)
+    with torch.no_grad():
+        ref_cls, ref_box = model.heads(x)
+        got_cls, got_box = fused.heads(x)
+    for r, g in zip(ref_cls + ref_box, got_cls + got_box):
+        assert r.shape == g.shape
+        scale = r.abs().max().item() + 1e-6
+        assert (r - g).abs().max().item() <= 2e-3 * scale, (r - g).abs().max().item() / scale
+    # bf16 fused graph: same function up to bf16 rounding; detections come out of the HIP path
+    fused16 = FusedRetinaNet(model, dtype=torch.bfloat16)
+    with torch.no_grad():
+        c16, _ = fused16.heads(x)
+        det = fused16(x)
+    for r, g in zip(ref_cls, c16):
+        cos = F.cosine_similarity(r.flatten().float(), g.flatten().float(), dim=0).item()
+        assert cos > 0.999, cos
+    assert det[0].shape == (2, 100) and det[1].shape == (2, 100, 4)
