@@ -43,7 +43,7 @@ extern "C" {
 #define ODTK_ERR_HIP          -3   /* a HIP runtime call failed; see odtk_last_hip_error() */
 #define ODTK_ERR_UNSUPPORTED  -4   /* dtype / layout combination not implemented          */
 
-#define ODTK_MAX_LEVELS    8       /* pyramid levels per odtk_decode_levels call          */
+#define ODTK_MAX_LEVELS    6       /* pyramid levels per call (P3..P7 = 5); keeps kernargs < 4 KiB */
 #define ODTK_MAX_ANCHORS   32      /* anchors per cell (9 axis-aligned, 27 rotated)       */
 #define ODTK_MAX_TOP_N     4096    /* per-level top_n                                     */
 #define ODTK_MAX_NMS_COUNT 7680    /* candidates per image into nms (5 x 1000 by default) */

@@ -1,0 +1,34 @@
+import sys, os, time
+sys.path[:0] = ['/root/repo', '/root/repo/retinanet-examples_amd']
+import torch
+torch.backends.cudnn.benchmark = True
+from odtk.model import Model
+from odtk.fused import FusedRetinaNet
+torch.manual_seed(0)
+m = Model('ResNet50FPN'); m.initialize(None)
+m = m.cuda().to(memory_format=torch.channels_last).eval()
+x = torch.randn(8, 3, 800, 1280, device='cuda').contiguous(memory_format=torch.channels_last)
+eng = FusedRetinaNet(m).cuda()
+def step(): return eng(x)
+for _ in range(8): step()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(20): step()
+torch.cuda.synchronize()
+print('eager fused: %.3f ms/step' % ((time.perf_counter() - t0) * 50))
+g = torch.cuda.CUDAGraph()
+s = torch.cuda.Stream(); s.wait_stream(torch.cuda.current_stream())
+with torch.cuda.stream(s):
+    for _ in range(3): step()
+torch.cuda.current_stream().wait_stream(s)
+with torch.cuda.graph(g):
+    out = step()
+for _ in range(3): g.replay()
+torch.cuda.synchronize()
+ref = step()
+g.replay(); torch.cuda.synchronize()
+print('graph output equals eager:', all(torch.equal(a, b) for a, b in zip(out, ref)))
+t0 = time.perf_counter()
+for _ in range(20): g.replay()
+torch.cuda.synchronize()
+print('hipGraph replay fused: %.3f ms/step' % ((time.perf_counter() - t0) * 50))

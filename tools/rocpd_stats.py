@@ -15,13 +15,26 @@ def main():
     ap.add_argument('db')
     ap.add_argument('--csv')
     ap.add_argument('--top', type=int, default=40)
+    ap.add_argument('--steady', metavar='PATTERN:N',
+                    help='restrict to the window spanned by the LAST N dispatches of the kernel matching PATTERN '
+                         '(e.g. prefilter_scan:10 = the 10 timed steps of bench.py), minus one step of lead-in')
     args = ap.parse_args()
     con = sqlite3.connect(args.db)
     cur = con.cursor()
+    where, params = '', ()
+    if args.steady:
+        pat, n = args.steady.rsplit(':', 1)
+        marks = cur.execute("select d.start, d.end from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s on "
+                            "d.kernel_id = s.id where s.kernel_name like ? order by d.start", ('%' + pat + '%',)).fetchall()
+        n = int(n)
+        first, last = marks[-n], marks[-1]
+        lead = (last[0] - first[0]) // max(n - 1, 1)          # one step before the first marker
+        where, params = 'where d.start >= ? and d.end <= ?', (first[0] - lead, last[1] + 2000000)
+        print('steady window: %.3f ms for %d steps' % ((last[1] - first[0] + lead) / 1e6, n))
     rows = cur.execute(
         "select s.kernel_name, count(*), sum(d.end - d.start), avg(d.end - d.start), min(d.end - d.start), "
         "max(d.end - d.start) from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s on d.kernel_id = s.id "
-        "group by s.kernel_name order by 3 desc").fetchall()
+        + where + " group by s.kernel_name order by 3 desc", params).fetchall()
     total = sum(r[2] for r in rows) or 1
     lines = ['name,calls,total_ns,avg_ns,min_ns,max_ns,percent']
     for name, calls, tot, avg, mn, mx in rows:
