@@ -165,12 +165,23 @@ def main():
     alg_bytes = bytes_per_score * scores_per_batch
     ms, n = prof['prefilter_scan_kernel']
     roofline = None
+    # HBM traffic per launch comes from PMC passes (cannot be collected live next to the timing):
+    # profiles/r01_pmc_traffic.json, quoted only when the workload matches the profiled one
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')))
+        key = 'bf16_logits_channels_last' if (model.fused_postprocess and bytes_per_score == 2) else 'fp32_scores_nchw'
+        if pmc[key]['scores_per_launch'] == scores_per_batch and (bytes_per_score == 2) == (key[0] == 'b'):
+            traffic = pmc[key]['traffic_bytes']
+    except Exception:
+        traffic = None
     if n:
         avg_ms = ms / n
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
         roofline = {'kernel': 'prefilter_scan_kernel', 'bound': 'hbm', 'achieved': round(achieved, 1),
                     'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
-                    'traffic': None, 'alg_bytes_per_launch': alg_bytes, 'bytes_per_score': bytes_per_score, 'avg_ms': round(avg_ms, 5), 'launches': n}
+                    'traffic': traffic, 'traffic_source': 'profiles/r01_pmc_traffic.json (rocprofv3 --pmc, same workload)'
+                    if traffic else None, 'alg_bytes_per_launch': alg_bytes, 'bytes_per_score': bytes_per_score, 'avg_ms': round(avg_ms, 5), 'launches': n}
     kernels = {k: {'avg_us': round(v[0] / v[1] * 1e3, 2), 'launches': v[1]} for k, v in prof.items() if v[1]}
     conv_tflops = flops_img * (value / world) / 1e12
     conv_roofline = {'bound': 'mfma', 'achieved': round(conv_tflops, 1), 'peak': MFMA_BF16_PEAK_TFLOPS,
