@@ -1,0 +1,82 @@
+"""BASELINE.json configs other than the bench line, as parity cases on real model head tensors.
+
+config[0]  ResNet18FPN, 1 synthetic 3x512x512 image, fp32: Model.forward (HIP post-processing) vs the
+           reference's CPU algorithm (oracle) on the SAME head tensors.
+config[4]  --rotated-bbox: ResNet(18)FPN with 27 anchors / 6 box parameters through the rotated HIP
+           decode + rotated NMS vs the C restatement of decode_rotate.cu / nms_iou.cu.
+(The convolutions themselves are library kernels; CPU and GPU convs differ in fp32 rounding, so the
+comparison point is the head tensors, as SURVEY.md 0.7 prescribes.)"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import box_oracle, c_oracle
+from odtk import box
+from odtk.model import Model
+
+pytestmark = pytest.mark.gpu
+
+
+def _calibrated(backbone, rotated, size, batch, seed=0, classes=80):
+    torch.manual_seed(seed)
+    model = Model(backbone, classes=classes, rotated_bbox=rotated)
+    model.initialize(None)
+    model = model.cuda().eval()
+    x = torch.randn(batch, 3, *size, device='cuda')
+    with torch.no_grad():
+        cls_heads, _ = model.heads(x)
+        bias = model.cls_head[-1].bias.view(1, -1, 1, 1)
+        sigma = torch.cat([(c - bias).flatten() for c in cls_heads]).std()
+        model.cls_head[-1].weight.mul_(0.7 / sigma)        # class prior alone gives zero detections
+        if rotated:                                          # rotated box head shares the prior init
+            model.box_head[-1].bias.zero_()
+    return model, x
+
+
+def test_config0_resnet18fpn_512_plumbing():
+    model, x = _calibrated('ResNet18FPN', False, (512, 512), 1)
+    with torch.no_grad():
+        cached = model.heads(x)
+        model.heads = lambda _x: cached
+        fused = model(x)
+        model.fused_postprocess = False
+        plain = model(x)
+    assert fused[0].shape == (1, 100) and fused[1].shape == (1, 100, 4) and fused[2].shape == (1, 100)
+    for f, p in zip(fused, plain):
+        assert torch.equal(f, p)
+    cls_heads, box_heads = cached
+    strides = [512 // c.shape[-1] for c in cls_heads]
+    assert strides == [8, 16, 32, 64, 128]
+    ref = box_oracle.postprocess([c.sigmoid().cpu() for c in cls_heads], [b.cpu() for b in box_heads], strides,
+                                 model.anchors, model.threshold, model.top_n, model.nms, model.detections)
+    assert int((ref[0] > 0).sum()) > 20
+    # scores go through torch's GPU sigmoid vs CPU sigmoid here: compare what is bit-stable
+    # (selection + classes via the HIP path on GPU-materialised scores), boxes within tolerance
+    gpu_scores = [c.sigmoid() for c in cls_heads]
+    hip = box.detect(gpu_scores, box_heads, strides, model.anchors, model.threshold, model.top_n, model.nms,
+                     model.detections)
+    ref2 = box_oracle.postprocess([c.cpu() for c in gpu_scores], [b.cpu() for b in box_heads], strides,
+                                  model.anchors, model.threshold, model.top_n, model.nms, model.detections)
+    assert torch.equal(hip[0].cpu(), ref2[0]) and torch.equal(hip[2].cpu(), ref2[2])
+    assert (hip[1].cpu() - ref2[1]).abs().max() <= 1.3e-4
+    for f, h in zip(fused, hip):
+        assert torch.equal(f, h)
+
+
+def test_config4_rotated_model():
+    model, x = _calibrated('ResNet18FPN', True, (256, 320), 2, seed=1, classes=10)
+    assert model.num_anchors == 27 and model.box_head[-1].out_channels == 27 * 6
+    with torch.no_grad():
+        cls_heads, box_heads = model.heads(x)
+        model.heads = lambda _x: (cls_heads, box_heads)
+        out = model(x)
+    assert out[1].shape == (2, 100, 6)
+    strides = [320 // c.shape[-1] for c in cls_heads]
+    scores = [c.sigmoid() for c in cls_heads]
+    dec = [c_oracle.decode(s.cpu().numpy(), b.cpu().numpy(), st, model.threshold, model.top_n,
+                           model.anchors[st][0].numpy(), rotated=True) for s, b, st in zip(scores, box_heads, strides)]
+    cat = [np.concatenate(t, 1) for t in zip(*dec)]
+    ref = c_oracle.nms(cat[0], cat[1], cat[2], model.nms, model.detections, rotated=True)
+    assert int((ref[0] > 0).sum()) > 20
+    for h, r in zip(out, ref[:3]):
+        assert np.array_equal(np.ascontiguousarray(h.cpu().numpy()).view(np.uint32), r.view(np.uint32))
