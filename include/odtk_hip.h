@@ -188,6 +188,10 @@ int odtk_bias_act(void *y, const float *bias, const void *residual, size_t n_pix
 #define ODTK_KERNEL_IOU       3   /* iou_pairs_kernel                              */
 #define ODTK_KERNEL_EPILOGUE  4   /* bias_act_kernel                               */
 #define ODTK_KERNEL_COUNT     5
+/* on: 0 = off, otherwise a bit mask of kernel ids (1 << ODTK_KERNEL_*), -1 = all.  An event pair
+ * is a queue marker before and after the kernel: cheap for the 3 post-processing launches of a step,
+ * measurably NOT free for the ~110 epilogue launches (about 10 % of an 8.7 ms step), so time those
+ * only in a separate pass. */
 int odtk_profile_enable(int on);
 int odtk_profile_collect(double total_ms[ODTK_KERNEL_COUNT], int launches[ODTK_KERNEL_COUNT]);
 

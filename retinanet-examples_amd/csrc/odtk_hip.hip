@@ -39,7 +39,7 @@ int hip_fail(hipError_t e, const char *what) {
 struct EventPair { hipEvent_t start, stop; };
 struct Profiler {
   std::mutex mu;
-  bool on = false;
+  unsigned on = 0;   // bit k set: kernel id k is timed
   std::vector<EventPair> pending[ODTK_KERNEL_COUNT];
   std::vector<EventPair> spare;
 };
@@ -49,9 +49,9 @@ constexpr size_t kMaxPendingEvents = 1 << 16;
 struct KernelTimer {   // RAII: records start now and stop at scope exit, on `stream`
   int id; hipStream_t stream; EventPair ev; bool active = false;
   KernelTimer(int id_, hipStream_t s) : id(id_), stream(s) {
-    if (!g_prof.on) return;
+    if (!((g_prof.on >> id) & 1u)) return;
     std::lock_guard<std::mutex> lock(g_prof.mu);
-    if (!g_prof.on || g_prof.pending[id].size() >= kMaxPendingEvents) return;
+    if (!((g_prof.on >> id) & 1u) || g_prof.pending[id].size() >= kMaxPendingEvents) return;
     if (!g_prof.spare.empty()) { ev = g_prof.spare.back(); g_prof.spare.pop_back(); }
     else if (hipEventCreate(&ev.start) != hipSuccess || hipEventCreate(&ev.stop) != hipSuccess) return;
     active = hipEventRecord(ev.start, stream) == hipSuccess;
@@ -347,7 +347,7 @@ const char *odtk_last_hip_error(void) { return g_last_error; }
 
 int odtk_profile_enable(int on) {
   std::lock_guard<std::mutex> lock(g_prof.mu);
-  g_prof.on = on != 0;
+  g_prof.on = on < 0 ? ~0u : static_cast<unsigned>(on);
   return ODTK_OK;
 }
 

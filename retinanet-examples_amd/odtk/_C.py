@@ -323,9 +323,18 @@ def bias_act_(y, bias, residual=None, relu=True):
     return y
 
 
-def profile_enable(on=True):
-    """Bracket every kernel launch of the library with a hipEvent pair on its launch stream."""
-    _check(library().odtk_profile_enable(1 if on else 0), 'profile_enable')
+def profile_enable(on=True, kernels=None):
+    """Bracket kernel launches of the library with hipEvent pairs on their launch stream.
+    kernels: iterable of names from KERNEL_NAMES (default: all)."""
+    if not on:
+        mask = 0
+    elif kernels is None:
+        mask = -1
+    else:
+        mask = 0
+        for k in kernels:
+            mask |= 1 << KERNEL_NAMES.index(k)
+    _check(library().odtk_profile_enable(mask), 'profile_enable')
 
 
 def profile_collect():
