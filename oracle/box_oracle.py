@@ -164,3 +164,51 @@ def postprocess(cls_heads, box_heads, strides, anchors_per_stride, threshold=0.0
                for c, b, s in zip(cls_heads, box_heads, strides)]
     scores, boxes, classes = (torch.cat(t, 1) for t in zip(*decoded))
     return nms(scores, boxes, classes, nms_thresh, detections)
+
+
+# ---------------------------------------------------------------------------------------------
+# training-side target assignment
+# ---------------------------------------------------------------------------------------------
+def box2delta(boxes, anchors):
+    """box.py:67-78."""
+    a_wh = anchors[:, 2:] - anchors[:, :2] + 1
+    a_ctr = anchors[:, :2] + 0.5 * a_wh
+    b_wh = boxes[:, 2:] - boxes[:, :2] + 1
+    b_ctr = boxes[:, :2] + 0.5 * b_wh
+    return torch.cat([(b_ctr - a_ctr) / a_wh, torch.log(b_wh / a_wh)], 1)
+
+
+def snap_to_anchors(boxes, size, stride, anchors, num_classes, anchor_ious):
+    """box.py:134-189 restated in the anchor order [A, H, W] directly (the reference builds
+    [A, W, H] and transposes; every per-anchor value is independent of that order).
+    boxes [N, 5] = (x, y, w, h, class); size = [W*stride, H*stride] in pixels.
+    -> cls_target [A, C, H, W], box_target [A, 4, H, W], depth [A, 1, H, W]."""
+    A = anchors.shape[0]
+    W, H = int(size[0] / stride), int(size[1] / stride)
+    if boxes.nelement() == 0:
+        return torch.zeros(A, num_classes, H, W), torch.zeros(A, 4, H, W), torch.zeros(A, 1, H, W)
+    boxes, classes = boxes.split(4, dim=1)
+    xs = torch.arange(0, size[0], stride, dtype=classes.dtype)
+    ys = torch.arange(0, size[1], stride, dtype=classes.dtype)
+    gy, gx = torch.meshgrid(ys, xs, indexing='ij')                       # [H, W]
+    grid = torch.stack((gx, gy, gx, gy), 2).unsqueeze(0)                 # [1, H, W, 4]
+    anc = (grid + anchors.view(-1, 1, 1, 4).to(classes.dtype)).contiguous().view(-1, 4)   # (a, y, x)
+    boxes = torch.cat([boxes[:, :2], boxes[:, :2] + boxes[:, 2:] - 1], 1)
+    xy1 = torch.max(anc[:, None, :2], boxes[:, :2])
+    xy2 = torch.min(anc[:, None, 2:], boxes[:, 2:])
+    inter = torch.prod((xy2 - xy1 + 1).clamp(0), 2)
+    boxes_area = torch.prod(boxes[:, 2:] - boxes[:, :2] + 1, 1)
+    anc_area = torch.prod(anc[:, 2:] - anc[:, :2] + 1, 1)
+    overlap = inter / (anc_area[:, None] + boxes_area - inter)
+    overlap, indices = overlap.max(1)
+    box_target = box2delta(boxes[indices], anc).view(A, H, W, 4).permute(0, 3, 1, 2).contiguous()
+    depth = torch.ones_like(overlap) * -1
+    depth[overlap < anchor_ious[0]] = 0
+    fg = overlap >= anchor_ious[1]
+    depth[fg] = classes[indices][fg].squeeze(1) + 1
+    cls_idx = classes[indices].long().view(-1)
+    cls_idx[overlap < anchor_ious[0]] = num_classes
+    cls_target = torch.zeros(anc.shape[0], num_classes + 1, dtype=boxes.dtype)
+    cls_target.scatter_(1, cls_idx.view(-1, 1), 1)
+    cls_target = cls_target[:, :num_classes].view(A, H, W, num_classes).permute(0, 3, 1, 2).contiguous()
+    return cls_target, box_target, depth.view(A, 1, H, W)

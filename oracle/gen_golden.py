@@ -108,6 +108,23 @@ def anchors_case():
     print('anchors.npz')
 
 
+def snap_case(name, seed, stride, size, n_boxes, classes=10, ious=(0.4, 0.5)):
+    """reference box.py:134-189 on random ground-truth boxes (x, y, w, h, class)."""
+    import warnings
+    warnings.filterwarnings('ignore')
+    g = torch.Generator().manual_seed(seed)
+    anchors = ref_loader.ref_generate_anchors(stride, RATIOS, SCALES)
+    xy = torch.rand(n_boxes, 2, generator=g) * torch.tensor([size[0] * 0.7, size[1] * 0.7])
+    wh = torch.rand(n_boxes, 2, generator=g) * torch.tensor([size[0] * 0.5, size[1] * 0.5]) + 8
+    cls = torch.randint(0, classes, (n_boxes, 1), generator=g).float()
+    boxes = torch.cat([xy.floor(), wh.floor(), cls], 1)
+    out = ref_loader.reference_box().snap_to_anchors(boxes, list(size), stride, anchors, classes, 'cpu', list(ious))
+    np.savez_compressed(os.path.join(GOLDEN, name + '.npz'), kind='snap', boxes=_np(boxes), size=np.array(size),
+                        stride=stride, anchors=_np(anchors), classes=classes, ious=np.array(ious),
+                        cls_target=_np(out[0]), box_target=_np(out[1]), depth=_np(out[2]))
+    print('%-28s fg %d ignore %d' % (name, int((out[2] > 0).sum()), int((out[2] < 0).sum())))
+
+
 def main():
     assert ref_loader.available(), 'needs /root/reference'
     os.makedirs(GOLDEN, exist_ok=True)
@@ -142,6 +159,11 @@ def main():
     nms_case('nms_clustered_3000', 2, 3000, 31, 0.5, 100)
     nms_case('nms_thr03_det10', 3, 500, 32, 0.3, 10)
     nms_case('nms_few', 2, 40, 33, 0.5, 100, zero_frac=0.8)
+
+    snap_case('snap_s16_256x160', 41, 16, (256, 160), 7)
+    snap_case('snap_s8_128x128', 42, 8, (128, 128), 20)
+    snap_case('snap_s64_one_box', 43, 64, (256, 192), 1)
+    snap_case('snap_s32_none', 44, 32, (128, 96), 0)
 
 
 if __name__ == '__main__':

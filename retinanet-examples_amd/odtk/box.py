@@ -114,6 +114,107 @@ def delta2box_rotated(deltas, anchors, size, stride):
                       torch.atan2(deltas[:, 4], deltas[:, 5])[:, None]], 1)
 
 
+def _cell_anchors(anchors, size, stride, dtype, device):
+    """All anchors of a level in (anchor, y, x) order, [A*H*W, K] (K = 4 corners or 8 quad coords)."""
+    xs = torch.arange(0, size[0], stride, device=device, dtype=dtype)
+    ys = torch.arange(0, size[1], stride, device=device, dtype=dtype)
+    gy, gx = torch.meshgrid(ys, xs, indexing='ij')
+    k = anchors.shape[1]
+    grid = torch.stack([gx, gy] * (k // 2), 2).unsqueeze(0)                       # [1, H, W, K]
+    return (grid + anchors.view(-1, 1, 1, k).to(device=device, dtype=dtype)).reshape(-1, k)
+
+
+def _targets_from_overlap(overlap, boxes_xyxy, classes, cell, num_anchors, height, width, num_classes, anchor_ious,
+                          to_delta):
+    """Shared tail of snap_to_anchors[_rotated] (reference box.py:165-189 / :228-252): best box per
+    anchor -> regression target, depth (-1 ignore / 0 background / class+1) and one-hot class target,
+    produced directly in [A, *, H, W] order."""
+    overlap, best = overlap.max(1)
+    box_target = to_delta(boxes_xyxy[best], cell)
+    nb = box_target.shape[1]
+    box_target = box_target.view(num_anchors, height, width, nb).permute(0, 3, 1, 2).contiguous()
+    background = overlap < anchor_ious[0]
+    foreground = overlap >= anchor_ious[1]
+    best_cls = classes[best].view(-1)
+    depth = torch.full_like(overlap, -1)
+    depth[background] = 0
+    depth[foreground] = best_cls[foreground] + 1
+    onehot_idx = best_cls.long()
+    onehot_idx[background] = num_classes                                          # background has no class
+    cls_target = torch.zeros((cell.shape[0], num_classes + 1), device=overlap.device, dtype=boxes_xyxy.dtype)
+    cls_target.scatter_(1, onehot_idx.view(-1, 1), 1)
+    cls_target = cls_target[:, :num_classes].view(num_anchors, height, width, num_classes).permute(0, 3, 1, 2)
+    return cls_target.contiguous(), box_target, depth.view(num_anchors, 1, height, width)
+
+
+def snap_to_anchors(boxes, size, stride, anchors, num_classes, device, anchor_ious):
+    """Training targets for one image and one pyramid level (reference box.py:134-189).
+
+    boxes [N, 5] = (x, y, w, h, class); size = [W*stride, H*stride].  Returns
+    cls_target [A, C, H, W], box_target [A, 4, H, W], depth [A, 1, H, W].  Pure torch like the
+    reference's (which has no native op here) and device-agnostic; per-anchor values equal the
+    reference's (it builds [A, W, H] and transposes, which changes no value)."""
+    num_anchors = anchors.shape[0]
+    width, height = int(size[0] / stride), int(size[1] / stride)
+    if boxes.nelement() == 0:
+        return (torch.zeros([num_anchors, num_classes, height, width], device=device),
+                torch.zeros([num_anchors, 4, height, width], device=device),
+                torch.zeros([num_anchors, 1, height, width], device=device))
+    boxes, classes = boxes.split(4, dim=1)
+    cell = _cell_anchors(anchors, size, stride, classes.dtype, device)
+    xyxy = torch.cat([boxes[:, :2], boxes[:, :2] + boxes[:, 2:] - 1], 1)
+    lo = torch.max(cell[:, None, :2], xyxy[:, :2])
+    hi = torch.min(cell[:, None, 2:], xyxy[:, 2:])
+    inter = torch.prod((hi - lo + 1).clamp(0), 2)
+    area_b = torch.prod(xyxy[:, 2:] - xyxy[:, :2] + 1, 1)
+    area_a = torch.prod(cell[:, 2:] - cell[:, :2] + 1, 1)
+    overlap = inter / (area_a[:, None] + area_b - inter)
+    return _targets_from_overlap(overlap, xyxy, classes, cell, num_anchors, height, width, num_classes, anchor_ious,
+                                 box2delta)
+
+
+def rotate_boxes(boxes, points=False):
+    """(x, y, w, h, theta) targets -> ([x1, y1, x2, y2, sin, cos], ordered corner quads [N, 8])
+    (reference utils.py:33-82; `points=True` takes (x1, y1, x2, y2, theta))."""
+    theta = boxes[:, 4]
+    cos, sin = torch.cos(theta), torch.sin(theta)
+    if points:
+        x1, y1, x2, y2 = boxes[:, 0], boxes[:, 1], boxes[:, 2], boxes[:, 3]
+        cx, cy = (x1 + x2) / 2, (y1 + y2) / 2
+    else:
+        x1, y1 = boxes[:, 0], boxes[:, 1]
+        x2, y2 = x1 + boxes[:, 2], y1 + boxes[:, 3]
+        cx, cy = x1 + boxes[:, 2] / 2, y1 + boxes[:, 3] / 2
+    quads = []
+    for px, py in ((x1, y1), (x2, y1), (x2, y2), (x1, y2)):
+        dx, dy = px - cx, py - cy
+        quads.append(torch.stack([cos * dx + sin * dy + cx, -sin * dx + cos * dy + cy], 1))
+    axis = torch.cat([boxes[:, :2], boxes[:, :2] + boxes[:, 2:4] - 1, sin[:, None], cos[:, None]], 1)
+    return axis, _order_quads(torch.stack(quads, 1)).view(-1, 8)
+
+
+def snap_to_anchors_rotated(boxes, size, stride, anchors, num_classes, device, anchor_ious):
+    """Rotated training targets (reference box.py:192-252): overlap = polygon IoU between the
+    ground-truth quads and the rotated anchor quads, computed by the HIP `iou` op (GPU only -- the
+    reference has no CPU implementation of it either, box.py:220-223)."""
+    anchors_axis, anchors_rotated = anchors
+    num_anchors = anchors_rotated.shape[0]
+    width, height = int(size[0] / stride), int(size[1] / stride)
+    if boxes.nelement() == 0:
+        return (torch.zeros([num_anchors, num_classes, height, width], device=device),
+                torch.zeros([num_anchors, 6, height, width], device=device),
+                torch.zeros([num_anchors, 1, height, width], device=device))
+    boxes, classes = boxes.split(5, dim=1)
+    boxes_axis, boxes_quads = rotate_boxes(boxes)
+    boxes_axis, boxes_quads = boxes_axis.to(device), boxes_quads.to(device)
+    cell_axis = _cell_anchors(anchors_axis, size, stride, torch.float32, device)
+    cell_quads = _cell_anchors(anchors_rotated, size, stride, torch.float32, device)
+    _require_gpu(boxes_quads, 'snap_to_anchors_rotated')
+    overlap = _C.iou(boxes_quads.contiguous().view(-1), cell_quads.contiguous().view(-1))[0]
+    return _targets_from_overlap(overlap, boxes_axis, classes, cell_axis, num_anchors, height, width, num_classes,
+                                 anchor_ious, box2delta_rotated)
+
+
 def _require_gpu(t, what):
     if not t.is_cuda:
         raise RuntimeError('odtk.box.%s: tensors must be on the GPU -- the MI355X build has no CPU path '

@@ -1,0 +1,82 @@
+"""Training-side target assignment: the oracle restatement against the
+reference's own snap_to_anchors (golden fixtures + live), and the product implementation against
+the oracle."""
+import glob
+import os
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import box_oracle, ref_loader
+from odtk import box
+
+GOLDEN = os.path.join(os.path.dirname(__file__), 'golden')
+SNAP = sorted(p for p in glob.glob(os.path.join(GOLDEN, 'snap_*.npz')))
+RATIOS = [1.0, 2.0, 0.5]
+SCALES = [4 * 2 ** (i / 3) for i in range(3)]
+
+
+def _bits(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float32)).view(np.uint32)
+
+
+@pytest.mark.parametrize('path', SNAP, ids=os.path.basename)
+def test_snap_to_anchors_matches_reference_fixture(path):
+    with np.load(path) as z:
+        g = {k: z[k] for k in z.files}
+    boxes, anchors = torch.from_numpy(g['boxes']).view(-1, 5), torch.from_numpy(g['anchors'])
+    size, stride, classes, ious = [int(v) for v in g['size']], int(g['stride']), int(g['classes']), list(g['ious'])
+    ora = box_oracle.snap_to_anchors(boxes, size, stride, anchors, classes, ious)
+    prod = box.snap_to_anchors(boxes, size, stride, anchors, classes, 'cpu', ious)
+    for o, p, k in zip(ora, prod, ('cls_target', 'box_target', 'depth')):
+        assert o.shape == tuple(g[k].shape)
+        assert np.array_equal(_bits(o.numpy()), _bits(g[k])), k          # oracle == reference, bit for bit
+        assert np.array_equal(_bits(p.numpy()), _bits(g[k])), k          # product == reference, bit for bit
+
+
+@pytest.mark.skipif(not ref_loader.available() or torch.cuda.is_available(), reason='reference tree only in the build container')
+def test_snap_to_anchors_live_reference():
+    warnings.filterwarnings('ignore')
+    g = torch.Generator().manual_seed(9)
+    for stride, size, n in [(8, (320, 256), 30), (32, (320, 256), 5), (128, (384, 256), 2)]:
+        anchors = box.generate_anchors(stride, RATIOS, SCALES)
+        xy = torch.rand(n, 2, generator=g) * torch.tensor([size[0] * 0.7, size[1] * 0.7])
+        wh = torch.rand(n, 2, generator=g) * torch.tensor([size[0] * 0.6, size[1] * 0.6]) + 4
+        boxes = torch.cat([xy, wh, torch.randint(0, 80, (n, 1), generator=g).float()], 1)
+        ref = ref_loader.reference_box().snap_to_anchors(boxes, list(size), stride, anchors, 80, 'cpu', [0.4, 0.5])
+        got = box.snap_to_anchors(boxes, list(size), stride, anchors, 80, 'cpu', [0.4, 0.5])
+        for r, o in zip(ref, got):
+            assert np.array_equal(_bits(r.numpy()), _bits(o.numpy()))
+
+
+def test_rotate_boxes_geometry():
+    b = torch.tensor([[10., 20., 40., 10., 0.0], [10., 20., 40., 10., np.pi / 2], [0., 0., 8., 8., 0.3]])
+    axis, quads = box.rotate_boxes(b)
+    assert torch.allclose(axis[0], torch.tensor([10., 20., 49., 29., 0., 1.]))
+    q0 = quads[0].view(4, 2)
+    assert torch.allclose(q0, torch.tensor([[10., 20.], [50., 20.], [50., 30.], [10., 30.]]))        # tl, tr, br, bl
+    # rotation preserves side lengths and the centre
+    for i in range(3):
+        q = quads[i].view(4, 2)
+        assert torch.allclose(q.mean(0), torch.tensor([b[i, 0] + b[i, 2] / 2, b[i, 1] + b[i, 3] / 2]), atol=1e-4)
+        sides = (q - q.roll(-1, 0)).norm(dim=1)
+        assert torch.allclose(sides.sort().values, torch.tensor([b[i, 2:4].min()] * 2 + [b[i, 2:4].max()] * 2), atol=1e-4)
+
+
+def test_loss_pipeline_on_cpu():
+    """Model._compute_loss end to end on CPU (pure torch part of the training path)."""
+    from odtk.model import Model
+    torch.manual_seed(0)
+    m = Model('ResNet18FPN', classes=5)
+    m.initialize(None)
+    m.train()
+    x = torch.randn(2, 3, 128, 128)
+    targets = torch.tensor([[[10., 10., 60., 50., 2.], [70., 30., 40., 80., 4.], [-1, -1, -1, -1, -1]],
+                            [[5., 60., 100., 40., 0.], [-1, -1, -1, -1, -1], [-1, -1, -1, -1, -1]]])
+    cls_loss, box_loss = m([x, targets])
+    assert torch.isfinite(cls_loss) and torch.isfinite(box_loss) and cls_loss > 0
+    (cls_loss + box_loss).backward()
+    g = m.cls_head[-1].weight.grad
+    assert g is not None and torch.isfinite(g).all() and g.abs().sum() > 0
