@@ -168,6 +168,8 @@ def main():
     with torch.no_grad(), torch.autocast('cuda', dtype=amp_dtype, enabled=amp_dtype is not None):
         cls_heads, _ = model.heads(x)
     scores_per_batch = sum(c.numel() for c in cls_heads)
+    with torch.no_grad():
+        candidates = [int((c.float().sigmoid() >= model.threshold).sum().item()) // args.batch for c in cls_heads]
     # every score is read exactly once, in the dtype the kernel consumes: the head's own dtype on the
     # fused path, fp32 on the reference-sequence path (after torch's .float())
     bytes_per_score = cls_heads[0].element_size() if model.fused_postprocess else 4
@@ -240,6 +242,7 @@ def main():
                        'graph': 'BN folded into conv weights + HIP bias/skip/ReLU epilogue' if fuse_graph
                                 else 'eager nn.Module under autocast'},
             'roofline': roofline, 'conv_roofline': conv_roofline, 'kernels': kernels,
+            'candidates_per_image_per_level': candidates,
             'cpu_baseline': cpu_baseline,
         }
         print(json.dumps(line), flush=True)

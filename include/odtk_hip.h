@@ -193,6 +193,9 @@ int odtk_bias_act(void *y, const float *bias, const void *residual, size_t n_pix
  * measurably NOT free for the ~110 epilogue launches (about 10 % of an 8.7 ms step), so time those
  * only in a separate pass. */
 int odtk_profile_enable(int on);
+/* Debug: device buffer (>= 16 KiB) that select_decode / nms workgroups stamp with wall_clock64()
+ * (100 MHz) at their phase boundaries; NULL (default) disables.  Not for production use. */
+int odtk_debug_set_trace(void *device_buffer);
 int odtk_profile_collect(double total_ms[ODTK_KERNEL_COUNT], int launches[ODTK_KERNEL_COUNT]);
 
 #ifdef __cplusplus

@@ -28,7 +28,7 @@
 
 #include "common.hpp"
 #include "rotated_iou.hpp"
-#include "select_decode.hpp"   // radix_threshold, bitonic_sort_desc
+#include "select_decode.hpp"   // radix_threshold, sort_keys_desc
 #include "../../include/odtk_hip.h"
 
 namespace odtk {
@@ -49,6 +49,7 @@ struct NmsArgs {
   int ndet;
   float thresh;
   uint32_t flags;
+  unsigned long long *trace;   // debug (odtk_debug_set_trace): 8 timestamps per workgroup, or null
 };
 
 // LDS carve-up shared by host (size) and device (pointers); every offset is 16-byte aligned.
@@ -95,6 +96,29 @@ __device__ __forceinline__ bool box_suppresses(const float *m, const float *j, f
   else return rotated_suppresses(m, j, thr, own_angle);
 }
 
+// Does any box kept at ranks [q0, q1) suppress candidate (jb, jc)?  Class words are fetched eight at
+// a time (independent LDS reads) -- the common case is "no kept box of this class", and a one-read-
+// per-trip loop would pay the LDS latency once per kept box.
+template <int NB>
+__device__ __forceinline__ bool pull_against_kept(const float *s_kcls, const float *s_kbox, int q0, int q1,
+                                                  const float *jb, float jc, bool alive, float thr, bool own_angle) {
+  for (int q = q0; q < q1 && alive; q += 8) {
+    float kc[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) kc[u] = (q + u < q1) ? s_kcls[q + u] : __builtin_nanf("");   // NaN equals nothing
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (alive && kc[u] == jc) {                               // box.py:351: a different class keeps
+        float mb[NB];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) mb[k] = s_kbox[(q + u) * NB + k];
+        if (box_suppresses<NB>(mb, jb, thr, own_angle)) alive = false;
+      }
+    }
+  }
+  return alive;
+}
+
 struct LdsKeySource {   // keys of this image that rank below `upper` (exclusive)
   const uint64_t *keys;
   uint32_t count;
@@ -130,6 +154,7 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsArgs a) {
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int img = blockIdx.x;
+  if (a.trace && tid == 0) a.trace[(gridDim.x + blockIdx.x) * 8 + 0] = wall_clock64();
   const uint32_t count = a.count;
   const int ndet = a.ndet;
   const float thr = a.thresh;
@@ -141,9 +166,18 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsArgs a) {
   // ---- compact positive-score candidates into 64-bit (score, ~position) keys ----
   if (tid == 0) { s_misc[32] = 0; s_misc[34] = 0; }
   __syncthreads();
-  for (uint32_t base = 0; base < count; base += kNmsThreads) {
-    const uint32_t i = base + tid;
-    const float s = i < count ? in_s[i] : 0.0f;
+  constexpr int kScoreLoads = (ODTK_MAX_NMS_COUNT + kNmsThreads - 1) / kNmsThreads;   // 8
+  float my_scores[kScoreLoads];
+#pragma unroll
+  for (int u = 0; u < kScoreLoads; ++u) {                   // all score loads in flight at once
+    const uint32_t i = u * kNmsThreads + tid;
+    my_scores[u] = i < count ? in_s[i] : 0.0f;
+  }
+#pragma unroll
+  for (int u = 0; u < kScoreLoads; ++u) {
+    const uint32_t i = u * kNmsThreads + tid;
+    if (u * kNmsThreads >= count) break;                    // block-uniform
+    const float s = my_scores[u];
     const bool pos = s > 0.0f;                              // box.py:328  score > 0 (NaN fails)
     const uint64_t m = __ballot(pos);
     if (m) {                                                // wave-uniform
@@ -155,6 +189,8 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsArgs a) {
   }
   __syncthreads();
   const uint32_t K = s_misc[32];
+  auto stamp = [&](int k) { if (a.trace && tid == 0) a.trace[(gridDim.x + blockIdx.x) * 8 + k] = wall_clock64(); };
+  stamp(1);
 
   uint32_t consumed = 0;             // candidates handed to earlier rounds
   uint64_t upper = ~0ull;            // keys >= upper were consumed
@@ -171,9 +207,10 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsArgs a) {
     if (tid == 0) s_misc[33] = 0;
     __syncthreads();
     src.for_each([&](uint64_t key) { if (key >= lower) s_sel[atomicAdd(&s_misc[33], 1u)] = key; });
-    for (uint32_t i = n_round + tid; i < kNmsRound; i += kNmsThreads) s_sel[i] = 0;   // pad: sorts last
     __syncthreads();
-    bitonic_sort_desc(s_sel, kNmsRound);
+    if (consumed == 0) stamp(2);
+    sort_keys_desc(s_sel, n_round);                        // pads to 1024 with zeros (sort last)
+    if (consumed == 0) stamp(3);
     upper = lower;
     consumed += n_round;
 
@@ -196,15 +233,7 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsArgs a) {
           float jb[NB];
 #pragma unroll
           for (int k = 0; k < NB; ++k) jb[k] = s_box[tid * NB + k];
-          const float jc = s_cls[tid];
-          for (int q = 0; q < kept_before && alive; ++q) {
-            if (s_kcls[q] == jc) {                              // box.py:351 class != keeps
-              float mb[NB];
-#pragma unroll
-              for (int k = 0; k < NB; ++k) mb[k] = s_kbox[q * NB + k];
-              if (box_suppresses<NB>(mb, jb, thr, own_angle)) alive = false;
-            }
-          }
+          alive = pull_against_kept<NB>(s_kcls, s_kbox, 0, kept_before, jb, s_cls[tid], true, thr, own_angle);
         }
         const uint64_t word = __ballot(alive);
         if (lane == 0) s_alive[(tid - c0) >> 6] = word;
@@ -215,25 +244,18 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsArgs a) {
       if (wave == 0) {
         int k_cnt = kept_before;
         for (int g = 0; g < kNmsChunk / kWave && k_cnt < ndet; ++g) {
-          const uint32_t r = c0 + g * kWave + lane;             // rank inside the round
+          const uint32_t r = c0 + g * kWave + lane;             // rank inside the round (< 1024)
           uint64_t mask = s_alive[g];
+          if (mask == 0) continue;                              // wave-uniform
           bool alive = (mask >> lane) & 1ull;
-          if (mask == 0) continue;
           float jb[NB];
 #pragma unroll
-          for (int k = 0; k < NB; ++k) jb[k] = s_box[(r < kNmsRound ? r : 0) * NB + k];
-          const float jc = s_cls[r < kNmsRound ? r : 0];
+          for (int k = 0; k < NB; ++k) jb[k] = s_box[r * NB + k];
+          const float jc = s_cls[r];
           // pull against the boxes kept earlier in THIS chunk
-          for (int q = kept_before; q < k_cnt; ++q) {
-            const float kc = s_kcls[q];
-            if (alive && kc == jc) {
-              float mb[NB];
-#pragma unroll
-              for (int k = 0; k < NB; ++k) mb[k] = s_kbox[q * NB + k];
-              if (box_suppresses<NB>(mb, jb, thr, own_angle)) alive = false;
-            }
-          }
-          // sequential greedy inside the group
+          alive = pull_against_kept<NB>(s_kcls, s_kbox, kept_before, k_cnt, jb, jc, alive, thr, own_angle);
+          // sequential greedy inside the group: one step per KEPT box, registers + readlane only
+          int my_rank = -1;
           mask = __ballot(alive);
           while (mask) {
             // mask is wave-uniform: keep l0 in an SGPR so the broadcasts are v_readlane, not LDS permutes
@@ -242,19 +264,19 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsArgs a) {
 #pragma unroll
             for (int k = 0; k < NB; ++k) mb[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(jb[k]), l0));
             const float mc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(jc), l0));
-            if (lane == l0) {                                   // keep it
-              const uint64_t key = s_sel[r];
-#pragma unroll
-              for (int k = 0; k < NB; ++k) s_kbox[k_cnt * NB + k] = jb[k];
-              s_kcls[k_cnt] = jc;
-              s_kscore[k_cnt] = key_score(key);
-              s_ksrc[k_cnt] = static_cast<int32_t>(key_index(key));
-              alive = false;
-            }
+            if (lane == l0) { my_rank = k_cnt; alive = false; } // kept: its entry is written after the loop
             ++k_cnt;
             if (k_cnt == ndet) break;
             if (alive && lane > l0 && jc == mc && box_suppresses<NB>(mb, jb, thr, own_angle)) alive = false;
             mask = __ballot(alive);
+          }
+          if (my_rank >= 0) {                                   // all lanes kept in this group, in parallel
+            const uint64_t key = s_sel[r];
+#pragma unroll
+            for (int k = 0; k < NB; ++k) s_kbox[my_rank * NB + k] = jb[k];
+            s_kcls[my_rank] = jc;
+            s_kscore[my_rank] = key_score(key);
+            s_ksrc[my_rank] = static_cast<int32_t>(key_index(key));
           }
         }
         if (lane == 0) s_misc[34] = static_cast<uint32_t>(k_cnt);
@@ -264,6 +286,8 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsArgs a) {
     }
   }
 
+  stamp(4);
+  if (a.trace && tid == 0) { a.trace[(gridDim.x + blockIdx.x) * 8 + 5] = consumed; a.trace[(gridDim.x + blockIdx.x) * 8 + 6] = K; }
   // ---- outputs: kept boxes, then the zero-padded tail (box.py:322-324) ----
   for (int t = tid; t < ndet; t += kNmsThreads) {
     const size_t o = static_cast<size_t>(img) * ndet + t;

@@ -24,6 +24,7 @@
 namespace {
 
 thread_local char g_last_error[256] = "";
+unsigned long long *g_trace = nullptr;   // odtk_debug_set_trace
 
 int hip_fail(hipError_t e, const char *what) {
   std::snprintf(g_last_error, sizeof g_last_error, "%s: %s", what, hipGetErrorString(e));
@@ -96,8 +97,9 @@ int decode_layout(int batch, int n_levels, const odtk_level_t *levels, int A, in
     // never less than one full tile's worth for tiny levels (a single tile feeds a single sub-list)
     const unsigned long long seg_cap = n < cand_cap_limit() ? n : cand_cap_limit();
     unsigned long long sub = (seg_cap + odtk::kSubLists - 1) / odtk::kSubLists;
-    const unsigned long long one_tile = n < static_cast<unsigned long long>(odtk::kTile) ? n : odtk::kTile;
-    if (sub < one_tile && n <= 4ull * odtk::kTile) sub = one_tile;
+    const unsigned long long span = static_cast<unsigned long long>(odtk::kTile) * odtk::kMaxSpanTiles;
+    const unsigned long long one_tile = n < span ? n : span;     // one workgroup feeds one sub-list
+    if (sub < one_tile && n <= 4ull * span) sub = one_tile;
     out->cap[l] = static_cast<uint32_t>((sub + 31) / 32 * 32);
     out->cand_off[l] = off;
     off += align_up(sizeof(uint64_t) * static_cast<size_t>(batch) * odtk::kSubLists * out->cap[l]);
@@ -170,6 +172,8 @@ int decode_levels_impl(int batch, int n_levels, const odtk_level_t *levels, int 
   odtk::DecodeArgs da;
   std::memset(&da, 0, sizeof da);
   uint32_t tiles = 0;
+  const uint32_t span = dtype == ODTK_F32 ? 1u : static_cast<uint32_t>(odtk::kMaxSpanTiles);
+  sa.span = static_cast<int>(span);
   for (int l = 0; l < n_levels; ++l) {
     const uint64_t total = static_cast<uint64_t>(batch) * lay.n[l];
     sa.lv[l].cls = levels[l].cls;
@@ -184,7 +188,8 @@ int decode_levels_impl(int batch, int n_levels, const odtk_level_t *levels, int 
     sa.lv[l].channels_last = static_cast<uint32_t>(levels[l].channels_last);
     sa.lv[l].tiles = static_cast<uint32_t>((total + odtk::kTile - 1) / odtk::kTile);
     sa.lv[l].chunk = (sa.lv[l].tiles + batch - 1) / batch;
-    tiles += sa.lv[l].chunk * batch;                       // launched workgroups (<= batch-1 idle ones)
+    sa.lv[l].chunk = (sa.lv[l].chunk + span - 1) / span * span;
+    tiles += sa.lv[l].chunk / span * batch;                // launched workgroups (a few idle ones per level)
 
     da.lv[l].cls = levels[l].cls;
     da.lv[l].box = levels[l].box;
@@ -216,6 +221,7 @@ int decode_levels_impl(int batch, int n_levels, const odtk_level_t *levels, int 
   da.num_classes = C;
   da.top_n = top_n;
   da.thresh = thresh;
+  da.trace = g_trace;
 
   const int n_seg = batch * n_levels;
   ODTK_HIP_TRY(hipMemsetAsync(counts, 0, sizeof(uint32_t) * n_seg * odtk::kSubLists, stream));
@@ -270,6 +276,7 @@ int nms_impl(int batch, const void *const *inputs, void *const *outputs, int n_o
   na.ndet = ndet;
   na.thresh = thresh;
   na.flags = flags;
+  na.trace = g_trace ? g_trace + 8 * 64 : nullptr;          // after the select_decode slots
   const size_t lds = odtk::NmsLds(na.count, ndet, nb).total;   // same carve-up the kernel computes
   if (lds > 160 * 1024) return ODTK_ERR_INVALID;
   return nb == 6 ? nms_launch<6>(na, batch, lds, stream) : nms_launch<4>(na, batch, lds, stream);
@@ -344,6 +351,11 @@ extern "C" {
 
 const char *odtk_version(void) { return "odtk-hip 0.1 (gfx950)"; }
 const char *odtk_last_hip_error(void) { return g_last_error; }
+
+int odtk_debug_set_trace(void *device_buffer) {
+  g_trace = static_cast<unsigned long long *>(device_buffer);
+  return ODTK_OK;
+}
 
 int odtk_profile_enable(int on) {
   std::lock_guard<std::mutex> lock(g_prof.mu);

@@ -28,9 +28,6 @@
 // Tiles with more than kStageCap raw hits (saturated / adversarial inputs) and the <= 1 tile per
 // image that straddles an image boundary take a rolled multi-round path over the same stage.
 #pragma once
-#ifndef ODTK_ABLATE
-#define ODTK_ABLATE 0
-#endif
 
 #include <type_traits>
 
@@ -42,8 +39,10 @@ namespace odtk {
 typedef uint32_t vuint4 __attribute__((ext_vector_type(4)));
 
 constexpr int kScanThreads = 256;
-constexpr int kTile = 16384;                     // elements per workgroup (64 per lane)
-constexpr int kStageCap = 1024;                  // hits staged in LDS per round (8 KiB)
+constexpr int kTile = 16384;                     // elements per tile (64 per lane)
+constexpr int kMaxSpanTiles = 2;                 // consecutive tiles per workgroup (ONE drain + ONE atomic for all):
+                                                 // measured bs=8: 16-bit 57.4 -> 52.4 us with 2; fp32 is better at 1
+constexpr int kStageCap = 2048;                  // hits staged in LDS per round (16 KiB; 4096 costs occupancy: 52 -> 62 us)
 constexpr int kSubLists = 16;                    // candidate sub-lists (and counters) per segment
 
 struct ScanLevel {
@@ -58,7 +57,7 @@ struct ScanLevel {
   uint32_t hw;           // H*W
   uint32_t channels_last;
   uint32_t tiles;        // tiles in this level = ceil(total / kTile)
-  uint32_t chunk;        // tiles per interleave chunk = ceil(tiles / batch)
+  uint32_t chunk;        // tiles per interleave chunk = ceil(tiles / batch), a multiple of the span
   uint32_t pad_;
 };
 
@@ -68,6 +67,7 @@ struct ScanArgs {
   uint64_t *cand;        // candidate pool
   int n_levels;
   int batch;
+  int span;              // tiles per workgroup, 1..kMaxSpanTiles
   float thresh;          // threshold on the SCORE
   float raw_lo;          // kLogits: conservative lower bound on the raw logit of any survivor
 };
@@ -130,7 +130,7 @@ __device__ __forceinline__ uint32_t memory_offset(uint32_t i, uint32_t channels,
 template <typename T, bool kLogits>
 __global__ __launch_bounds__(kScanThreads) void prefilter_scan_kernel(const ScanArgs a) {
   constexpr int kPer = T::kPerLoad;                        // elements per 16-byte load
-  constexpr int kVec = kTile / (kScanThreads * kPer);      // loads per lane: 16 (f32) or 8 (16-bit)
+  constexpr int kVec = kTile / (kScanThreads * kPer);      // loads per lane per tile: 16 (f32) or 8 (16-bit)
   __shared__ uint64_t s_stage[kStageCap];
   __shared__ uint32_t s_cnt;                               // raw hits staged this round
   __shared__ uint32_t s_ok;                                // of which pass the exact test
@@ -143,61 +143,33 @@ __global__ __launch_bounds__(kScanThreads) void prefilter_scan_kernel(const Scan
     if (i < a.n_levels && blockIdx.x >= a.lv[i].tile_begin) l = i;
   const ScanLevel &L = a.lv[l];
 
-  // Consecutive workgroups take tiles from DIFFERENT images (chunk c ~ image c of the flat level
-  // tensor): workgroups that run together then reserve slots on `batch` different counters.  One
-  // counter word sustains only ~88 returning atomics/us, and walking the tensor front to back keeps
-  // a single image's counter hot at a time (measured: +40 us on a 78 us scan at bs=8).
+  const uint32_t kSpanTiles = static_cast<uint32_t>(a.span);
+  // A workgroup owns a SPAN of `span` consecutive tiles.  Consecutive workgroups take spans from
+  // DIFFERENT images (chunk c ~ image c of the flat level tensor): workgroups that run together
+  // then reserve slots on `batch` different counters.  One counter word sustains only ~88 returning
+  // atomics/us, and walking the tensor front to back keeps a single image's counter hot at a time.
   const uint32_t j = blockIdx.x - L.tile_begin;
   const uint32_t chunk_id = j % static_cast<uint32_t>(a.batch), in_chunk = j / static_cast<uint32_t>(a.batch);
-  const uint32_t tile = chunk_id * L.chunk + in_chunk;
-  if (tile >= L.tiles) return;                            // padding workgroup (block-uniform exit)
-  const uint64_t tile_base = static_cast<uint64_t>(tile) * kTile;
+  const uint32_t tile0 = chunk_id * L.chunk + in_chunk * kSpanTiles;
+  if (tile0 >= L.tiles) return;                           // padding workgroup (block-uniform exit)
+  const uint64_t span_base = static_cast<uint64_t>(tile0) * kTile;
   const uint32_t n = L.n;
   const float thr = a.thresh;
   const float raw_thr = kLogits ? a.raw_lo : a.thresh;
-  const typename T::storage *tile_ptr = static_cast<const typename T::storage *>(L.cls) + tile_base;
-  const vuint4 *src = reinterpret_cast<const vuint4 *>(tile_ptr);
-  const uint64_t left = L.total - tile_base;               // > 0 by construction
-  const uint32_t tile_len = left < kTile ? static_cast<uint32_t>(left) : kTile;
-  const uint32_t n_vec = tile_len / kPer;                  // whole 16-byte groups in this tile
+  const typename T::storage *span_ptr = static_cast<const typename T::storage *>(L.cls) + span_base;
+  const uint64_t left = L.total - span_base;               // > 0 by construction
+  const uint32_t span_len = left < static_cast<uint64_t>(kSpanTiles) * kTile ? static_cast<uint32_t>(left) : kSpanTiles * kTile;
+  const uint32_t span_vec = span_len / kPer;               // whole 16-byte groups in this span
 
   if (tid == 0) { s_cnt = 0; s_ok = 0; }
 
-  // Every tile appends to ONE of the segment's kSubLists sub-lists (tile % kSubLists): a counter
-  // word sustains only ~88 returning atomics/us and ~30 k tiles per launch all want one, so the
-  // reservations are spread over 16x more words (measured: 116 -> see DESIGN.md us at bs=8).
-  const uint32_t sub = tile % kSubLists;
+  // Every span appends to ONE of the segment's kSubLists sub-lists: ~15 k workgroups per launch all
+  // want a slot reservation, so the returning atomics are spread over 16x more counter words
+  // (measured at bs=8: fp32 118 -> 89 us, bf16 102 -> 56 us).
+  const uint32_t sub = (tile0 / kSpanTiles) % kSubLists;
   auto counter_of = [&](uint32_t b) -> uint32_t * { return a.counts + (static_cast<size_t>(L.seg_base + b) * kSubLists + sub); };
   auto list_of = [&](uint32_t b) -> uint64_t * {
     return a.cand + L.cand_off + (static_cast<uint64_t>(b) * kSubLists + sub) * L.cap;
-  };
-
-  // ---- phase A: issue all loads first (kVec x 16 B per lane, lane-contiguous => coalesced) ----
-  vuint4 v[kVec];
-#pragma unroll
-  for (int u = 0; u < kVec; ++u) {
-    const uint32_t q = u * kScanThreads + tid;
-    if (q < n_vec) v[u] = __builtin_nontemporal_load(src + q);     // streamed once: keep it out of L2's way
-    else v[u] = std::is_same_v<T, F32> ? vuint4{0x7fc00000u, 0x7fc00000u, 0x7fc00000u, 0x7fc00000u}
-                                       : vuint4{0x7fc07fc0u, 0x7fc07fc0u, 0x7fc07fc0u, 0x7fc07fc0u};   // NaNs
-  }
-  __syncthreads();                                         // s_cnt = 0 visible; overlaps the load latency
-
-  // element e of load u  <->  tile element kPer*(u*256+tid)+e
-  auto raw_at = [&](int u, int e) -> float {
-    if constexpr (std::is_same_v<T, F32>) {
-      return __uint_as_float(v[u][e]);
-    } else {
-      const uint32_t w = v[u][e >> 1];
-      const uint32_t h = (e & 1) ? (w >> 16) : (w & 0xffffu);
-      return std::is_same_v<T, BF16> ? bf16_bits_to_float(h) : f16_bits_to_float(h);
-    }
-  };
-
-  // storage bits of an element (integer ops only: keeps the converted floats out of registers)
-  auto bits_at = [&](int u, int e) -> uint32_t {
-    if constexpr (std::is_same_v<T, F32>) return v[u][e];
-    else return (v[u][e >> 1] >> (16 * (e & 1))) & 0xffffu;
   };
   auto bits_to_raw = [](uint32_t bits) -> float {
     if constexpr (std::is_same_v<T, F32>) return __uint_as_float(bits);
@@ -205,44 +177,79 @@ __global__ __launch_bounds__(kScanThreads) void prefilter_scan_kernel(const Scan
     else return f16_bits_to_float(bits);
   };
 
-  // hit mask over the lane's 64 elements: bit (kPer*u + e); one compare each, NaN fails >=
-  uint64_t mask = 0;
-#pragma unroll
-  for (int u = 0; u < kVec; ++u) {
-    uint32_t m = 0;
-#pragma unroll
-    for (int e = 0; e < kPer; ++e) m |= (raw_at(u, e) >= raw_thr ? 1u : 0u) << e;
-    mask |= static_cast<uint64_t>(m) << (kPer * u);
-  }
-  const uint32_t cnt = __popcll(mask);
+  // position of the span inside the level: image index and offset within the image
+  const uint32_t b0 = static_cast<uint32_t>(span_base / n);
+  const uint32_t r0 = static_cast<uint32_t>(span_base - static_cast<uint64_t>(b0) * n);
+  const bool one_image = static_cast<uint64_t>(r0) + span_len <= n;
 
-  // position of the tile inside the level: image index and offset within the image
-  const uint32_t b0 = static_cast<uint32_t>(tile_base / n);
-  const uint32_t r0 = static_cast<uint32_t>(tile_base - static_cast<uint64_t>(b0) * n);
-  const bool one_image = static_cast<uint64_t>(r0) + tile_len <= n;
+  // ---- phase A, once per tile of the span: loads, hit mask, stage (raw bits, span offset) in LDS ----
+#pragma unroll 1
+  for (uint32_t t = 0; t < kSpanTiles; ++t) {
+    const uint32_t vec0 = t * (kTile / kPer);              // first 16-byte group of this tile
+    if (vec0 >= span_vec && t > 0) break;
+    const vuint4 *src = reinterpret_cast<const vuint4 *>(span_ptr) + vec0;
+    const uint32_t n_vec = span_vec - vec0 < kTile / kPer ? span_vec - vec0 : kTile / kPer;
 
-  uint32_t off = 0;
-  if (cnt) off = atomicAdd(&s_cnt, cnt);                   // block-local slots (order is irrelevant)
-  if (cnt && off + cnt <= kStageCap) {
-    uint32_t o = off;
+    // issue all loads first (kVec x 16 B per lane, lane-contiguous => fully coalesced)
+    vuint4 v[kVec];
 #pragma unroll
     for (int u = 0; u < kVec; ++u) {
-      const uint32_t m = static_cast<uint32_t>(mask >> (kPer * u)) & ((1u << kPer) - 1u);
-      if (m) {
+      const uint32_t q = u * kScanThreads + tid;
+      if (q < n_vec) v[u] = __builtin_nontemporal_load(src + q);     // streamed once: keep it out of L2's way
+      else v[u] = std::is_same_v<T, F32> ? vuint4{0x7fc00000u, 0x7fc00000u, 0x7fc00000u, 0x7fc00000u}
+                                         : vuint4{0x7fc07fc0u, 0x7fc07fc0u, 0x7fc07fc0u, 0x7fc07fc0u};   // NaNs
+    }
+    if (t == 0) __syncthreads();                           // s_cnt = 0 visible; overlaps the load latency
+
+    // element e of load u  <->  tile element kPer*(u*256+tid)+e
+    auto raw_at = [&](int u, int e) -> float {
+      if constexpr (std::is_same_v<T, F32>) {
+        return __uint_as_float(v[u][e]);
+      } else {
+        const uint32_t w = v[u][e >> 1];
+        const uint32_t h = (e & 1) ? (w >> 16) : (w & 0xffffu);
+        return std::is_same_v<T, BF16> ? bf16_bits_to_float(h) : f16_bits_to_float(h);
+      }
+    };
+    // storage bits of an element (integer ops only: keeps the converted floats out of registers)
+    auto bits_at = [&](int u, int e) -> uint32_t {
+      if constexpr (std::is_same_v<T, F32>) return v[u][e];
+      else return (v[u][e >> 1] >> (16 * (e & 1))) & 0xffffu;
+    };
+
+    // hit mask over the lane's 64 elements: bit (kPer*u + e); one compare each, NaN fails >=
+    uint64_t mask = 0;
 #pragma unroll
-        for (int e = 0; e < kPer; ++e)
-          if (m & (1u << e))
-            s_stage[o++] = (static_cast<uint64_t>(bits_at(u, e)) << 32) |
-                           static_cast<uint32_t>(kPer * (u * kScanThreads + tid) + e);
+    for (int u = 0; u < kVec; ++u) {
+      uint32_t m = 0;
+#pragma unroll
+      for (int e = 0; e < kPer; ++e) m |= (raw_at(u, e) >= raw_thr ? 1u : 0u) << e;
+      mask |= static_cast<uint64_t>(m) << (kPer * u);
+    }
+    const uint32_t cnt = __popcll(mask);
+    if (cnt) {
+      uint32_t o = atomicAdd(&s_cnt, cnt);                 // block-local slots (order is irrelevant)
+      if (o + cnt <= kStageCap) {
+        const uint32_t elem0 = vec0 * kPer + kPer * tid;   // span offset of this lane's first element
+#pragma unroll
+        for (int u = 0; u < kVec; ++u) {
+          const uint32_t m = static_cast<uint32_t>(mask >> (kPer * u)) & ((1u << kPer) - 1u);
+          if (m) {
+#pragma unroll
+            for (int e = 0; e < kPer; ++e)
+              if (m & (1u << e))
+                s_stage[o++] = (static_cast<uint64_t>(bits_at(u, e)) << 32) |
+                               static_cast<uint32_t>(elem0 + kPer * u * kScanThreads + e);
+          }
+        }
       }
     }
   }
   __syncthreads();
   const uint32_t raw_tot = s_cnt;
 
-  // ---- phase B + copy-out over `cnt_staged` staged (raw bits, tile offset) entries ----
-  // last_round: waves 1..3 may retire before the copy-out (no barrier follows).
-  auto drain = [&](uint32_t cnt_staged, bool last_round) {
+  // ---- phase B + copy-out over `cnt_staged` staged (raw bits, span offset) entries ----
+  auto drain = [&](uint32_t cnt_staged) {
     uint32_t ok_here = 0;
     for (uint32_t i = tid; i < cnt_staged; i += kScanThreads) {        // exact test, one call site
       const uint64_t ent = s_stage[i];
@@ -253,7 +260,7 @@ __global__ __launch_bounds__(kScanThreads) void prefilter_scan_kernel(const Scan
         if (one_image) {
           key = make_key(s, canonical_index(rr, L));
           ++ok_here;
-        } else {                                                        // boundary tile: own atomics
+        } else {                                                        // boundary span: own atomics
           const uint32_t b = b0 + rr / n;
           const uint32_t slot = atomicAdd(counter_of(b), 1u);
           if (slot < L.cap) list_of(b)[slot] = make_key(s, canonical_index(rr % n, L));
@@ -273,9 +280,9 @@ __global__ __launch_bounds__(kScanThreads) void prefilter_scan_kernel(const Scan
     __syncthreads();
     if (!one_image) return;
     const uint32_t ok_tot = s_ok;
-#if ODTK_ABLATE == 1
-    return;
-#endif
+    // ONE wave reserves the global slots (one returning atomic per span) and writes the keys out
+    // coalesced; in the common single-round case waves 1..3 have nothing left to do and retire, so
+    // the ~1 us round trip of the atomic under streaming load never idles the whole workgroup
     if (tid < kWave && ok_tot) {
       uint32_t base = 0;
       if (tid == 0) base = atomicAdd(counter_of(b0), ok_tot);
@@ -290,43 +297,39 @@ __global__ __launch_bounds__(kScanThreads) void prefilter_scan_kernel(const Scan
         run += __popcll(m);
       }
     }
-    (void)last_round;
   };
 
-#if ODTK_ABLATE == 2
-  return;
-#endif
   if (raw_tot != 0 && raw_tot <= kStageCap) {
-    drain(raw_tot, true);
+    drain(raw_tot);
   } else if (raw_tot > kStageCap) {
-    // saturated tile: re-walk it in rounds of kStageCap elements (4 per lane), rolled
-    for (uint32_t c0 = 0; c0 < tile_len; c0 += kStageCap) {
+    // saturated span: re-walk it in rounds of kStageCap elements (4 per lane), rolled
+    for (uint32_t c0 = 0; c0 < span_vec * kPer; c0 += kStageCap) {
       __syncthreads();
       if (tid == 0) { s_cnt = 0; s_ok = 0; }
       __syncthreads();
 #pragma unroll 1
       for (int k = 0; k < kStageCap / kScanThreads; ++k) {
-        const uint32_t t = c0 + k * kScanThreads + tid;
-        if (t < n_vec * kPer) {
-          const float raw = load_raw<T>(tile_ptr, t);
+        const uint32_t e = c0 + k * kScanThreads + tid;
+        if (e < span_vec * kPer) {
+          const float raw = load_raw<T>(span_ptr, e);
           if (raw >= raw_thr) {
             uint32_t bits;
             if constexpr (std::is_same_v<T, F32>) bits = __float_as_uint(raw);
-            else bits = static_cast<const uint16_t *>(static_cast<const void *>(tile_ptr))[t];
-            s_stage[atomicAdd(&s_cnt, 1u)] = (static_cast<uint64_t>(bits) << 32) | t;
+            else bits = static_cast<const uint16_t *>(static_cast<const void *>(span_ptr))[e];
+            s_stage[atomicAdd(&s_cnt, 1u)] = (static_cast<uint64_t>(bits) << 32) | e;
           }
         }
       }
       __syncthreads();
-      drain(s_cnt, false);
+      drain(s_cnt);
     }
   }
 
-  // ---- scalar tail of the level (total % kPer elements, last tile only) ----
-  const uint32_t tail = tile_len - n_vec * kPer;
+  // ---- scalar tail of the level (total % kPer elements, last span only) ----
+  const uint32_t tail = span_len - span_vec * kPer;
   if (tail && static_cast<uint32_t>(tid) < tail) {
-    const uint32_t toff = n_vec * kPer + tid;
-    const float s = score_of<T, kLogits>(load_raw<T>(tile_ptr, toff));
+    const uint32_t toff = span_vec * kPer + tid;
+    const float s = score_of<T, kLogits>(load_raw<T>(span_ptr, toff));
     if (s >= thr) {
       const uint64_t r = static_cast<uint64_t>(r0) + toff;
       const uint32_t b = b0 + static_cast<uint32_t>(r / n);

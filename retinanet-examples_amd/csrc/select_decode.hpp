@@ -52,6 +52,7 @@ struct DecodeArgs {
   int32_t *out_indices;  // optional
   int n_levels, batch, num_anchors, num_classes, top_n;
   float thresh;
+  unsigned long long *trace;   // debug (odtk_debug_set_trace): 8 timestamps per workgroup, or null
 };
 
 // ---- key sources -------------------------------------------------------------------------
@@ -81,10 +82,15 @@ struct ListSource {   // the kSubLists compacted candidate sub-lists written by 
         if (i >= start[q]) { s = q; base = start[q]; }
       return keys + static_cast<uint64_t>(s) * cap + (i - base);
     };
-    // 4 independent loads in flight per lane: the lists live in L2, a dependent one-load-per-trip
-    // loop would pay the full latency 20+ times per pass
-    constexpr int kBatch = 4;
+    // The lists live in L2 and ONE workgroup walks them: its only source of memory-level parallelism
+    // is independent loads per lane.  16 in flight per lane (128 KiB per workgroup), then 4, then 1.
     uint32_t i = threadIdx.x;
+    i = batched<16>(i, total, address, f);
+    i = batched<4>(i, total, address, f);
+    for (; i < total; i += kSelThreads) f(*address(i));
+  }
+  template <int kBatch, typename A, typename F>
+  static __device__ __forceinline__ uint32_t batched(uint32_t i, uint32_t total, A &&address, F &&f) {
     for (; i + (kBatch - 1) * kSelThreads < total; i += kBatch * kSelThreads) {
       uint64_t k[kBatch];
 #pragma unroll
@@ -92,7 +98,15 @@ struct ListSource {   // the kSubLists compacted candidate sub-lists written by 
 #pragma unroll
       for (int u = 0; u < kBatch; ++u) f(k[u]);
     }
-    for (; i < total; i += kSelThreads) f(*address(i));
+    return i;
+  }
+};
+struct LdsSource {    // keys already gathered into LDS
+  const uint64_t *keys;
+  uint32_t count;
+  template <typename F>
+  __device__ __forceinline__ void for_each(F &&f) const {
+    for (uint32_t i = threadIdx.x; i < count; i += kSelThreads) f(keys[i]);
   }
 };
 template <typename T, bool kLogits>
@@ -114,20 +128,93 @@ struct RawSource {    // the segment's raw head values (overflow path); walks me
 };
 
 // ---- block-wide helpers --------------------------------------------------------------------
-// Bitonic sort, descending, of s_keys[0..n) (n a power of two <= kSortCap), 1024 threads.
-__device__ __forceinline__ void bitonic_sort_desc(uint64_t *s_keys, uint32_t n) {
-  for (uint32_t k = 2; k <= n; k <<= 1) {
-    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-      for (uint32_t t = threadIdx.x; t < (n >> 1); t += kSelThreads) {
-        const uint32_t lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));   // element with bit j clear
+__device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int lane_mask) {
+  const uint32_t lo = __shfl_xor(static_cast<uint32_t>(v), lane_mask, kWave);
+  const uint32_t hi = __shfl_xor(static_cast<uint32_t>(v >> 32), lane_mask, kWave);
+  return (static_cast<uint64_t>(hi) << 32) | lo;
+}
+
+// Bitonic sort, descending, of s_keys[0 .. 1024*E), 1024 threads, E keys per thread (element
+// i = tid*E + e).  A compare-exchange with partner distance j needs
+//   j <  E      : nothing but the thread's own registers,
+//   j <  64*E   : one wave shuffle (partner lane = lane ^ j/E),
+//   j >= 64*E   : another wave -> LDS + barrier.
+// Of the 55 / 66 / 78 stages of a 1024 / 2048 / 4096-key network only 10 are of the last kind, so
+// the keys live in registers and go through LDS only for those: ~20 barriers instead of 55-78
+// (measured on MI355X: a 1024-key sort 13.6 us -> see DESIGN.md; every stage of the plain LDS
+// version costs a full barrier round, ~0.25 us).
+template <int E>
+__device__ void bitonic_sort_desc_regs(uint64_t *s_keys) {
+  constexpr uint32_t n = kSelThreads * E;
+  const uint32_t tid = threadIdx.x;
+  uint64_t v[E];
+  auto load = [&] {
+#pragma unroll
+    for (int e = 0; e < E; ++e) v[e] = s_keys[tid * E + e];
+  };
+  auto store = [&] {
+#pragma unroll
+    for (int e = 0; e < E; ++e) s_keys[tid * E + e] = v[e];
+  };
+  // all stages j = j_start .. 1 of phase k, for j_start < 64*E: registers + wave shuffles only
+  auto reg_stages = [&](uint32_t k, uint32_t j_start) {
+    for (uint32_t j = j_start; j >= static_cast<uint32_t>(E); j >>= 1) {   // partner in another lane
+      const int lane_mask = static_cast<int>(j / E);
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const uint64_t p = shfl_xor_u64(v[e], lane_mask);
+        const uint32_t i = tid * E + e;
+        const bool take_max = ((i & j) == 0) == ((i & k) == 0);   // lower element of a descending pair
+        v[e] = take_max ? (v[e] > p ? v[e] : p) : (v[e] < p ? v[e] : p);
+      }
+      if (j == 1) return;                                         // E == 1: j ran down to 1 here
+    }
+#pragma unroll
+    for (int j = E / 2; j > 0; j >>= 1) {                        // partner in the same thread
+      if (static_cast<uint32_t>(j) > j_start) continue;
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        if ((e & j) == 0) {
+          const uint32_t i = tid * E + e;
+          const bool desc = (i & k) == 0;
+          const uint64_t x = v[e], y = v[e | j];
+          if (desc ? (x < y) : (x > y)) { v[e] = y; v[e | j] = x; }
+        }
+      }
+    }
+  };
+  load();
+  for (uint32_t k = 2; k <= 64u * E; k <<= 1) reg_stages(k, k >> 1);           // no LDS, no barrier
+  for (uint32_t k = 128u * E; k <= n; k <<= 1) {
+    store();
+    __syncthreads();
+    for (uint32_t j = k >> 1; j >= 64u * E; j >>= 1) {                          // cross-wave stages
+      for (uint32_t t = tid; t < (n >> 1); t += kSelThreads) {
+        const uint32_t lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
         const uint32_t hi = lo | j;
         const uint64_t x = s_keys[lo], y = s_keys[hi];
-        const bool desc = (lo & k) == 0;                               // direction of this run
+        const bool desc = (lo & k) == 0;
         if (desc ? (x < y) : (x > y)) { s_keys[lo] = y; s_keys[hi] = x; }
       }
       __syncthreads();
     }
+    load();
+    reg_stages(k, 32u * E);
   }
+  store();
+  __syncthreads();
+}
+
+// Sorts s_keys[0..n_valid) descending; entries up to the padded size are zeroed (sort last).
+// The buffer must hold max(1024, pow2(n_valid)) <= kSortCap keys.
+__device__ __forceinline__ void sort_keys_desc(uint64_t *s_keys, uint32_t n_valid) {
+  uint32_t n_pad = kSelThreads;
+  while (n_pad < n_valid) n_pad <<= 1;
+  for (uint32_t i = n_valid + threadIdx.x; i < n_pad; i += kSelThreads) s_keys[i] = 0;
+  __syncthreads();
+  if (n_pad == kSelThreads) bitonic_sort_desc_regs<1>(s_keys);
+  else if (n_pad == 2 * kSelThreads) bitonic_sort_desc_regs<2>(s_keys);
+  else bitonic_sort_desc_regs<4>(s_keys);
 }
 
 // MSD radix descent (11-bit digits, LDS histogram) on the bin that holds the `want`-th largest key.
@@ -209,6 +296,8 @@ __global__ __launch_bounds__(kSelThreads) void select_decode_kernel(const Decode
   const uint32_t channels = static_cast<uint32_t>(A) * C;
   const typename T::storage *cls_image = static_cast<const typename T::storage *>(L.cls) + static_cast<uint64_t>(b) * L.n;
 
+  auto stamp = [&](int k) { if (a.trace && threadIdx.x == 0) a.trace[blockIdx.x * 8 + k] = wall_clock64(); };
+  stamp(0);
   const ListSource lists(a.cand + L.cand_off + static_cast<uint64_t>(b) * kSubLists * L.cap, sub_counts, L.cap);
   uint32_t n_sort;   // number of valid keys placed in s_keys
 
@@ -232,11 +321,36 @@ __global__ __launch_bounds__(kSelThreads) void select_decode_kernel(const Decode
     if (complete) lists.for_each(take);
     else raw.for_each(take);
   }
-  uint32_t n_pow2 = 1;
-  while (n_pow2 < n_sort) n_pow2 <<= 1;
-  for (uint32_t i = n_sort + threadIdx.x; i < n_pow2; i += kSelThreads) s_keys[i] = 0;   // pad: sorts last
+  stamp(1);
   __syncthreads();
-  if (n_pow2 > 1) bitonic_sort_desc(s_keys, n_pow2);
+  // Second stage, in LDS.  Sorting is the expensive part (measured: 1024 keys 7 us, 4096 keys 24 us)
+  // while a radix pass over keys that are already LDS-resident costs ~3 us, so narrow the buffer down
+  // to the smallest sortable size that still holds top_n (1024 for the default 1000) first.
+  uint32_t sort_size = kSelThreads;
+  while (sort_size < top_n) sort_size <<= 1;
+  if (n_sort > sort_size) {
+    uint32_t n_keep = n_sort;
+    const LdsSource in_lds{s_keys, n_sort};
+    const uint64_t T2 = radix_threshold(in_lds, top_n, sort_size, s_hist, s_misc, &n_keep);
+    // in-place compaction: every lane reads its keys (<= 4), barrier, survivors go to the front
+    uint64_t mine[kSortCap / kSelThreads];
+#pragma unroll
+    for (int u = 0; u < kSortCap / kSelThreads; ++u) {
+      const uint32_t i = u * kSelThreads + threadIdx.x;
+      mine[u] = i < n_sort ? s_keys[i] : 0;
+    }
+    if (threadIdx.x == 0) s_misc[20] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < kSortCap / kSelThreads; ++u)
+      if (mine[u] != 0 && mine[u] >= T2) s_keys[atomicAdd(&s_misc[20], 1u)] = mine[u];
+    n_sort = n_keep;
+    __syncthreads();
+  }
+  stamp(2);
+  if (a.trace && threadIdx.x == 0) { a.trace[blockIdx.x * 8 + 5] = count; a.trace[blockIdx.x * 8 + 6] = n_sort; a.trace[blockIdx.x * 8 + 7] = complete; }
+  sort_keys_desc(s_keys, n_sort);   // the first k_out are the answer
+  stamp(3);
 
   // ---- decode + write this segment's slice of the concatenated outputs ----
   const float stride = L.stride;
@@ -294,6 +408,7 @@ __global__ __launch_bounds__(kSelThreads) void select_decode_kernel(const Decode
     for (int k = 0; k < NB; ++k) a.out_boxes[(out_row + t) * NB + k] = bx[k];
     if (a.out_indices) a.out_indices[out_row + t] = index;
   }
+  stamp(4);
 }
 
 }  // namespace odtk

@@ -61,6 +61,7 @@ _SIGNATURES = {
                                    ctypes.c_int, _vpp, _vp, _sz, _vp]),
     'odtk_bias_act': (ctypes.c_int, [_vp, _vp, _vp, _sz, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp]),
     'odtk_profile_enable': (ctypes.c_int, [ctypes.c_int]),
+    'odtk_debug_set_trace': (ctypes.c_int, [_vp]),
     'odtk_profile_collect': (ctypes.c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]),
 }
 

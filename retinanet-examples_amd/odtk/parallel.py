@@ -27,8 +27,16 @@ def init_from_env(backend):
     return rank, local_rank, world
 
 
-def barrier():
-    if dist.is_available() and dist.is_initialized():
+def barrier(device=None):
+    """Rendezvous of all ranks.  With a device-side backend (RCCL) this is an explicit 1-element
+    all_reduce on `device` (never relies on a 'current device' guess) followed by a device sync."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return
+    if device is not None and torch.device(device).type == 'cuda':
+        t = torch.zeros(1, device=device)
+        dist.all_reduce(t)
+        torch.cuda.synchronize(device)
+    else:
         dist.barrier()
 
 
@@ -36,14 +44,14 @@ def timed_steps(step, steps, device_sync=None, device=None):
     """Run `step()` exactly `steps` times between barrier + device-sync brackets and return the
     MAX over ranks of the elapsed seconds (every rank gets the same number)."""
     sync = device_sync or (lambda: None)
-    barrier()
+    barrier(device)
     sync()
     t0 = time.perf_counter()
     out = None
     for _ in range(steps):
         out = step()
     sync()
-    barrier()
+    barrier(device)
     elapsed = time.perf_counter() - t0
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device or 'cpu')

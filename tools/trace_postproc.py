@@ -1,0 +1,43 @@
+#!/usr/bin/env python
+"""Phase timing INSIDE select_decode / nms (debug trace, odtk_debug_set_trace) on the head tensors
+of the calibrated bench model (real conv outputs: spatially correlated scores, bf16 ties)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, 'retinanet-examples_amd')]
+import torch
+torch.backends.cudnn.benchmark = True
+from odtk import _C, box
+from odtk.model import Model
+from odtk.fused import FusedRetinaNet
+sys.path.insert(0, ROOT)
+import bench
+
+torch.manual_seed(0)
+m = Model('ResNet50FPN'); m.initialize(None)
+m = m.cuda().to(memory_format=torch.channels_last).eval()
+x = torch.randn(8, 3, 800, 1280, generator=torch.Generator().manual_seed(0)).cuda().contiguous(memory_format=torch.channels_last)
+bench.calibrate_cls_head(m, x, 0.573, torch.bfloat16)
+eng = FusedRetinaNet(m).cuda()
+with torch.no_grad():
+    cls, dl = eng.heads(x)
+strides = [8, 16, 32, 64, 128]
+for s in strides: m.level_anchors(s)
+run = lambda: box.detect(cls, dl, strides, m.anchors, 0.05, 1000, 0.5, 100, logits=True)
+for _ in range(3): run()
+trace = torch.zeros(4096, dtype=torch.int64, device='cuda')
+_C.library().odtk_debug_set_trace(trace.data_ptr())
+run(); torch.cuda.synchronize()
+_C.library().odtk_debug_set_trace(None)
+t = trace.cpu().view(-1, 8)
+us = lambda a, b: (b - a).float() / 100.0
+print('select_decode phases (us): read+select | lds narrow | sort | decode   [per level, mean over 8 images]')
+for l in range(5):
+    blk = t[l * 8:(l + 1) * 8]
+    print('  P%d: %6.1f %6.1f %6.1f %6.1f   total %6.1f' % (l + 3, us(blk[:, 0], blk[:, 1]).mean(), us(blk[:, 1], blk[:, 2]).mean(),
+          us(blk[:, 2], blk[:, 3]).mean(), us(blk[:, 3], blk[:, 4]).mean(), us(blk[:, 0], blk[:, 4]).mean()),
+          'counts', blk[:, 5].tolist(), 'n_sort', blk[:, 6].tolist(), 'read+select per image', [round(float(v), 1) for v in us(blk[:, 0], blk[:, 1])])
+n = t[64 + 8:64 + 16]
+print('nms phases (us): compact | select round 0 | sort | chunks   consumed/K')
+for b in range(8):
+    r = n[b]
+    print('  img%d: %6.1f %6.1f %6.1f %6.1f  total %6.1f   %d / %d' % (b, us(r[0], r[1]), us(r[1], r[2]), us(r[2], r[3]), us(r[3], r[4]), us(r[0], r[4]), r[5], r[6]))
