@@ -1,12 +1,18 @@
-"""RetinaNet (https://arxiv.org/abs/1708.02002) -- model surface of the reference (odtk/model.py)
-with the inference post-processing on the MI355X HIP path.
+"""RetinaNet (https://arxiv.org/abs/1708.02002) on MI355X.
 
-Backbone, FPN, the two 5-conv heads and the losses are stock PyTorch-ROCm modules (MIOpen owns the
-MFMA work).  `forward` in eval mode hands the ten head tensors to `odtk.box.detect`, which covers
-decode of all five levels + batched NMS in three kernel launches with no host synchronisation
-(reference model.py:140-165: python loop of 5 `decode` calls, `torch.cat`, `nms`).
+Public surface = the reference's `odtk.model.Model` (constructor arguments, `initialize`, `forward`
+in train / eval mode, `save` / `load` with the same checkpoint keys, reference odtk/model.py), so
+training scripts and checkpoints carry over.  What runs where:
 
-Checkpoint format (`save` / `load`) keeps the reference's keys (model.py:217-258).
+  backbone + FPN + the two 5-conv heads + losses   stock PyTorch-ROCm modules (MIOpen owns the MFMA work)
+  eval post-processing                              `odtk.box.detect`: sigmoid + decode of all five levels
+                                                    + batched NMS, hand-written HIP, 3 launches, no host
+                                                    sync, head tensors read in place (bf16/fp16/fp32,
+                                                    NCHW or channels_last)
+  `fused_postprocess = False`                       the reference's own op sequence (model.py:140-165)
+                                                    on the same kernels, for A/B checks
+  `fuse()`                                          BN-folded inference graph with the HIP bias/skip/ReLU
+                                                    epilogue (odtk/fused.py)
 """
 import math
 import os.path
@@ -19,49 +25,65 @@ from . import backbones as backbones_mod
 from . import box as box_ops
 from .loss import FocalLoss, SmoothL1Loss
 
+DEFAULT_RATIOS = [1.0, 2.0, 0.5]
+DEFAULT_SCALES = [4 * 2 ** (i / 3) for i in range(3)]
+DEFAULT_ANGLES = [-np.pi / 6, 0, np.pi / 6]
+CLASS_PRIOR = 0.01                       # initial foreground probability of every anchor
+
+
+def conv_tower(out_channels, width=256, depth=4):
+    """`depth` x (3x3 conv + ReLU) followed by the 3x3 output conv; shared by all pyramid levels.
+    nn.Sequential indices (0, 2, 4, 6, 8 are convs) are part of the checkpoint format."""
+    layers = []
+    for _ in range(depth):
+        layers.extend([nn.Conv2d(width, width, 3, padding=1), nn.ReLU()])
+    layers.append(nn.Conv2d(width, out_channels, 3, padding=1))
+    return nn.Sequential(*layers)
+
+
+def _init_tower(tower):
+    for layer in tower:
+        if isinstance(layer, nn.Conv2d):
+            nn.init.normal_(layer.weight, std=0.01)
+            nn.init.zeros_(layer.bias)
+
+
+def _init_prior(conv):
+    nn.init.normal_(conv.weight, std=0.01)
+    nn.init.constant_(conv.bias, -math.log((1 - CLASS_PRIOR) / CLASS_PRIOR))
+
 
 class Model(nn.Module):
-    def __init__(self, backbones='ResNet50FPN', classes=80, ratios=[1.0, 2.0, 0.5],
-                 scales=[4 * 2 ** (i / 3) for i in range(3)], angles=None, rotated_bbox=False,
-                 anchor_ious=[0.4, 0.5], config={}):
-        super().__init__()
-        if not isinstance(backbones, list):
-            backbones = [backbones]
-        self.backbones = nn.ModuleDict({b: getattr(backbones_mod, b)() for b in backbones})
-        self.name = 'RetinaNet'
-        self.unused_modules = []
-        for b in backbones:
-            self.unused_modules.extend(getattr(self.backbones, b).features.unused_modules)
-        self.exporting = False
-        self.fused_postprocess = True      # False: the reference's op sequence (sigmoid, decode x5, cat, nms)
-        self.rotated_bbox = rotated_bbox
-        self.anchor_ious = anchor_ious
+    CHECKPOINT_EXTRAS = ('iteration', 'optimizer', 'scheduler')
 
-        self.ratios = ratios
-        self.scales = scales
-        self.angles = angles if angles is not None else ([-np.pi / 6, 0, np.pi / 6] if rotated_bbox else None)
-        self.anchors = {}
+    def __init__(self, backbones='ResNet50FPN', classes=80, ratios=DEFAULT_RATIOS, scales=DEFAULT_SCALES,
+                 angles=None, rotated_bbox=False, anchor_ious=[0.4, 0.5], config={}):
+        super().__init__()
+        names = backbones if isinstance(backbones, list) else [backbones]
+        self.backbones = nn.ModuleDict({n: getattr(backbones_mod, n)() for n in names})
+        self.name = 'RetinaNet'
+        self.unused_modules = [u for n in names for u in self.backbones[n].features.unused_modules]
+        self.stride = max(b.stride for b in self.backbones.values())
+
         self.classes = classes
+        self.ratios, self.scales = ratios, scales
+        self.rotated_bbox = rotated_bbox
+        self.angles = angles if angles is not None else (DEFAULT_ANGLES if rotated_bbox else None)
+        self.anchor_ious = anchor_ious
+        self.anchors = {}                                   # stride -> base anchors, filled lazily
 
         # post-processing hyper-parameters are config entries, not CLI flags (reference model.py:49-52)
         self.threshold = config.get('threshold', 0.05)
         self.top_n = config.get('top_n', 1000)
         self.nms = config.get('nms', 0.5)
         self.detections = config.get('detections', 100)
-
-        self.stride = max(b.stride for b in self.backbones.values())
-
-        def head(out_channels):
-            layers = []
-            for _ in range(4):
-                layers += [nn.Conv2d(256, 256, 3, padding=1), nn.ReLU()]
-            layers.append(nn.Conv2d(256, out_channels, 3, padding=1))
-            return nn.Sequential(*layers)
+        self.exporting = False
+        self.fused_postprocess = True
 
         self.num_anchors = len(ratios) * len(scales) * (len(self.angles) if rotated_bbox else 1)
-        self.cls_head = head(classes * self.num_anchors)
-        self.box_head = head((6 if rotated_bbox else 4) * self.num_anchors)   # rotated: + sin, cos
-
+        box_params = 6 if rotated_bbox else 4               # rotated: (dx, dy, dw, dh, sin, cos)
+        self.cls_head = conv_tower(classes * self.num_anchors)
+        self.box_head = conv_tower(box_params * self.num_anchors)
         self.cls_criterion = FocalLoss()
         self.box_criterion = SmoothL1Loss(beta=0.11)
 
@@ -70,36 +92,63 @@ class Model(nn.Module):
                           '  backbone: {}'.format(', '.join(self.backbones.keys())),
                           '   classes: {}, anchors: {}'.format(self.classes, self.num_anchors)])
 
+    # ------------------------------------------------------------------ weights
     def initialize(self, pre_trained=None):
+        """Fresh initialisation, or fine-tuning from a checkpoint whose last classification (and, for
+        rotated boxes, regression) layer is re-initialised (reference model.py:80-123)."""
         if pre_trained:
             if not os.path.isfile(pre_trained):
                 raise ValueError('No checkpoint {}'.format(pre_trained))
             print('Fine-tuning weights from {}...'.format(os.path.basename(pre_trained)))
-            chk = torch.load(pre_trained, map_location='cpu')
-            skip = {'cls_head.8.bias', 'cls_head.8.weight'}
-            if self.rotated_bbox:
-                skip |= {'box_head.8.bias', 'box_head.8.weight'}
+            donor = torch.load(pre_trained, map_location='cpu')['state_dict']
+            dropped = ['cls_head.8.'] + (['box_head.8.'] if self.rotated_bbox else [])
             state = self.state_dict()
-            state.update({k: v for k, v in chk['state_dict'].items() if k not in skip})
+            state.update({k: v for k, v in donor.items() if not any(k.startswith(d) for d in dropped)})
             self.load_state_dict(state)
         else:
-            for b in self.backbones.values():
-                b.initialize()
-            for seq in (self.cls_head, self.box_head):
-                for m in seq:
-                    if isinstance(m, nn.Conv2d):
-                        nn.init.normal_(m.weight, std=0.01)
-                        nn.init.zeros_(m.bias)
-
-        # class prior pi = 0.01 on the last classification layer (reference model.py:114-123)
-        def prior(layer):
-            nn.init.constant_(layer.bias, -math.log((1 - 0.01) / 0.01))
-            nn.init.normal_(layer.weight, std=0.01)
-
-        prior(self.cls_head[-1])
+            for backbone in self.backbones.values():
+                backbone.initialize()
+            _init_tower(self.cls_head)
+            _init_tower(self.box_head)
+        _init_prior(self.cls_head[-1])
         if self.rotated_bbox:
-            prior(self.box_head[-1])
+            _init_prior(self.box_head[-1])
 
+    def freeze_unused_params(self):
+        for name, param in self.named_parameters():
+            if any(u in name for u in self.unused_modules):
+                param.requires_grad = False
+
+    def save(self, state):
+        checkpoint = {'backbone': list(self.backbones.keys()), 'classes': self.classes, 'ratios': self.ratios,
+                      'scales': self.scales, 'state_dict': self.state_dict()}
+        if self.rotated_bbox and self.angles:
+            checkpoint['angles'] = self.angles
+        checkpoint.update({k: state[k] for k in self.CHECKPOINT_EXTRAS if k in state})
+        torch.save(checkpoint, state['path'])
+
+    @classmethod
+    def load(cls, filename, rotated_bbox=False):
+        if not os.path.isfile(filename):
+            raise ValueError('No checkpoint {}'.format(filename))
+        checkpoint = torch.load(filename, map_location='cpu')
+        kwargs = {k: checkpoint[k] for k in ('ratios', 'scales', 'angles') if k in checkpoint}
+        if rotated_bbox or 'angles' in checkpoint:
+            kwargs['rotated_bbox'] = True
+        model = cls(backbones=checkpoint['backbone'], classes=checkpoint['classes'], **kwargs)
+        model.load_state_dict(checkpoint['state_dict'])
+        return model, {k: checkpoint[k] for k in cls.CHECKPOINT_EXTRAS if k in checkpoint}
+
+    def export(self, *args, **kwargs):
+        raise NotImplementedError('TensorRT export is not available on MI355X (the DALI / TensorRT / DeepStream '
+                                  'paths are dropped, BASELINE.json north_star)')
+
+    def fuse(self, dtype=torch.bfloat16):
+        """Inference engine with BN folded into the convolutions and the HIP epilogue (odtk/fused.py)."""
+        from .fused import FusedRetinaNet
+        return FusedRetinaNet(self, dtype)
+
+    # ------------------------------------------------------------------ forward
     def level_anchors(self, stride):
         if stride not in self.anchors:
             if self.rotated_bbox:
@@ -109,90 +158,60 @@ class Model(nn.Module):
         return self.anchors[stride]
 
     def heads(self, x):
-        feats = []
-        for b in self.backbones.values():
-            feats.extend(b(x))
-        return [self.cls_head(t) for t in feats], [self.box_head(t) for t in feats]
+        """Raw head tensors of every pyramid level: (cls logits x5, box deltas x5)."""
+        pyramid = [feature for backbone in self.backbones.values() for feature in backbone(x)]
+        return [self.cls_head(f) for f in pyramid], [self.box_head(f) for f in pyramid]
 
     def forward(self, x, rotated_bbox=None):
         if self.training:
-            x, targets = x
-        cls_heads, box_heads = self.heads(x)
-        if self.training:
-            return self._compute_loss(x, cls_heads, box_heads, targets.float())
+            images, targets = x
+            cls_heads, box_heads = self.heads(images)
+            return self._compute_loss(images, cls_heads, box_heads, targets.float())
 
+        cls_heads, box_heads = self.heads(x)
         strides = [x.shape[-1] // c.shape[-1] for c in cls_heads]
         if self.exporting:
             self.strides = strides
             return [c.sigmoid() for c in cls_heads], box_heads
-        for s in strides:
-            self.level_anchors(s)
+        for stride in strides:
+            self.level_anchors(stride)
+        return self.postprocess(cls_heads, box_heads, strides)
 
+    def postprocess(self, cls_heads, box_heads, strides):
+        """Raw head tensors -> (scores [B, D], boxes [B, D, 4|6], classes [B, D])."""
         if self.fused_postprocess:
-            # sigmoid + decode x5 + nms on the raw head tensors (bf16/fp16/fp32, NCHW or
-            # channels_last) in three launches: no sigmoid pass, no .contiguous(), no .float()
+            # sigmoid + decode x5 + nms on the head tensors as the convolutions wrote them
             return box_ops.detect(cls_heads, box_heads, strides, self.anchors, self.threshold, self.top_n,
                                   self.nms, self.detections, self.rotated_bbox, logits=True)
-
         # the reference's sequence, call for call (model.py:140, :153-165)
-        cls_heads = [c.sigmoid() for c in cls_heads]
-        nms_fn = box_ops.nms_rotated if self.rotated_bbox else box_ops.nms
-        decoded = [box_ops.decode(c.contiguous(), b.contiguous(), s, self.threshold, self.top_n, self.anchors[s],
-                                  self.rotated_bbox) for c, b, s in zip(cls_heads, box_heads, strides)]
-        decoded = [torch.cat(t, 1) for t in zip(*decoded)]
-        return nms_fn(*decoded, self.nms, self.detections)
+        suppress = box_ops.nms_rotated if self.rotated_bbox else box_ops.nms
+        per_level = [box_ops.decode(c.sigmoid().contiguous(), b.contiguous(), s, self.threshold, self.top_n,
+                                    self.anchors[s], self.rotated_bbox)
+                     for c, b, s in zip(cls_heads, box_heads, strides)]
+        return suppress(*[torch.cat(parts, 1) for parts in zip(*per_level)], self.nms, self.detections)
 
+    # ------------------------------------------------------------------ training loss
     def _extract_targets(self, targets, stride, size):
-        snap = box_ops.snap_to_anchors_rotated if self.rotated_bbox else box_ops.snap_to_anchors
+        """Per-image target assignment of one level, stacked over the batch (reference model.py:167-184)."""
+        assign = box_ops.snap_to_anchors_rotated if self.rotated_bbox else box_ops.snap_to_anchors
         anchors = self.level_anchors(stride)
         if not self.rotated_bbox:
             anchors = anchors.to(targets.device)
-        per_image = [snap(t[t[:, -1] > -1], [s * stride for s in size[::-1]], stride, anchors, self.classes,
-                          targets.device, self.anchor_ious) for t in targets]
-        return tuple(torch.stack(t) for t in zip(*per_image))
+        pixels = [extent * stride for extent in size[::-1]]             # [W, H] of the padded image
+        per_image = [assign(t[t[:, -1] > -1], pixels, stride, anchors, self.classes, targets.device, self.anchor_ious)
+                     for t in targets]
+        return tuple(torch.stack(parts) for parts in zip(*per_image))
 
     def _compute_loss(self, x, cls_heads, box_heads, targets):
-        cls_sum, box_sum, n_fg = [], [], []
+        """Focal + smooth-L1 losses summed over levels and normalised by the number of foreground
+        anchors (reference model.py:186-210); `depth` is -1 ignore / 0 background / class+1."""
+        cls_total, box_total, foreground = 0.0, 0.0, 0.0
         for cls_head, box_head in zip(cls_heads, box_heads):
-            size = cls_head.shape[-2:]
             stride = x.shape[-1] / cls_head.shape[-1]
-            cls_target, box_target, depth = self._extract_targets(targets, stride, size)
-            n_fg.append((depth > 0).sum().float().clamp(min=1))
+            cls_target, box_target, depth = self._extract_targets(targets, stride, cls_head.shape[-2:])
+            foreground = foreground + (depth > 0).sum().float().clamp(min=1)
             cls_loss = self.cls_criterion(cls_head.view_as(cls_target).float(), cls_target)
-            cls_sum.append(((depth >= 0).expand_as(cls_target).float() * cls_loss).sum())
+            cls_total = cls_total + (cls_loss * (depth >= 0).expand_as(cls_target).float()).sum()
             box_loss = self.box_criterion(box_head.view_as(box_target).float(), box_target)
-            box_sum.append(((depth > 0).expand_as(box_target).float() * box_loss).sum())
-        n_fg = torch.stack(n_fg).sum()
-        return torch.stack(cls_sum).sum() / n_fg, torch.stack(box_sum).sum() / n_fg
-
-    def freeze_unused_params(self):
-        for n, p in self.named_parameters():
-            if any(u in n for u in self.unused_modules):
-                p.requires_grad = False
-
-    def save(self, state):
-        checkpoint = {'backbone': list(self.backbones.keys()), 'classes': self.classes,
-                      'state_dict': self.state_dict(), 'ratios': self.ratios, 'scales': self.scales}
-        if self.rotated_bbox and self.angles:
-            checkpoint['angles'] = self.angles
-        for key in ('iteration', 'optimizer', 'scheduler'):
-            if key in state:
-                checkpoint[key] = state[key]
-        torch.save(checkpoint, state['path'])
-
-    @classmethod
-    def load(cls, filename, rotated_bbox=False):
-        if not os.path.isfile(filename):
-            raise ValueError('No checkpoint {}'.format(filename))
-        checkpoint = torch.load(filename, map_location='cpu')
-        kwargs = {k: checkpoint[k] for k in ('ratios', 'scales', 'angles') if k in checkpoint}
-        if 'angles' in checkpoint or rotated_bbox:
-            kwargs['rotated_bbox'] = True
-        model = cls(backbones=checkpoint['backbone'], classes=checkpoint['classes'], **kwargs)
-        model.load_state_dict(checkpoint['state_dict'])
-        state = {k: checkpoint[k] for k in ('iteration', 'optimizer', 'scheduler') if k in checkpoint}
-        return model, state
-
-    def export(self, *args, **kwargs):
-        raise NotImplementedError('TensorRT export is not available on MI355X (DALI/TensorRT/DeepStream paths are '
-                                  'dropped, BASELINE.json north_star)')
+            box_total = box_total + (box_loss * (depth > 0).expand_as(box_target).float()).sum()
+        return cls_total / foreground, box_total / foreground
