@@ -90,6 +90,8 @@ def main():
     ap.add_argument('--cpu-seconds', type=float, default=20.0, help='budget of the cpu_baseline leg (0 = skip)')
     ap.add_argument('--no-miopen-find', action='store_true',
                     help='torch.backends.cudnn.benchmark = False (MIOpen immediate mode instead of find mode)')
+    ap.add_argument('--rotated-bbox', action='store_true', help='BASELINE config 5: 27 anchors, 6 box parameters, '
+                                                                'rotated decode + polygon-IoU NMS')
     ap.add_argument('--no-fuse', action='store_true',
                     help='run the eager nn.Module graph under autocast instead of the BN-folded graph with the HIP '
                          'bias/skip/ReLU epilogue (odtk/fused.py)')
@@ -112,7 +114,7 @@ def main():
 
     amp_dtype = {'bf16': torch.bfloat16, 'fp16': torch.float16, 'fp32': None}[args.dtype]
     torch.manual_seed(0)
-    model = Model(backbones=args.backbone, classes=80)
+    model = Model(backbones=args.backbone, classes=80, rotated_bbox=args.rotated_bbox)
     model.initialize(None)
     model = model.to(dev).to(memory_format=torch.channels_last).eval()
     model.fused_postprocess = args.postproc == 'fused'
@@ -234,8 +236,9 @@ def main():
             'data': 'synthetic randn images, random-init weights; last cls conv rescaled so logits ~ '
                     'N(-ln99, %.3f^2) (measured sigma before: %.4f); %d detections in the last batch'
                     % (args.sigma, sigma0, n_det),
-            'config': {'workload': '%s %s inference, bs=%d per GPU at %dx%d, HIP decode x5 + NMS'
-                                   % (args.backbone, args.dtype, args.batch, args.height, args.width),
+            'config': {'workload': '%s %s inference%s, bs=%d per GPU at %dx%d, HIP decode x5 + NMS'
+                                   % (args.backbone, args.dtype, ' --rotated-bbox' if args.rotated_bbox else '',
+                                      args.batch, args.height, args.width),
                        'global_batch': args.batch * world, 'image': [args.height, args.width],
                        'parallelism': 'replicas x%d (no data-path collective)' % world,
                        'memory_format': 'channels_last', 'miopen_find': miopen_find, 'postproc': args.postproc,

@@ -14,6 +14,8 @@ __global__ __launch_bounds__(256) void iou_pairs_kernel(const float *__restrict_
                                                         const float *__restrict__ anchors,
                                                         float *__restrict__ out, int num_boxes,
                                                         int num_anchors) {
+  __shared__ float2 s_clip[4 * kClipSlotsPerWave];          // lane-private polygon columns (rotated_iou.hpp)
+  float2 *clip = s_clip + (threadIdx.x >> 6) * kClipSlotsPerWave + (threadIdx.x & 63);
   const long long pairs = 1ll * num_boxes * num_anchors;
   const long long step = 1ll * gridDim.x * blockDim.x;
   for (long long t = 1ll * blockIdx.x * blockDim.x + threadIdx.x; t < pairs; t += step) {
@@ -27,7 +29,7 @@ __global__ __launch_bounds__(256) void iou_pairs_kernel(const float *__restrict_
       M[k].x = boxes[bj * 8 + 2 * k];
       M[k].y = boxes[bj * 8 + 2 * k + 1];
     }
-    out[t] = overlap_from(I, M);
+    out[t] = overlap_from(I, M, clip);
   }
 }
 

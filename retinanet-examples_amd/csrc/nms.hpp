@@ -54,7 +54,7 @@ struct NmsArgs {
 
 // LDS carve-up shared by host (size) and device (pointers); every offset is 16-byte aligned.
 struct NmsLds {
-  size_t keys, sel, box, cls, kbox, kcls, kscore, ksrc, hist, misc, total;
+  size_t keys, sel, box, cls, kbox, kcls, kscore, ksrc, hist, misc, clip, total;
   __host__ __device__ NmsLds(uint32_t count, int ndet, int nb) {
     auto up = [](size_t v) { return (v + 15) & ~static_cast<size_t>(15); };
     size_t o = 0;
@@ -68,6 +68,9 @@ struct NmsLds {
     ksrc = o;   o += up(static_cast<size_t>(ndet) * 4);
     hist = o;   o += up(kRadixBins * 4);
     misc = o;   o += up(64 * 4);
+    // rotated IoU: lane-private polygon columns for the 5 waves that can clip at the same time
+    // (the chunk's 4 waves + wave 0), 4 KiB each -- see rotated_iou.hpp
+    clip = o;   o += nb == 6 ? up(5 * kClipSlotsPerWave * sizeof(float2)) : 0;
     total = o;
   }
 };
@@ -91,9 +94,9 @@ __device__ __forceinline__ bool axis_suppresses(const float *m, const float *j, 
 }
 
 template <int NB>
-__device__ __forceinline__ bool box_suppresses(const float *m, const float *j, float thr, bool own_angle) {
+__device__ __forceinline__ bool box_suppresses(const float *m, const float *j, float thr, bool own_angle, float2 *q) {
   if constexpr (NB == 4) return axis_suppresses(m, j, thr);
-  else return rotated_suppresses(m, j, thr, own_angle);
+  else return rotated_suppresses(m, j, thr, own_angle, q);
 }
 
 // Does any box kept at ranks [q0, q1) suppress candidate (jb, jc)?  Class words are fetched eight at
@@ -101,7 +104,8 @@ __device__ __forceinline__ bool box_suppresses(const float *m, const float *j, f
 // per-trip loop would pay the LDS latency once per kept box.
 template <int NB>
 __device__ __forceinline__ bool pull_against_kept(const float *s_kcls, const float *s_kbox, int q0, int q1,
-                                                  const float *jb, float jc, bool alive, float thr, bool own_angle) {
+                                                  const float *jb, float jc, bool alive, float thr, bool own_angle,
+                                                  float2 *clip) {
   for (int q = q0; q < q1 && alive; q += 8) {
     float kc[8];
 #pragma unroll
@@ -112,7 +116,7 @@ __device__ __forceinline__ bool pull_against_kept(const float *s_kcls, const flo
         float mb[NB];
 #pragma unroll
         for (int k = 0; k < NB; ++k) mb[k] = s_kbox[(q + u) * NB + k];
-        if (box_suppresses<NB>(mb, jb, thr, own_angle)) alive = false;
+        if (box_suppresses<NB>(mb, jb, thr, own_angle, clip)) alive = false;
       }
     }
   }
@@ -149,6 +153,7 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsArgs a) {
   // s_misc: [0..31] radix_select scratch, [32] key count, [33] gather cursor, [34] kept count,
   //         [40..47] alive words of the current chunk (4 x 64 bits)
   uint64_t *s_alive = reinterpret_cast<uint64_t *>(s_misc + 40);
+  float2 *s_clip = reinterpret_cast<float2 *>(smem + lay.clip);     // rotated only
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -233,7 +238,9 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsArgs a) {
           float jb[NB];
 #pragma unroll
           for (int k = 0; k < NB; ++k) jb[k] = s_box[tid * NB + k];
-          alive = pull_against_kept<NB>(s_kcls, s_kbox, 0, kept_before, jb, s_cls[tid], true, thr, own_angle);
+          // clip region of this wave: chunk waves use regions 0..3
+          float2 *clip = s_clip + ((static_cast<uint32_t>(tid) - c0) >> 6) * kClipSlotsPerWave + lane;
+          alive = pull_against_kept<NB>(s_kcls, s_kbox, 0, kept_before, jb, s_cls[tid], true, thr, own_angle, clip);
         }
         const uint64_t word = __ballot(alive);
         if (lane == 0) s_alive[(tid - c0) >> 6] = word;
@@ -242,6 +249,7 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsArgs a) {
 
       // (2) wave 0 resolves the chunk in order, 64 candidates at a time, no barrier inside
       if (wave == 0) {
+        float2 *clip = s_clip + 4 * kClipSlotsPerWave + lane;     // region 4: the resolver
         int k_cnt = kept_before;
         for (int g = 0; g < kNmsChunk / kWave && k_cnt < ndet; ++g) {
           const uint32_t r = c0 + g * kWave + lane;             // rank inside the round (< 1024)
@@ -253,7 +261,7 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsArgs a) {
           for (int k = 0; k < NB; ++k) jb[k] = s_box[r * NB + k];
           const float jc = s_cls[r];
           // pull against the boxes kept earlier in THIS chunk
-          alive = pull_against_kept<NB>(s_kcls, s_kbox, kept_before, k_cnt, jb, jc, alive, thr, own_angle);
+          alive = pull_against_kept<NB>(s_kcls, s_kbox, kept_before, k_cnt, jb, jc, alive, thr, own_angle, clip);
           // sequential greedy inside the group: one step per KEPT box, registers + readlane only
           int my_rank = -1;
           mask = __ballot(alive);
@@ -267,7 +275,7 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsArgs a) {
             if (lane == l0) { my_rank = k_cnt; alive = false; } // kept: its entry is written after the loop
             ++k_cnt;
             if (k_cnt == ndet) break;
-            if (alive && lane > l0 && jc == mc && box_suppresses<NB>(mb, jb, thr, own_angle)) alive = false;
+            if (alive && lane > l0 && jc == mc && box_suppresses<NB>(mb, jb, thr, own_angle, clip)) alive = false;
             mask = __ballot(alive);
           }
           if (my_rank >= 0) {                                   // all lanes kept in this group, in parallel

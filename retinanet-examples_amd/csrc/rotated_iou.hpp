@@ -12,6 +12,14 @@
 // degenerate clip emits more than 8 vertices, and calls rotateLeft(.., 0) on an empty polygon
 // (nms_iou.cu:139-149, :127-128) -- undefined behaviour.  Here a polygon is capped at 8 vertices
 // (extra vertices are dropped) and an empty polygon stays empty.
+//
+// Register plan.  The reference keeps ~7 float2[8] arrays per thread in local memory; a direct
+// port spills to scratch (176 B/lane) and every IoU pays dozens of dependent memory round trips
+// (measured: ~2.5 us per IoU inside the NMS).  Here the current polygon P[8] lives in VGPRs: every
+// loop over its vertices is fully unrolled and predicated on `j < count`, so all READS are
+// statically indexed.  Only the emitted polygon is written at a per-lane varying position; those
+// writes go to a lane-private LDS column (slot k of lane l at q[k*64 + l], conflict-free) and are
+// read back with static slots.  No scratch.
 #pragma once
 
 #include "common.hpp"
@@ -19,48 +27,58 @@
 namespace odtk {
 
 constexpr int kPolyMax = 8;
+constexpr int kClipSlotsPerWave = kPolyMax * kWave;      // float2 slots of LDS per wave (4 KiB)
 
 struct Pt { float x, y; };
 
-// Clips polygon P (count vertices) against the 4 directed edges of quad R; returns |area|.
-__device__ __forceinline__ float clip_area(const Pt *R, Pt *P) {
+// Clips polygon P (4 vertices on entry, in registers) against the 4 directed edges of quad R;
+// returns |area|.  q = this lane's column in a kClipSlotsPerWave-sized LDS region of its wave.
+__device__ __forceinline__ float clip_area(const Pt *R, Pt *P, float2 *q) {
   int count = 4;
-#pragma unroll 1
+#pragma unroll
   for (int e = 0; e < 4; ++e) {
     const Pt r1 = R[e], r2 = R[(e + 1) & 3];
     // Line(r1, r2): a = r2.y - r1.y, b = r1.x - r2.x, c = r2 x r1      (nms_iou.cu:86)
     const float la = r2.y - r1.y, lb = r1.x - r2.x, lc = r2.x * r1.y - r2.y * r1.x;
     float lv[kPolyMax];
 #pragma unroll
-    for (int j = 0; j < kPolyMax; ++j) lv[j] = (j < count) ? (la * P[j].x + lb * P[j].y + lc) : 0.0f;
-    Pt Q[kPolyMax];
+    for (int j = 0; j < kPolyMax; ++j) lv[j] = la * P[j].x + lb * P[j].y + lc;        // only j < count is used
     int nq = 0;
-#pragma unroll 1
-    for (int j = 0; j < count; ++j) {
-      const int jn = (j + 1 == count) ? 0 : j + 1;
-      if (lv[j] <= 0.0f) { if (nq < kPolyMax) Q[nq] = P[j]; ++nq; }
-      if (lv[j] * lv[jn] <= 0.0f) {
-        // Line(P[j], P[jn]) intersected with the clip line                (nms_iou.cu:92-95)
-        const Pt r3 = P[j], r4 = P[jn];
-        const float ma = r4.y - r3.y, mb = r3.x - r4.x, mc = r4.x * r3.y - r4.y * r3.x;
-        const float w = la * mb - lb * ma;
-        Pt x;
-        x.x = (lb * mc - lc * mb) / w;
-        x.y = (lc * ma - la * mc) / w;
-        if (nq < kPolyMax) Q[nq] = x;
-        ++nq;
+#pragma unroll
+    for (int j = 0; j < kPolyMax; ++j) {
+      if (j < count) {
+        const bool wrap = (j + 1 == count);
+        const Pt pn = wrap ? P[0] : P[(j + 1) & (kPolyMax - 1)];                        // next vertex, static index
+        const float lvn = wrap ? lv[0] : lv[(j + 1) & (kPolyMax - 1)];
+        if (lv[j] <= 0.0f) {                                                            // nms_iou.cu:140-143
+          if (nq < kPolyMax) q[nq * kWave] = make_float2(P[j].x, P[j].y);
+          ++nq;
+        }
+        if (lv[j] * lvn <= 0.0f) {                                                      // :144-150
+          // Line(P[j], P[j+1]) intersected with the clip line                         (:92-95)
+          const float ma = pn.y - P[j].y, mb = P[j].x - pn.x, mc = pn.x * P[j].y - pn.y * P[j].x;
+          const float w = la * mb - lb * ma;
+          const float ix = (lb * mc - lc * mb) / w, iy = (lc * ma - la * mc) / w;
+          if (nq < kPolyMax) q[nq * kWave] = make_float2(ix, iy);
+          ++nq;
+        }
       }
     }
     count = nq < kPolyMax ? nq : kPolyMax;
 #pragma unroll
-    for (int j = 0; j < kPolyMax; ++j) if (j < count) P[j] = Q[j];
+    for (int j = 0; j < kPolyMax; ++j) {                    // statically indexed read-back
+      const float2 v = q[j * kWave];
+      P[j].x = v.x;
+      P[j].y = v.y;
+    }
   }
   float area = 0.0f;
   if (count > 2) {
-#pragma unroll 1
-    for (int k = 0; k < count; ++k) {
-      const int kn = (k + 1 == count) ? 0 : k + 1;
-      area += P[k].x * P[kn].y - P[k].y * P[kn].x;
+#pragma unroll
+    for (int k = 0; k < kPolyMax; ++k) {
+      const Pt pn = (k + 1 == count) ? P[0] : P[(k + 1) & (kPolyMax - 1)];
+      const float term = P[k].x * pn.y - P[k].y * pn.x;                                 // :163-165
+      area = (k < count) ? area + term : area;
     }
   }
   return fabsf(area / 2.0f);
@@ -86,7 +104,7 @@ __device__ __forceinline__ void rotated_corners(const float *b, float s, float c
 }
 
 // overlap with the reference's NaN rules (nms_iou.cu:240-247)
-__device__ __forceinline__ float overlap_from(const Pt *I, const Pt *M) {
+__device__ __forceinline__ float overlap_from(const Pt *I, const Pt *M, float2 *q) {
   Pt P[kPolyMax];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -95,7 +113,7 @@ __device__ __forceinline__ float overlap_from(const Pt *I, const Pt *M) {
   }
 #pragma unroll
   for (int k = 4; k < kPolyMax; ++k) { P[k].x = 0.0f; P[k].y = 0.0f; }
-  const float inter = clip_area(M, P);
+  const float inter = clip_area(M, P, q);
   const float uni = (fabsf(quad_shoelace(I)) + fabsf(quad_shoelace(M))) / 2.0f;
   if (inter != inter && uni != uni) return 1.0f;
   if (inter != inter) return 0.0f;
@@ -104,11 +122,12 @@ __device__ __forceinline__ float overlap_from(const Pt *I, const Pt *M) {
 
 // Does the kept box m suppress the lower-scored box j?  boxes are [x1,y1,x2,y2,sin,cos].
 // Reference default (nms_iou.cu:186-193): BOTH quads are rotated by j's (sin, cos).
-__device__ __forceinline__ bool rotated_suppresses(const float *m, const float *j, float thr, bool own_angle) {
+__device__ __forceinline__ bool rotated_suppresses(const float *m, const float *j, float thr, bool own_angle,
+                                                   float2 *q) {
   Pt I[4], M[4];
   rotated_corners(j, j[4], j[5], I);
   rotated_corners(m, own_angle ? m[4] : j[4], own_angle ? m[5] : j[5], M);
-  return overlap_from(I, M) > thr;
+  return overlap_from(I, M, q) > thr;
 }
 
 }  // namespace odtk

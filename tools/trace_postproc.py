@@ -13,7 +13,8 @@ sys.path.insert(0, ROOT)
 import bench
 
 torch.manual_seed(0)
-m = Model('ResNet50FPN'); m.initialize(None)
+ROT = '--rotated' in sys.argv
+m = Model('ResNet50FPN', rotated_bbox=ROT); m.initialize(None)
 m = m.cuda().to(memory_format=torch.channels_last).eval()
 x = torch.randn(8, 3, 800, 1280, generator=torch.Generator().manual_seed(0)).cuda().contiguous(memory_format=torch.channels_last)
 bench.calibrate_cls_head(m, x, 0.573, torch.bfloat16)
@@ -22,7 +23,7 @@ with torch.no_grad():
     cls, dl = eng.heads(x)
 strides = [8, 16, 32, 64, 128]
 for s in strides: m.level_anchors(s)
-run = lambda: box.detect(cls, dl, strides, m.anchors, 0.05, 1000, 0.5, 100, logits=True)
+run = lambda: box.detect(cls, dl, strides, m.anchors, 0.05, 1000, 0.5, 100, ROT, logits=True)
 for _ in range(3): run()
 trace = torch.zeros(4096, dtype=torch.int64, device='cuda')
 _C.library().odtk_debug_set_trace(trace.data_ptr())
