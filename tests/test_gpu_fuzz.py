@@ -1,0 +1,91 @@
+"""Seeded differential fuzzing of the HIP path against the oracles: random shapes, anchor/class
+counts, thresholds, top_n, batch sizes, dtypes, layouts, tie densities.  Deterministic (fixed seeds) so
+a failure names its case."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import box_oracle, c_oracle
+from odtk import _C, box
+
+pytestmark = pytest.mark.gpu
+
+RATIOS = [1.0, 2.0, 0.5]
+SCALES = [4 * 2 ** (i / 3) for i in range(3)]
+
+
+def _case(seed):
+    r = np.random.default_rng(seed)
+    a = int(r.integers(1, 10))
+    c = int(r.integers(1, 12))
+    levels = int(r.integers(1, 4))
+    b = int(r.integers(1, 6))
+    shapes = [(int(r.integers(1, 40)), int(r.integers(1, 40))) for _ in range(levels)]
+    strides = [int(r.choice([4, 8, 16, 32, 64])) for _ in range(levels)]
+    thr = float(r.choice([0.0, 0.05, 0.3, 0.5, 0.9]))
+    top_n = int(r.choice([1, 7, 64, 100, 1000, 1500]))
+    spread = float(r.choice([0.5, 1.5, 4.0]))
+    quant = str(r.choice(['none', 'bf16', 'coarse']))
+    return a, c, b, shapes, strides, thr, top_n, spread, quant
+
+
+@pytest.mark.parametrize('seed', range(24))
+def test_decode_levels_random_configs(seed):
+    a, c, b, shapes, strides, thr, top_n, spread, quant = _case(seed)
+    g = torch.Generator().manual_seed(1000 + seed)
+    cls, dl = [], []
+    for (h, w) in shapes:
+        s = (torch.randn(b, a * c, h, w, generator=g) * spread - 1.0).sigmoid()
+        if quant == 'bf16':
+            s = s.bfloat16().float()                       # heavy ties
+        elif quant == 'coarse':
+            s = (s * 8).round() / 8                        # extreme ties, exact thresholds
+        cls.append(s)
+        dl.append(torch.randn(b, a * 4, h, w, generator=g) * 0.5)
+    anchors = {s: box.generate_anchors(s, RATIOS, SCALES)[:a].contiguous() for s in set(strides)}
+    out = _C.decode_levels([x.cuda() for x in cls], [x.cuda() for x in dl], [anchors[s] for s in strides], strides,
+                           thr, top_n, False, return_indices=True)
+    ref = [box_oracle.decode(x, d, s, thr, top_n, anchors[s], return_indices=True) for x, d, s in zip(cls, dl, strides)]
+    ref = [torch.cat(t, 1) for t in zip(*ref)]
+    assert torch.equal(out[3].cpu().long(), ref[3]), 'indices'
+    assert torch.equal(out[0].cpu(), ref[0]) and torch.equal(out[2].cpu(), ref[2])
+    tol = torch.maximum(torch.tensor(1e-4), torch.from_numpy(np.spacing(ref[1].abs().numpy())))
+    assert ((out[1].cpu() - ref[1]).abs() <= tol).all()
+    # same inputs as bf16 channels_last logits-free scores: identical selection on the rounded values
+    if quant == 'bf16':
+        out16 = _C.decode_levels([x.cuda().bfloat16().contiguous(memory_format=torch.channels_last) for x in cls],
+                                 [x.cuda().bfloat16().contiguous(memory_format=torch.channels_last) for x in dl],
+                                 [anchors[s] for s in strides], strides, thr, top_n, False, return_indices=True)
+        assert torch.equal(out16[3], out[3]) and torch.equal(out16[0], out[0])
+
+
+@pytest.mark.parametrize('seed', range(16))
+def test_nms_random_configs(seed):
+    r = np.random.default_rng(500 + seed)
+    b = int(r.integers(1, 5))
+    count = int(r.choice([1, 3, 64, 65, 300, 1025, 2500, 5000, 7680]))
+    ndet = int(r.choice([1, 5, 100, 300]))
+    thr = float(r.choice([0.0, 0.3, 0.5, 0.7, 1.0]))
+    n_cls = int(r.choice([1, 2, 80]))
+    rotated = bool(r.integers(0, 2)) and count <= 2500
+    g = torch.Generator().manual_seed(700 + seed)
+    span = float(r.choice([60.0, 300.0]))
+    ctr = torch.rand(b, count, 2, generator=g) * span + 20
+    wh = torch.rand(b, count, 2, generator=g) * 60 + 2
+    boxes = torch.cat([ctr - wh / 2, ctr + wh / 2], 2)
+    if rotated:
+        th = (torch.rand(b, count, generator=g) - 0.5) * 3.0
+        boxes = torch.cat([boxes, th.sin()[..., None], th.cos()[..., None]], 2)
+    scores = torch.rand(b, count, generator=g)
+    if r.integers(0, 2):
+        scores = (scores * 16).round() / 16                # ties (and exact zeros)
+    scores[torch.rand(b, count, generator=g) < 0.2] = 0
+    classes = torch.randint(0, n_cls, (b, count), generator=g).float()
+    out = _C.nms(scores.cuda(), boxes.cuda(), classes.cuda(), thr, ndet, rotated, return_indices=True)
+    ref = c_oracle.nms(scores.numpy(), boxes.numpy(), classes.numpy(), thr, ndet, rotated=rotated)
+    assert np.array_equal(out[3].cpu().numpy().astype(np.int64), ref[3]), 'kept positions'
+    for h, e in zip(out[:3], ref[:3]):
+        assert np.array_equal(np.ascontiguousarray(h.cpu().numpy()).view(np.uint32), e.view(np.uint32))
+    if not rotated:
+        t = box_oracle.nms(scores, boxes, classes, thr, ndet, return_indices=True)
+        assert torch.equal(out[3].cpu().long(), t[3])
