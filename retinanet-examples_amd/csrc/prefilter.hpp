@@ -127,8 +127,10 @@ __device__ __forceinline__ uint32_t memory_offset(uint32_t i, uint32_t channels,
   return pix * channels + ch;
 }
 
+// launch bounds: >= 8 waves/SIMD for the 16-bit forms (64 VGPRs, no spill), >= 6 for fp32 (80 VGPRs):
+// more workgroups in their load phase while others drain (measured bf16 52.6 -> 48.4 us)
 template <typename T, bool kLogits>
-__global__ __launch_bounds__(kScanThreads) void prefilter_scan_kernel(const ScanArgs a) {
+__global__ __launch_bounds__(kScanThreads, (sizeof(typename T::storage) == 2 ? 8 : 6)) void prefilter_scan_kernel(const ScanArgs a) {
   constexpr int kPer = T::kPerLoad;                        // elements per 16-byte load
   constexpr int kVec = kTile / (kScanThreads * kPer);      // loads per lane per tile: 16 (f32) or 8 (16-bit)
   __shared__ uint64_t s_stage[kStageCap];
