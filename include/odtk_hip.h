@@ -176,6 +176,22 @@ int odtk_detect(int batch_size, int n_levels, const odtk_level_t *levels,
 int odtk_bias_act(void *y, const float *bias, const void *residual, size_t n_pixels, int channels,
                   int dtype, int relu, void *stream);
 
+/*
+ * odtk_snap_to_anchors -- fused training-target assignment for ONE pyramid level of the whole batch.
+ * Replaces the reference's pure-torch snap_to_anchors (odtk/box.py:134-189, called per image and
+ * level from odtk/model.py:167-184): IoU of every anchor against every ground-truth box (+1 pixel
+ * convention), first maximum wins, regression deltas (box2delta, box.py:67-78), depth
+ * (-1 ignore / 0 background / class+1) and the one-hot class map.
+ *   targets     float32 [batch, n_max, 5] = (x, y, w, h, class); rows with class < 0 are padding
+ *   anchors     HOST float[4*num_anchors]
+ *   cls_target  float32 [batch, A, C, H, W]   box_target [batch, A, 4, H, W]   depth [batch, A, 1, H, W]
+ * n_max <= 1024.
+ */
+int odtk_snap_to_anchors(int batch_size, const float *targets, int n_max, const float *anchors,
+                         int num_anchors, int num_classes, int height, int width, int stride,
+                         float iou_background, float iou_foreground,
+                         float *cls_target, float *box_target, float *depth, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * Measurement hooks (used by bench.py; off by default, zero cost when off).
  * While enabled, every kernel launch of this library is bracketed by a hipEvent pair recorded on
@@ -187,7 +203,8 @@ int odtk_bias_act(void *y, const float *bias, const void *residual, size_t n_pix
 #define ODTK_KERNEL_NMS       2   /* nms_kernel                                    */
 #define ODTK_KERNEL_IOU       3   /* iou_pairs_kernel                              */
 #define ODTK_KERNEL_EPILOGUE  4   /* bias_act_kernel                               */
-#define ODTK_KERNEL_COUNT     5
+#define ODTK_KERNEL_TARGETS   5   /* snap_to_anchors_kernel                        */
+#define ODTK_KERNEL_COUNT     6
 /* on: 0 = off, otherwise a bit mask of kernel ids (1 << ODTK_KERNEL_*), -1 = all.  An event pair
  * is a queue marker before and after the kernel: cheap for the 3 post-processing launches of a step,
  * measurably NOT free for the ~110 epilogue launches (about 10 % of an 8.7 ms step), so time those

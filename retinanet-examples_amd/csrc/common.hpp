@@ -56,6 +56,10 @@ __device__ __forceinline__ float clamp_like_torch(float t, float hi) {
   return (mn != mn) ? mn : (mn > 0.0f ? mn : 0.0f);
 }
 
+// torch.max / torch.min propagate NaN
+__device__ __forceinline__ float tmax_nan(float a, float b) { return (a > b || a != a) ? a : b; }
+__device__ __forceinline__ float tmin_nan(float a, float b) { return (a < b || a != a) ? a : b; }
+
 // Correctly rounded fp32 exp (double-precision exp rounded once).  torch's CPU exp is within
 // 1 ulp of this (measured: 1.1 % of inputs differ, by exactly 1 ulp) -- see DESIGN.md "exp".
 __device__ __forceinline__ float exp_cr(float x) { return static_cast<float>(exp(static_cast<double>(x))); }

@@ -20,6 +20,7 @@
 #include "nms.hpp"
 #include "prefilter.hpp"
 #include "select_decode.hpp"
+#include "targets.hpp"
 
 namespace {
 
@@ -432,6 +433,39 @@ int odtk_iou(const void *const *inputs, void *const *outputs, int num_boxes, int
                        static_cast<hipStream_t>(stream), static_cast<const float *>(inputs[0]),
                        static_cast<const float *>(inputs[1]), static_cast<float *>(outputs[0]), num_boxes,
                        num_anchors);
+  }
+  ODTK_HIP_TRY(hipGetLastError());
+  return ODTK_OK;
+}
+
+int odtk_snap_to_anchors(int batch_size, const float *targets, int n_max, const float *anchors, int num_anchors,
+                         int num_classes, int height, int width, int stride, float iou_background,
+                         float iou_foreground, float *cls_target, float *box_target, float *depth, void *stream) {
+  if (batch_size <= 0 || n_max < 0 || n_max > odtk::kSnapMaxBoxes || num_anchors <= 0 ||
+      num_anchors > ODTK_MAX_ANCHORS || num_classes <= 0 || height <= 0 || width <= 0)
+    return ODTK_ERR_INVALID;
+  if (!anchors || !cls_target || !box_target || !depth || (n_max > 0 && !targets)) return ODTK_ERR_INVALID;
+  odtk::SnapArgs sa;
+  std::memset(&sa, 0, sizeof sa);
+  sa.targets = targets;
+  sa.cls_target = cls_target;
+  sa.box_target = box_target;
+  sa.depth = depth;
+  sa.n_max = n_max;
+  sa.num_anchors = num_anchors;
+  sa.num_classes = num_classes;
+  sa.height = height;
+  sa.width = width;
+  sa.stride = static_cast<float>(stride);
+  sa.iou_bg = iou_background;
+  sa.iou_fg = iou_foreground;
+  std::memcpy(sa.anchors, anchors, sizeof(float) * 4 * num_anchors);
+  const long long cells = 1ll * num_anchors * height * width;
+  const unsigned blocks = static_cast<unsigned>((cells + odtk::kSnapThreads - 1) / odtk::kSnapThreads);
+  {
+    KernelTimer t(ODTK_KERNEL_TARGETS, static_cast<hipStream_t>(stream));
+    hipLaunchKernelGGL(odtk::snap_to_anchors_kernel, dim3(blocks, batch_size), dim3(odtk::kSnapThreads), 0,
+                       static_cast<hipStream_t>(stream), sa);
   }
   ODTK_HIP_TRY(hipGetLastError());
   return ODTK_OK;

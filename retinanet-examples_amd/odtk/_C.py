@@ -59,13 +59,17 @@ _SIGNATURES = {
     'odtk_detect': (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.POINTER(Level), ctypes.c_int, ctypes.c_int,
                                    ctypes.c_int, ctypes.c_uint32, ctypes.c_float, ctypes.c_int, ctypes.c_float,
                                    ctypes.c_int, _vpp, _vp, _sz, _vp]),
+    'odtk_snap_to_anchors': (ctypes.c_int, [ctypes.c_int, _vp, ctypes.c_int, _fp, ctypes.c_int, ctypes.c_int,
+                                            ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float,
+                                            _vp, _vp, _vp, _vp]),
     'odtk_bias_act': (ctypes.c_int, [_vp, _vp, _vp, _sz, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp]),
     'odtk_profile_enable': (ctypes.c_int, [ctypes.c_int]),
     'odtk_debug_set_trace': (ctypes.c_int, [_vp]),
     'odtk_profile_collect': (ctypes.c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]),
 }
 
-KERNEL_NAMES = ('prefilter_scan_kernel', 'select_decode_kernel', 'nms_kernel', 'iou_pairs_kernel', 'bias_act_kernel')
+KERNEL_NAMES = ('prefilter_scan_kernel', 'select_decode_kernel', 'nms_kernel', 'iou_pairs_kernel', 'bias_act_kernel',
+                'snap_to_anchors_kernel')
 
 _lib = None
 
@@ -302,6 +306,29 @@ def detect(cls_heads, box_heads, anchors_list, strides, score_thresh, top_n, nms
         ws, stream = _workspace(dev, size)
         _check(lib.odtk_detect(*args, _ptrs(out), ws.data_ptr(), ws.numel(), stream), 'detect')
     return out
+
+
+def snap_to_anchors(targets, anchors, num_classes, height, width, stride, iou_background, iou_foreground):
+    """Fused target assignment of one pyramid level for the whole batch (reference box.py:134-189 per
+    image).  targets: float32 CUDA [B, N, 5] (x, y, w, h, class; class < 0 = padding row).
+    -> cls_target [B, A, C, H, W], box_target [B, A, 4, H, W], depth [B, A, 1, H, W]."""
+    _check_input(targets, 'targets')
+    if targets.dim() != 3 or targets.shape[2] != 5:
+        raise RuntimeError('targets must be [B, N, 5]')
+    arr, n = _anchor_array(anchors.reshape(-1).tolist() if isinstance(anchors, torch.Tensor) else anchors)
+    a = n // 4
+    b, n_max = targets.shape[0], targets.shape[1]
+    dev = targets.device
+    with torch.cuda.device(dev):
+        cls = torch.empty((b, a, num_classes, height, width), dtype=torch.float32, device=dev)
+        box_t = torch.empty((b, a, 4, height, width), dtype=torch.float32, device=dev)
+        depth = torch.empty((b, a, 1, height, width), dtype=torch.float32, device=dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _check(library().odtk_snap_to_anchors(b, targets.data_ptr(), n_max, arr, a, int(num_classes), int(height),
+                                              int(width), int(stride), float(iou_background), float(iou_foreground),
+                                              cls.data_ptr(), box_t.data_ptr(), depth.data_ptr(), stream),
+               'snap_to_anchors')
+    return cls, box_t, depth
 
 
 def bias_act_(y, bias, residual=None, relu=True):

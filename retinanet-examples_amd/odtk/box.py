@@ -173,6 +173,15 @@ def snap_to_anchors(boxes, size, stride, anchors, num_classes, device, anchor_io
                                  box2delta)
 
 
+def snap_to_anchors_batched(targets, width, height, stride, anchors, num_classes, anchor_ious):
+    """snap_to_anchors for every image of the batch in ONE fused HIP launch (GPU only).
+    targets [B, N, 5] padded with class = -1 rows (reference data.py:154-161 format).
+    Returns the stacked (cls_target [B,A,C,H,W], box_target [B,A,4,H,W], depth [B,A,1,H,W])."""
+    _require_gpu(targets, 'snap_to_anchors_batched')
+    return _C.snap_to_anchors(targets.float().contiguous(), anchors, num_classes, int(height), int(width),
+                              int(stride), anchor_ious[0], anchor_ious[1])
+
+
 def rotate_boxes(boxes, points=False):
     """(x, y, w, h, theta) targets -> ([x1, y1, x2, y2, sin, cos], ordered corner quads [N, 8])
     (reference utils.py:33-82; `points=True` takes (x1, y1, x2, y2, theta))."""

@@ -80,3 +80,72 @@ def test_loss_pipeline_on_cpu():
     (cls_loss + box_loss).backward()
     g = m.cls_head[-1].weight.grad
     assert g is not None and torch.isfinite(g).all() and g.abs().sum() > 0
+
+
+# ------------------------------------------------------------------------------------------------
+# fused HIP kernel (csrc/targets.hpp) -- GPU
+# ------------------------------------------------------------------------------------------------
+def _pad(boxes_list, n_max):
+    out = torch.full((len(boxes_list), n_max, 5), -1.0)
+    for i, b in enumerate(boxes_list):
+        out[i, :b.shape[0]] = b
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('path', SNAP, ids=os.path.basename)
+def test_fused_kernel_matches_reference_fixture(path):
+    from odtk import _C
+    with np.load(path) as z:
+        g = {k: z[k] for k in z.files}
+    boxes, anchors = torch.from_numpy(g['boxes']).view(-1, 5), torch.from_numpy(g['anchors'])
+    size, stride, classes, ious = [int(v) for v in g['size']], int(g['stride']), int(g['classes']), list(g['ious'])
+    w, h = size[0] // stride, size[1] // stride
+    targets = _pad([boxes, boxes[:0]], max(boxes.shape[0], 1) + 3).cuda()          # image 1 has no boxes
+    cls, box_t, depth = _C.snap_to_anchors(targets, anchors, classes, h, w, stride, ious[0], ious[1])
+    assert np.array_equal(_bits(cls[0].cpu().numpy()), _bits(g['cls_target']))
+    assert np.array_equal(_bits(depth[0].cpu().numpy()), _bits(g['depth']))
+    # deltas: only log() differs from the CPU reference (<= 1-2 ulp)
+    assert np.allclose(box_t[0].cpu().numpy(), g['box_target'], rtol=1e-6, atol=1e-6)
+    assert float(cls[1].abs().sum()) == 0 and float(box_t[1].abs().sum()) == 0 and float(depth[1].abs().sum()) == 0
+
+
+@pytest.mark.gpu
+def test_fused_kernel_random_batches_vs_oracle():
+    from odtk import _C
+    g = torch.Generator().manual_seed(77)
+    for stride, (wpx, hpx), n_list in [(8, (320, 256), [30, 1, 0, 17]), (32, (352, 224), [5, 12]), (128, (384, 256), [2])]:
+        anchors = box.generate_anchors(stride, RATIOS, SCALES)
+        per_image = []
+        for n in n_list:
+            xy = torch.rand(n, 2, generator=g) * torch.tensor([wpx * 0.7, hpx * 0.7])
+            wh = torch.rand(n, 2, generator=g) * torch.tensor([wpx * 0.6, hpx * 0.6]) + 4
+            per_image.append(torch.cat([xy, wh, torch.randint(0, 80, (n, 1), generator=g).float()], 1))
+        # padding rows interleaved (not only at the end): the kernel filters by class > -1 in order
+        targets = _pad(per_image, max(n_list) + 2)
+        targets[0, [1, 3]] = targets[0, [3, 1]]
+        per_image[0] = targets[0][targets[0][:, 4] > -1]
+        out = _C.snap_to_anchors(targets.cuda(), anchors, 80, hpx // stride, wpx // stride, stride, 0.4, 0.5)
+        for i, b in enumerate(per_image):
+            ora = box_oracle.snap_to_anchors(b, [wpx, hpx], stride, anchors, 80, [0.4, 0.5])
+            assert np.array_equal(_bits(out[0][i].cpu().numpy()), _bits(ora[0].numpy())), (stride, i, 'cls')
+            assert np.array_equal(_bits(out[2][i].cpu().numpy()), _bits(ora[2].numpy())), (stride, i, 'depth')
+            assert np.allclose(out[1][i].cpu().numpy(), ora[1].numpy(), rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_training_loss_fused_equals_torch_targets():
+    """Model._compute_loss with the fused HIP target assignment == with the per-image torch path."""
+    from odtk.model import Model
+    from odtk import train as T
+    torch.manual_seed(0)
+    m = Model('ResNet18FPN', classes=6)
+    m.initialize(None)
+    m = m.cuda().train()
+    data, target = T.SyntheticBatches(2, 256, 320, classes=6, max_boxes=6, seed=5, device='cuda').batch()
+    with torch.no_grad():
+        heads = m.heads(data)
+        fused = m._compute_loss(data, *heads, target)
+        long_target = torch.cat([target, torch.full((2, 1100, 5), -1.0, device='cuda')], 1)   # > 1024 rows: torch path
+        plain = m._compute_loss(data, *heads, long_target)
+    assert torch.allclose(fused[0], plain[0], rtol=1e-6) and torch.allclose(fused[1], plain[1], rtol=1e-5)
