@@ -17,13 +17,13 @@
 //   round    : the next 1024 best keys are radix-selected out of the LDS-resident key list and
 //              sorted (bitonic, 1 key per thread) -- a full sort of all candidates never happens
 //              unless the greedy scan really needs them all.
-//   chunk    : 256 candidates.  (1) their threads test them, in parallel, against every box kept
-//              before the chunk; (2) wave 0 walks the chunk's survivors in order, 64 at a time:
-//              pull against the boxes kept earlier in this chunk, then resolve the 64 sequentially
-//              with ballot / readlane -- no barrier inside.
+//   chunk    : 64 candidates (lane <-> candidate).  (1) all 16 waves test the SAME 64 candidates,
+//              each against its own 1/16 slice of the kept list (a candidate's <= ndetections IoU
+//              tests run on 16 threads); (2) wave 0 ANDs the 16 verdict words and resolves the
+//              survivors sequentially with ballot / v_readlane -- registers only, no barrier inside.
 // Typical inputs (100 detections found among the first few hundred candidates) finish in one round
 // and one or two chunks; the worst case (all one class, heavy suppression) is bounded by
-// count/256 chunks x (<= ndetections parallel IoU tests + 2 barriers).
+// count/64 chunks x (<= ndetections/16 IoU tests per thread + 2 barriers).
 #pragma once
 
 #include "common.hpp"
@@ -35,7 +35,7 @@ namespace odtk {
 
 constexpr int kNmsThreads = 1024;
 constexpr int kNmsRound = 1024;        // keys selected + sorted per round (one per thread)
-constexpr int kNmsChunk = 256;         // candidates resolved per chunk (4 groups of 64)
+constexpr int kNmsChunk = 64;          // candidates resolved per chunk: one wave-width
 
 struct NmsArgs {
   const float *scores;     // [batch, count]
@@ -54,7 +54,9 @@ struct NmsArgs {
 
 // LDS carve-up shared by host (size) and device (pointers); every offset is 16-byte aligned.
 struct NmsLds {
+  static constexpr size_t kLdsBudget = 160 * 1024;
   size_t keys, sel, box, cls, kbox, kcls, kscore, ksrc, hist, misc, clip, total;
+  int ways;     // waves that take part in the pull phase
   __host__ __device__ NmsLds(uint32_t count, int ndet, int nb) {
     auto up = [](size_t v) { return (v + 15) & ~static_cast<size_t>(15); };
     size_t o = 0;
@@ -67,10 +69,16 @@ struct NmsLds {
     kscore = o; o += up(static_cast<size_t>(ndet) * 4);
     ksrc = o;   o += up(static_cast<size_t>(ndet) * 4);
     hist = o;   o += up(kRadixBins * 4);
-    misc = o;   o += up(64 * 4);
-    // rotated IoU: lane-private polygon columns for the 5 waves that can clip at the same time
-    // (the chunk's 4 waves + wave 0), 4 KiB each -- see rotated_iou.hpp
-    clip = o;   o += nb == 6 ? up(5 * kClipSlotsPerWave * sizeof(float2)) : 0;
+    misc = o;   o += up(96 * 4);
+    // rotated IoU: one lane-private polygon region (4 KiB, rotated_iou.hpp) per wave that takes part
+    // in the pull phase: as many of the 16 waves as the 160 KiB budget allows
+    clip = o;
+    ways = 16;
+    if (nb == 6) {
+      const size_t room = o < kLdsBudget ? (kLdsBudget - o) / (kClipSlotsPerWave * sizeof(float2)) : 0;
+      ways = room >= 16 ? 16 : (room >= 1 ? static_cast<int>(room) : 1);
+      o += static_cast<size_t>(ways) * kClipSlotsPerWave * sizeof(float2);
+    }
     total = o;
   }
 };
@@ -99,23 +107,23 @@ __device__ __forceinline__ bool box_suppresses(const float *m, const float *j, f
   else return rotated_suppresses(m, j, thr, own_angle, q);
 }
 
-// Does any box kept at ranks [q0, q1) suppress candidate (jb, jc)?  Class words are fetched eight at
-// a time (independent LDS reads) -- the common case is "no kept box of this class", and a one-read-
-// per-trip loop would pay the LDS latency once per kept box.
+// Does any box kept at ranks q0, q0 + step, ... (< q1) suppress candidate (jb, jc)?  Class words are
+// fetched eight at a time (independent LDS reads) -- the common case is "no kept box of this class",
+// and a one-read-per-trip loop would pay the LDS latency once per kept box.
 template <int NB>
-__device__ __forceinline__ bool pull_against_kept(const float *s_kcls, const float *s_kbox, int q0, int q1,
+__device__ __forceinline__ bool pull_against_kept(const float *s_kcls, const float *s_kbox, int q0, int q1, int step,
                                                   const float *jb, float jc, bool alive, float thr, bool own_angle,
                                                   float2 *clip) {
-  for (int q = q0; q < q1 && alive; q += 8) {
+  for (int q = q0; q < q1 && alive; q += 8 * step) {
     float kc[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) kc[u] = (q + u < q1) ? s_kcls[q + u] : __builtin_nanf("");   // NaN equals nothing
+    for (int u = 0; u < 8; ++u) kc[u] = (q + u * step < q1) ? s_kcls[q + u * step] : __builtin_nanf("");   // NaN equals nothing
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       if (alive && kc[u] == jc) {                               // box.py:351: a different class keeps
         float mb[NB];
 #pragma unroll
-        for (int k = 0; k < NB; ++k) mb[k] = s_kbox[(q + u) * NB + k];
+        for (int k = 0; k < NB; ++k) mb[k] = s_kbox[(q + u * step) * NB + k];
         if (box_suppresses<NB>(mb, jb, thr, own_angle, clip)) alive = false;
       }
     }
@@ -151,9 +159,10 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsArgs a) {
   uint32_t *s_hist = reinterpret_cast<uint32_t *>(smem + lay.hist);
   uint32_t *s_misc = reinterpret_cast<uint32_t *>(smem + lay.misc);
   // s_misc: [0..31] radix_select scratch, [32] key count, [33] gather cursor, [34] kept count,
-  //         [40..47] alive words of the current chunk (4 x 64 bits)
+  //         [40..71] verdict words of the pull phase (16 x 64 bits)
   uint64_t *s_alive = reinterpret_cast<uint64_t *>(s_misc + 40);
   float2 *s_clip = reinterpret_cast<float2 *>(smem + lay.clip);     // rotated only
+  const int ways = lay.ways;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -208,7 +217,7 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsArgs a) {
     const LdsKeySource src{s_keys, K, upper};
     uint64_t lower = 0;
     // any top-prefix of 256..1024 keys will do for a round: stop the radix descent early
-    if (left > kNmsRound) lower = radix_threshold(src, kNmsChunk, kNmsRound, s_hist, s_misc, &n_round);
+    if (left > kNmsRound) lower = radix_threshold(src, 256, kNmsRound, s_hist, s_misc, &n_round);
     if (tid == 0) s_misc[33] = 0;
     __syncthreads();
     src.for_each([&](uint64_t key) { if (key >= lower) s_sel[atomicAdd(&s_misc[33], 1u)] = key; });
@@ -228,64 +237,52 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsArgs a) {
     }
     __syncthreads();
 
-    // ---- chunks of 256 candidates ----
+    // ---- chunks of 64 candidates: 16-way parallel pull, then one wave resolves the 64 in order ----
     for (uint32_t c0 = 0; c0 < n_round && kept < ndet; c0 += kNmsChunk) {
       const int kept_before = kept;
-      // (1) the chunk's own threads pull against everything kept before the chunk
-      if (static_cast<uint32_t>(tid) >= c0 && static_cast<uint32_t>(tid) < c0 + kNmsChunk) {
-        bool alive = static_cast<uint32_t>(tid) < n_round;
-        if (alive) {
-          float jb[NB];
+      // (1) EVERY wave looks at the same 64 candidates (lane <-> candidate) but against its own
+      //     slice of the kept list (ranks wave, wave + ways, ...): a candidate's <= ndet tests are
+      //     spread over `ways` threads.  Wave w publishes its verdict word; the AND is the survivor set.
+      const uint32_t r = c0 + lane;                           // rank inside the round (< 1024)
+      float jb[NB];
 #pragma unroll
-          for (int k = 0; k < NB; ++k) jb[k] = s_box[tid * NB + k];
-          // clip region of this wave: chunk waves use regions 0..3
-          float2 *clip = s_clip + ((static_cast<uint32_t>(tid) - c0) >> 6) * kClipSlotsPerWave + lane;
-          alive = pull_against_kept<NB>(s_kcls, s_kbox, 0, kept_before, jb, s_cls[tid], true, thr, own_angle, clip);
-        }
+      for (int k = 0; k < NB; ++k) jb[k] = s_box[r * NB + k];
+      const float jc = s_cls[r];
+      float2 *clip = s_clip + static_cast<size_t>(wave) * kClipSlotsPerWave + lane;   // rotated: wave-private
+      if (wave < ways) {
+        bool alive = r < n_round;
+        if (alive) alive = pull_against_kept<NB>(s_kcls, s_kbox, wave, kept_before, ways, jb, jc, true, thr, own_angle, clip);
         const uint64_t word = __ballot(alive);
-        if (lane == 0) s_alive[(tid - c0) >> 6] = word;
+        if (lane == 0) s_alive[wave] = word;
       }
       __syncthreads();
 
-      // (2) wave 0 resolves the chunk in order, 64 candidates at a time, no barrier inside
+      // (2) wave 0 resolves the 64 survivors sequentially: one step per KEPT box, registers + readlane
       if (wave == 0) {
-        float2 *clip = s_clip + 4 * kClipSlotsPerWave + lane;     // region 4: the resolver
-        int k_cnt = kept_before;
-        for (int g = 0; g < kNmsChunk / kWave && k_cnt < ndet; ++g) {
-          const uint32_t r = c0 + g * kWave + lane;             // rank inside the round (< 1024)
-          uint64_t mask = s_alive[g];
-          if (mask == 0) continue;                              // wave-uniform
-          bool alive = (mask >> lane) & 1ull;
-          float jb[NB];
+        uint64_t mask = ~0ull;
+        for (int w = 0; w < ways; ++w) mask &= s_alive[w];
+        bool alive = (mask >> lane) & 1ull;
+        int k_cnt = kept_before, my_rank = -1;
+        while (mask) {
+          // mask is wave-uniform: keep l0 in an SGPR so the broadcasts are v_readlane, not LDS permutes
+          const int l0 = __builtin_amdgcn_readfirstlane(__ffsll(static_cast<unsigned long long>(mask)) - 1);
+          float mb[NB];
 #pragma unroll
-          for (int k = 0; k < NB; ++k) jb[k] = s_box[r * NB + k];
-          const float jc = s_cls[r];
-          // pull against the boxes kept earlier in THIS chunk
-          alive = pull_against_kept<NB>(s_kcls, s_kbox, kept_before, k_cnt, jb, jc, alive, thr, own_angle, clip);
-          // sequential greedy inside the group: one step per KEPT box, registers + readlane only
-          int my_rank = -1;
+          for (int k = 0; k < NB; ++k) mb[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(jb[k]), l0));
+          const float mc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(jc), l0));
+          if (lane == l0) { my_rank = k_cnt; alive = false; }   // kept: its entry is written after the loop
+          ++k_cnt;
+          if (k_cnt == ndet) break;
+          if (alive && lane > l0 && jc == mc && box_suppresses<NB>(mb, jb, thr, own_angle, clip)) alive = false;
           mask = __ballot(alive);
-          while (mask) {
-            // mask is wave-uniform: keep l0 in an SGPR so the broadcasts are v_readlane, not LDS permutes
-            const int l0 = __builtin_amdgcn_readfirstlane(__ffsll(static_cast<unsigned long long>(mask)) - 1);
-            float mb[NB];
+        }
+        if (my_rank >= 0) {                                     // all lanes kept in this chunk, in parallel
+          const uint64_t key = s_sel[r];
 #pragma unroll
-            for (int k = 0; k < NB; ++k) mb[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(jb[k]), l0));
-            const float mc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(jc), l0));
-            if (lane == l0) { my_rank = k_cnt; alive = false; } // kept: its entry is written after the loop
-            ++k_cnt;
-            if (k_cnt == ndet) break;
-            if (alive && lane > l0 && jc == mc && box_suppresses<NB>(mb, jb, thr, own_angle, clip)) alive = false;
-            mask = __ballot(alive);
-          }
-          if (my_rank >= 0) {                                   // all lanes kept in this group, in parallel
-            const uint64_t key = s_sel[r];
-#pragma unroll
-            for (int k = 0; k < NB; ++k) s_kbox[my_rank * NB + k] = jb[k];
-            s_kcls[my_rank] = jc;
-            s_kscore[my_rank] = key_score(key);
-            s_ksrc[my_rank] = static_cast<int32_t>(key_index(key));
-          }
+          for (int k = 0; k < NB; ++k) s_kbox[my_rank * NB + k] = jb[k];
+          s_kcls[my_rank] = jc;
+          s_kscore[my_rank] = key_score(key);
+          s_ksrc[my_rank] = static_cast<int32_t>(key_index(key));
         }
         if (lane == 0) s_misc[34] = static_cast<uint32_t>(k_cnt);
       }

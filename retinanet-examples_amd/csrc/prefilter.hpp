@@ -213,12 +213,6 @@ __global__ __launch_bounds__(kScanThreads, (sizeof(typename T::storage) == 2 ? 8
         return std::is_same_v<T, BF16> ? bf16_bits_to_float(h) : f16_bits_to_float(h);
       }
     };
-    // storage bits of an element (integer ops only: keeps the converted floats out of registers)
-    auto bits_at = [&](int u, int e) -> uint32_t {
-      if constexpr (std::is_same_v<T, F32>) return v[u][e];
-      else return (v[u][e >> 1] >> (16 * (e & 1))) & 0xffffu;
-    };
-
     // hit mask over the lane's 64 elements: bit (kPer*u + e); one compare each, NaN fails >=
     uint64_t mask = 0;
 #pragma unroll
@@ -233,15 +227,34 @@ __global__ __launch_bounds__(kScanThreads, (sizeof(typename T::storage) == 2 ? 8
       uint32_t o = atomicAdd(&s_cnt, cnt);                 // block-local slots (order is irrelevant)
       if (o + cnt <= kStageCap) {
         const uint32_t elem0 = vec0 * kPer + kPer * tid;   // span offset of this lane's first element
+        if constexpr (std::is_same_v<T, F32>) {
+          // fp32: 16 loads are live (64 VGPRs) -- the fully unrolled walk is what fits in 80 registers
 #pragma unroll
-        for (int u = 0; u < kVec; ++u) {
-          const uint32_t m = static_cast<uint32_t>(mask >> (kPer * u)) & ((1u << kPer) - 1u);
-          if (m) {
+          for (int u = 0; u < kVec; ++u) {
+            const uint32_t m = static_cast<uint32_t>(mask >> (kPer * u)) & ((1u << kPer) - 1u);
+            if (m) {
 #pragma unroll
-            for (int e = 0; e < kPer; ++e)
-              if (m & (1u << e))
-                s_stage[o++] = (static_cast<uint64_t>(bits_at(u, e)) << 32) |
-                               static_cast<uint32_t>(elem0 + kPer * u * kScanThreads + e);
+              for (int e = 0; e < kPer; ++e)
+                if (m & (1u << e))
+                  s_stage[o++] = (static_cast<uint64_t>(v[u][e]) << 32) |
+                                 static_cast<uint32_t>(elem0 + kPer * u * kScanThreads + e);
+            }
+          }
+        } else {
+#pragma unroll
+          for (int u = 0; u < kVec; ++u) {
+            uint32_t m = static_cast<uint32_t>(mask >> (kPer * u)) & ((1u << kPer) - 1u);
+            // rolled: one trip per hit of this lane inside load u (the wave almost never needs a
+            // second); an unrolled walk over the 64 bit positions costs ~2x the mask build itself
+#pragma unroll 1
+            while (m) {
+              const uint32_t e = static_cast<uint32_t>(__builtin_ctz(m));
+              m &= m - 1u;
+              const uint32_t d = e >> 1;
+              const uint32_t w = d == 0 ? v[u][0] : (d == 1 ? v[u][1] : (d == 2 ? v[u][2] : v[u][3]));
+              s_stage[o++] = (static_cast<uint64_t>((w >> (16u * (e & 1u))) & 0xffffu) << 32) |
+                             (elem0 + kPer * u * kScanThreads + e);
+            }
           }
         }
       }

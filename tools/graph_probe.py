@@ -4,38 +4,38 @@ import torch
 torch.backends.cudnn.benchmark = True
 from odtk.model import Model
 from odtk.fused import FusedRetinaNet
-from odtk import box, _C
-which = sys.argv[1]
+P = lambda *a: print(*a, flush=True)
 torch.manual_seed(0)
 m = Model('ResNet50FPN'); m.initialize(None)
 m = m.cuda().to(memory_format=torch.channels_last).eval()
 x = torch.randn(8, 3, 800, 1280, device='cuda').contiguous(memory_format=torch.channels_last)
 eng = FusedRetinaNet(m).cuda()
-with torch.no_grad():
-    cls, dl = eng.heads(x)
-strides = [8, 16, 32, 64, 128]
-for s in strides: m.level_anchors(s)
-def post(): return box.detect(cls, dl, strides, m.anchors, 0.05, 1000, 0.5, 100, logits=True)
-def heads():
-    with torch.no_grad(): return eng.heads(x)
-def bias_only():
-    y = cls[0]
-    return _C.bias_act_(y, eng.cls_head[-1].bias, None, False)
-def conv_only():
-    with torch.no_grad(): return torch.nn.functional.conv2d(x.bfloat16(), eng.stem.weight, None, 2, 3)
-fn = {'post': post, 'heads': heads, 'bias': bias_only, 'conv': conv_only}[which]
-for _ in range(3): fn()
+def step(): return eng(x)
+for _ in range(8): step()
 torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(20): step()
+torch.cuda.synchronize()
+P('eager fused: %.3f ms/step' % ((time.perf_counter() - t0) * 50))
 g = torch.cuda.CUDAGraph()
 s = torch.cuda.Stream(); s.wait_stream(torch.cuda.current_stream())
 with torch.cuda.stream(s):
-    for _ in range(3): fn()
+    for _ in range(3): step()
 torch.cuda.current_stream().wait_stream(s)
 torch.cuda.synchronize()
+P('side-stream warmup done')
 with torch.cuda.graph(g):
-    out = fn()
+    out = step()
 torch.cuda.synchronize()
-print(which, 'captured', flush=True)
+P('captured')
+g.replay(); torch.cuda.synchronize()
+P('first replay ok')
 for _ in range(3): g.replay()
 torch.cuda.synchronize()
-print(which, 'replayed OK', flush=True)
+t0 = time.perf_counter()
+for _ in range(20): g.replay()
+torch.cuda.synchronize()
+P('hipGraph replay fused: %.3f ms/step' % ((time.perf_counter() - t0) * 50))
+snap = [o.clone() for o in out]
+ref = step(); torch.cuda.synchronize()
+P('graph output equals eager:', all(torch.equal(a, b) for a, b in zip(snap, ref)))

@@ -26,6 +26,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--kind', default='sparse', choices=['sparse', 'dense', 'empty', 'saturated'])
     ap.add_argument('--batch', type=int, default=8)
+    ap.add_argument('--sigma', type=float, default=None, help='std of the logits (overrides --kind; 0.6225 -> 0.4 %% pass 0.05)')
     ap.add_argument('--height', type=int, default=800)
     ap.add_argument('--width', type=int, default=1280)
     ap.add_argument('--anchors', type=int, default=9)
@@ -53,7 +54,7 @@ def main():
         elif args.kind == 'saturated':
             c = torch.ones(shape, device=dev)
         else:
-            c = torch.randn(shape, generator=g, device=dev) * synthetic.SIGMA[args.kind] + synthetic.LOGIT_PRIOR
+            c = torch.randn(shape, generator=g, device=dev) * (args.sigma or synthetic.SIGMA[args.kind]) + synthetic.LOGIT_PRIOR
             if not args.logits:
                 c = c.sigmoid()
         d = torch.randn((args.batch, args.anchors * nb, h, w), generator=g, device=dev) * 0.2
