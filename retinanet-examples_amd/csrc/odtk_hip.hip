@@ -94,13 +94,18 @@ int decode_layout(int batch, int n_levels, const odtk_level_t *levels, int A, in
     const unsigned long long n = 1ull * A * C * levels[l].height * levels[l].width;
     if (n == 0 || n > 0x7fff0000ull) return ODTK_ERR_INVALID;
     out->n[l] = static_cast<uint32_t>(n);
-    // per sub-list capacity: the segment's capacity min(n, ODTK_CAND_CAP) split kSubLists ways, but
-    // never less than one full tile's worth for tiny levels (a single tile feeds a single sub-list)
-    const unsigned long long seg_cap = n < cand_cap_limit() ? n : cand_cap_limit();
-    unsigned long long sub = (seg_cap + odtk::kSubLists - 1) / odtk::kSubLists;
-    const unsigned long long span = static_cast<unsigned long long>(odtk::kTile) * odtk::kMaxSpanTiles;
-    const unsigned long long one_tile = n < span ? n : span;     // one workgroup feeds one sub-list
-    if (sub < one_tile && n <= 4ull * span) sub = one_tile;
+    // Per sub-list capacity.  An image's spans are consecutive and rotate over the kSubLists sub-lists,
+    // so one sub-list receives at most ceil(spans / kSubLists) spans' worth of that image's scores:
+    // with that capacity no sub-list overflows, whatever the density.  (Sized for the longest span;
+    // the fp32 form's one-tile spans need no more.)  Levels with more than ODTK_CAND_CAP scores per
+    // image get ODTK_CAND_CAP / kSubLists instead; if an input overflows a sub-list, select_decode
+    // falls back to scanning that segment's raw scores, so capacity is a speed knob, never a result.
+    const unsigned long long span_elems = static_cast<unsigned long long>(odtk::kTile) * odtk::kMaxSpanTiles;
+    const unsigned long long spans = (n + span_elems - 1) / span_elems + 1;          // +1: unaligned start
+    unsigned long long sub = (spans + odtk::kSubLists - 1) / odtk::kSubLists * span_elems;
+    if (sub > n) sub = n;
+    const unsigned long long limited = (cand_cap_limit() + odtk::kSubLists - 1) / odtk::kSubLists;
+    if (n > cand_cap_limit() && sub > limited) sub = limited;
     out->cap[l] = static_cast<uint32_t>((sub + 31) / 32 * 32);
     out->cand_off[l] = off;
     off += align_up(sizeof(uint64_t) * static_cast<size_t>(batch) * odtk::kSubLists * out->cap[l]);

@@ -89,3 +89,24 @@ def test_nms_random_configs(seed):
     if not rotated:
         t = box_oracle.nms(scores, boxes, classes, thr, ndet, return_indices=True)
         assert torch.equal(out[3].cpu().long(), t[3])
+
+
+@pytest.mark.parametrize('shape', [(9, 20, 40, 40), (9, 80, 25, 40), (3, 7, 96, 100)])
+def test_every_score_passes_on_a_mid_size_level(shape):
+    """Threshold 0 on levels of 0.2-0.7 M scores: every element is a candidate, so one prefilter
+    workgroup hands a whole span's worth of keys to one sub-list (sized for it; were it not, the
+    raw-score fallback of select_decode would take over) -- top-n must still be the exact top-n."""
+    a, c, h, w = shape
+    g = torch.Generator().manual_seed(31 + h)
+    cls = torch.rand(2, a * c, h, w, generator=g) * 0.999 + 0.0005
+    dl = torch.randn(2, a * 4, h, w, generator=g) * 0.3
+    anchors = box.generate_anchors(16, RATIOS, SCALES)[:a].contiguous()
+    out = _C.decode_levels([cls.cuda()], [dl.cuda()], [anchors], [16], 0.0, 1000, False, return_indices=True)
+    ref = box_oracle.decode(cls, dl, 16, 0.0, 1000, anchors, return_indices=True)
+    assert torch.equal(out[0].cpu(), ref[0]), 'scores'
+    # ties among fp32 uniforms are possible: compare indices where the score is unique in the reference
+    uniq = torch.ones_like(ref[0], dtype=torch.bool)
+    uniq[:, 1:] &= ref[0][:, 1:] != ref[0][:, :-1]
+    uniq[:, :-1] &= ref[0][:, :-1] != ref[0][:, 1:]
+    assert torch.equal(out[3].cpu().long()[uniq], ref[3][uniq])
+    assert torch.equal(out[3].cpu().long(), ref[3]), 'indices (canonical tie order)'
