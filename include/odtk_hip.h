@@ -177,6 +177,30 @@ int odtk_bias_act(void *y, const float *bias, const void *residual, size_t n_pix
                   int dtype, int relu, void *stream);
 
 /*
+ * odtk_gemm_bias_act -- 1x1 (pointwise) convolution of a channels_last activation as ONE GEMM with
+ * the whole epilogue fused:
+ *     y[p][o] = act( sum_c x[p][c] * w[o][c] + bias[o] (+ residual[p][o]) ),   act = ReLU if relu != 0
+ * x: device [m, k], w: device [n, k] (= the convolution weight [C_out, C_in, 1, 1]), y / residual:
+ * device [m, n], all of `dtype` (ODTK_BF16/F16/F32), row-major, 16-byte aligned; bias: DEVICE float32
+ * [n]; residual may be NULL and must not alias y.  The contraction runs on hipBLASLt (bound at run time,
+ * see odtk_gemm_init); the first call for a shape times the library's candidate kernels on `stream`
+ * (synchronises once), later calls only enqueue.  workspace: device scratch for the library (32 MiB is
+ * plenty), caller-owned like every other buffer of this ABI.
+ * Like odtk_bias_act it has no reference kernel equivalent: it replaces conv1x1 -> frozen BN ->
+ * (+ skip) -> ReLU of the reference's PyTorch graph (torchvision Bottleneck.forward,
+ * odtk/backbones/layers.py:5-16, odtk/backbones/fpn.py lateral convs) once BN is folded.
+ * Returns ODTK_ERR_UNSUPPORTED when hipBLASLt cannot be bound or has no kernel for the problem.
+ *
+ * odtk_gemm_init -- bind hipBLASLt from `path` (NULL: the already mapped / default libhipblaslt.so.1).
+ * Optional; odtk_gemm_bias_act binds the default on first use.  Inside a PyTorch process pass the
+ * copy PyTorch ships (torch/lib/libhipblaslt.so) so that only one copy of the soname is in use.
+ */
+int odtk_gemm_init(const char *hipblaslt_path);
+int odtk_gemm_bias_act(void *y, const void *x, const void *w, const float *bias, const void *residual,
+                       size_t m, int n, int k, int dtype, int relu,
+                       void *workspace, size_t workspace_size, void *stream);
+
+/*
  * odtk_snap_to_anchors -- fused training-target assignment for ONE pyramid level of the whole batch.
  * Replaces the reference's pure-torch snap_to_anchors (odtk/box.py:134-189, called per image and
  * level from odtk/model.py:167-184): IoU of every anchor against every ground-truth box (+1 pixel
@@ -204,7 +228,8 @@ int odtk_snap_to_anchors(int batch_size, const float *targets, int n_max, const 
 #define ODTK_KERNEL_IOU       3   /* iou_pairs_kernel                              */
 #define ODTK_KERNEL_EPILOGUE  4   /* bias_act_kernel                               */
 #define ODTK_KERNEL_TARGETS   5   /* snap_to_anchors_kernel                        */
-#define ODTK_KERNEL_COUNT     6
+#define ODTK_KERNEL_GEMM      6   /* hipBLASLt kernels behind odtk_gemm_bias_act    */
+#define ODTK_KERNEL_COUNT     7
 /* on: 0 = off, otherwise a bit mask of kernel ids (1 << ODTK_KERNEL_*), -1 = all.  An event pair
  * is a queue marker before and after the kernel: cheap for the 3 post-processing launches of a step,
  * measurably NOT free for the ~110 epilogue launches (about 10 % of an 8.7 ms step), so time those

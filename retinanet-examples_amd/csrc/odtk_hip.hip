@@ -21,6 +21,7 @@
 #include "prefilter.hpp"
 #include "select_decode.hpp"
 #include "targets.hpp"
+#include "gemm_lt.hpp"
 
 namespace {
 
@@ -474,6 +475,21 @@ int odtk_snap_to_anchors(int batch_size, const float *targets, int n_max, const 
   }
   ODTK_HIP_TRY(hipGetLastError());
   return ODTK_OK;
+}
+
+int odtk_gemm_init(const char *hipblaslt_path) { return odtk::lt::init(hipblaslt_path); }
+
+int odtk_gemm_bias_act(void *y, const void *x, const void *w, const float *bias, const void *residual, size_t m,
+                       int n, int k, int dtype, int relu, void *workspace, size_t workspace_size, void *stream) {
+  if (!y || !x || !w || !bias || n <= 0 || k <= 0 || residual == y) return ODTK_ERR_INVALID;
+  if (dtype != ODTK_F32 && dtype != ODTK_BF16 && dtype != ODTK_F16) return ODTK_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w) |
+       reinterpret_cast<uintptr_t>(residual) | reinterpret_cast<uintptr_t>(workspace)) & 15u)
+    return ODTK_ERR_INVALID;
+  if (m == 0) return ODTK_OK;
+  KernelTimer t(ODTK_KERNEL_GEMM, static_cast<hipStream_t>(stream));
+  return odtk::lt::gemm_bias_act(y, x, w, bias, residual, m, static_cast<uint32_t>(n), static_cast<uint32_t>(k), dtype,
+                                 relu, workspace, workspace_size, static_cast<hipStream_t>(stream));
 }
 
 int odtk_bias_act(void *y, const float *bias, const void *residual, size_t n_pixels, int channels, int dtype,

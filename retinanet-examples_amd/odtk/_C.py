@@ -65,11 +65,15 @@ _SIGNATURES = {
     'odtk_bias_act': (ctypes.c_int, [_vp, _vp, _vp, _sz, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp]),
     'odtk_profile_enable': (ctypes.c_int, [ctypes.c_int]),
     'odtk_debug_set_trace': (ctypes.c_int, [_vp]),
+    'odtk_gemm_init': (ctypes.c_int, [ctypes.c_char_p]),
+    'odtk_gemm_bias_act': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                          ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                          ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     'odtk_profile_collect': (ctypes.c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]),
 }
 
 KERNEL_NAMES = ('prefilter_scan_kernel', 'select_decode_kernel', 'nms_kernel', 'iou_pairs_kernel', 'bias_act_kernel',
-                'snap_to_anchors_kernel')
+                'snap_to_anchors_kernel', 'gemm_bias_act')
 
 _lib = None
 
@@ -348,6 +352,52 @@ def bias_act_(y, bias, residual=None, relu=True):
         stream = torch.cuda.current_stream(y.device).cuda_stream
         _check(library().odtk_bias_act(y.data_ptr(), bias.data_ptr(), residual.data_ptr() if residual is not None else None,
                                        n * h * w, c, _DTYPES[y.dtype], 1 if relu else 0, stream), 'bias_act')
+    return y
+
+
+_GEMM_WORKSPACE = {}
+_GEMM_READY = []
+
+
+def _gemm_setup(device):
+    """Bind hipBLASLt (the copy PyTorch ships, so that one copy of the soname serves the process) and
+    keep one 32 MiB scratch buffer per device."""
+    if not _GEMM_READY:
+        shipped = os.path.join(os.path.dirname(torch.__file__), 'lib', 'libhipblaslt.so')
+        path = shipped if os.path.exists(shipped) else None
+        _check(library().odtk_gemm_init(path.encode() if path else None), 'gemm_init')
+        _GEMM_READY.append(True)
+    if device not in _GEMM_WORKSPACE:
+        _GEMM_WORKSPACE[device] = torch.empty(32 << 20, dtype=torch.uint8, device=device)
+    return _GEMM_WORKSPACE[device]
+
+
+def gemm_bias_act(x, weight, bias, residual=None, relu=True):
+    """1x1 convolution of a channels_last activation as one hipBLASLt GEMM with bias (+ residual)
+    (+ ReLU) in its epilogue: returns act(conv1x1(x, weight) + bias (+ residual)), channels_last.
+    x [B, Cin, H, W] channels_last, weight [Cout, Cin] (or [Cout, Cin, 1, 1]), bias float32 [Cout]."""
+    if not x.is_cuda or x.dim() != 4 or x.dtype not in _DTYPES:
+        raise RuntimeError('gemm_bias_act: x must be a 4-d CUDA tensor of float32/bfloat16/float16')
+    b, k, h, w = x.shape
+    n = weight.shape[0]
+    if weight.numel() != n * k or weight.dtype != x.dtype or not weight.is_contiguous() and not weight.is_contiguous(
+            memory_format=torch.channels_last):
+        raise RuntimeError('gemm_bias_act: weight must be a dense [Cout, Cin(, 1, 1)] tensor of x.dtype')
+    if not (x.is_contiguous(memory_format=torch.channels_last) or h * w == 1):
+        raise RuntimeError('gemm_bias_act: x must be channels_last')
+    if bias.dtype != torch.float32 or bias.numel() != n or not bias.is_cuda:
+        raise RuntimeError('gemm_bias_act: bias must be a float32 CUDA vector of length Cout')
+    y = torch.empty((b, n, h, w), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    if residual is not None and (residual.shape != y.shape or residual.dtype != y.dtype or not (
+            residual.is_contiguous(memory_format=torch.channels_last) or h * w == 1)):
+        raise RuntimeError('gemm_bias_act: residual must match the output (shape, dtype, channels_last)')
+    with torch.cuda.device(x.device):
+        ws = _gemm_setup(x.device)
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        _check(library().odtk_gemm_bias_act(y.data_ptr(), x.data_ptr(), weight.data_ptr(), bias.data_ptr(),
+                                            residual.data_ptr() if residual is not None else None,
+                                            b * h * w, n, k, _DTYPES[x.dtype], 1 if relu else 0,
+                                            ws.data_ptr(), ws.numel(), stream), 'gemm_bias_act')
     return y
 
 

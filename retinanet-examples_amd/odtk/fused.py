@@ -11,6 +11,9 @@ Measured on MI355X those passes cost more than the convolutions between them.  H
   * weights are stored once in the inference dtype (bf16), channels_last;
   * ONE hand-written HIP epilogue (`odtk_bias_act`, csrc/epilogue.hpp) applies bias (+ skip) (+ ReLU)
     in place on the convolution output;
+  * 1x1 stride-1 convolutions (two of the three convs of every bottleneck, the FPN laterals) are a
+    plain GEMM on the channels_last activation: they run as ONE hipBLASLt call with bias, skip and ReLU
+    in the GEMM epilogue (`odtk_gemm_bias_act`, csrc/gemm_lt.hpp) -- no epilogue pass at all;
   * the post-processing reads the raw head tensors in place (odtk.box.detect(..., logits=True)).
 
 `FusedRetinaNet(model)` is a drop-in for `model.eval()` inference: same outputs up to the rounding of
@@ -46,8 +49,13 @@ class _Conv(nn.Module):
         self.register_buffer('weight', w.to(dtype).contiguous(memory_format=torch.channels_last))
         self.register_buffer('bias', b.contiguous())
         self.stride, self.padding, self.relu = conv.stride, conv.padding, relu
+        # pointwise: a GEMM over [N*H*W, Cin] with the whole epilogue fused (set False to A/B against MIOpen)
+        self.pointwise = (tuple(conv.kernel_size) == (1, 1) and tuple(conv.stride) == (1, 1)
+                          and tuple(conv.padding) == (0, 0) and conv.groups == 1 and tuple(conv.dilation) == (1, 1))
 
     def forward(self, x, residual=None):
+        if self.pointwise:
+            return _C.gemm_bias_act(x, self.weight, self.bias, residual, self.relu)
         y = F.conv2d(x, self.weight, None, self.stride, self.padding)
         if not y.is_contiguous(memory_format=torch.channels_last):
             y = y.contiguous(memory_format=torch.channels_last)
@@ -112,11 +120,15 @@ class FusedRetinaNet(nn.Module):
                 feats.append(x)
         c3, c4, c5 = feats
         p5 = self.lateral[2](c5)
-        p4 = self.lateral[1](c4, F.interpolate(p5, scale_factor=2))     # lateral + upsampled, one pass
-        p3 = self.lateral[0](c3, F.interpolate(p4, scale_factor=2))
+        p4 = self.lateral[1](c4, self._upsample(p5))                    # lateral + upsampled, one pass
+        p3 = self.lateral[0](c3, self._upsample(p4))
         p6 = self.pyramid6(c5)
         p7 = self.pyramid7(F.relu(p6))
         return [self.smooth[0](p3), self.smooth[1](p4), self.smooth[2](p5), p6, p7]
+
+    @staticmethod
+    def _upsample(t):
+        return F.interpolate(t, scale_factor=2).contiguous(memory_format=torch.channels_last)
 
     @staticmethod
     def _run(seq, t):

@@ -120,3 +120,30 @@ def test_model_fused_equals_reference_sequence():
     assert int((fused[0] > 0).sum()) > 50
     for f, p in zip(fused, plain):
         assert torch.equal(f, p)
+
+
+@pytest.mark.parametrize('shape', [(2, 64, 256, 40, 56), (3, 256, 64, 20, 28), (1, 512, 2048, 7, 10), (2, 40, 24, 5, 3)])
+@pytest.mark.parametrize('with_residual', [False, True])
+@pytest.mark.parametrize('relu', [False, True])
+def test_gemm_bias_act_matches_conv1x1(shape, with_residual, relu):
+    """odtk_gemm_bias_act == conv1x1 + bias (+ residual) (+ ReLU) computed in float32 from the same bf16
+    inputs, to bf16 rounding of the result (the GEMM accumulates in fp32 and rounds once)."""
+    import torch.nn.functional as F
+    b, ci, co, h, w = shape
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(b, ci, h, w, generator=g).bfloat16().cuda().contiguous(memory_format=torch.channels_last)
+    wt = (torch.randn(co, ci, 1, 1, generator=g) * ci ** -0.5).bfloat16().cuda().contiguous(memory_format=torch.channels_last)
+    bias = torch.randn(co, generator=g).cuda()
+    res = torch.randn(b, co, h, w, generator=g).bfloat16().cuda().contiguous(memory_format=torch.channels_last)
+    y = _C.gemm_bias_act(x, wt, bias, res if with_residual else None, relu)
+    assert y.shape == (b, co, h, w) and y.is_contiguous(memory_format=torch.channels_last) and y.dtype == torch.bfloat16
+    ref = F.conv2d(x.float(), wt.float()) + bias.view(1, -1, 1, 1)
+    if with_residual:
+        ref = ref + res.float()
+    if relu:
+        ref = ref.relu()
+    err = (y.float() - ref).abs()
+    tol = 2.0 ** -8 * ref.abs() + 1e-2          # one bf16 rounding + fp32 accumulation order
+    assert (err <= tol).all(), float((err - tol).max())
+    # second call (plan cache hit) is bit-identical
+    assert torch.equal(y, _C.gemm_bias_act(x, wt, bias, res if with_residual else None, relu))
