@@ -156,12 +156,12 @@ def main():
     _C.profile_enable(False)
     prof = _C.profile_collect()
     if rank == 0:
-        _C.profile_enable(True, ('bias_act_kernel',))
+        _C.profile_enable(True, ('bias_act_kernel', 'gemm_bias_act'))
         for _ in range(3):
             step()
         torch.cuda.synchronize()
         _C.profile_enable(False)
-        prof.update({k: v for k, v in _C.profile_collect().items() if k == 'bias_act_kernel'})
+        prof.update({k: v for k, v in _C.profile_collect().items() if k in ('bias_act_kernel', 'gemm_bias_act')})
 
     images = args.batch * world * args.steps
     value = images / elapsed

@@ -177,6 +177,17 @@ int odtk_bias_act(void *y, const float *bias, const void *residual, size_t n_pix
                   int dtype, int relu, void *stream);
 
 /*
+ * odtk_bias_act_maxpool -- stem epilogue: out = maxpool3x3/s2/p1( act( y + bias[c] ) ) in one pass over a
+ * channels_last activation (ResNet conv1 -> bn1 -> relu -> maxpool, reference odtk/backbones/resnet.py
+ * via torchvision's ResNet.forward).  y: device [batch, height, width, channels], out: device
+ * [batch, (height+1)/2, (width+1)/2, channels], both ODTK_BF16 or ODTK_F16, 16-byte aligned,
+ * channels % 8 == 0; bias: DEVICE float32 [channels].  Bit-identical to odtk_bias_act followed by
+ * torch's max_pool2d (the epilogue is monotone, so it commutes with the maximum).
+ */
+int odtk_bias_act_maxpool(const void *y, const float *bias, void *out, int batch_size, int height, int width,
+                          int channels, int dtype, int relu, void *stream);
+
+/*
  * odtk_gemm_bias_act -- 1x1 (pointwise) convolution of a channels_last activation as ONE GEMM with
  * the whole epilogue fused:
  *     y[p][o] = act( sum_c x[p][c] * w[o][c] + bias[o] (+ residual[p][o]) ),   act = ReLU if relu != 0

@@ -102,4 +102,60 @@ __global__ void bias_act_scalar_kernel(void *y, const float *bias, const void *r
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Stem epilogue: bias + ReLU + 3x3 / stride 2 / pad 1 max-pool in ONE pass (ResNet conv1 -> bn1 -> relu
+// -> maxpool, reference odtk/backbones/resnet.py:24-39 via torchvision).  Bias-add, ReLU and the
+// rounding to the storage type are monotone, so  pool(round(relu(y + b))) == round(relu(pool(y) + b))
+// bit for bit: take the maximum of the RAW conv outputs, then apply the epilogue to one value instead
+// of nine.  Reads the full-resolution conv output once (neighbouring windows overlap in L2) and
+// writes the quarter-size result: the separate epilogue pass (read + write of the biggest activation
+// of the network, 262 MB at bs 8) disappears.
+// One thread = one output pixel x kPer channels (16 bytes); consecutive threads walk the channels of a
+// pixel, then x: every load and store is a coalesced 16-byte access.  Padding never wins (torch pads
+// with -inf).  16-bit types only (the inference dtypes); channels % 8 == 0.
+template <typename T, bool kRelu>
+__global__ __launch_bounds__(256) void bias_act_maxpool_kernel(const uint16_t *__restrict__ y, const float *__restrict__ bias,
+                                                               uint16_t *__restrict__ out, uint32_t batch, uint32_t h,
+                                                               uint32_t w, uint32_t c, uint32_t ho, uint32_t wo) {
+  constexpr int kPer = T::kPerLoad;                        // 8
+  const uint32_t groups = c / kPer;
+  const uint64_t total = static_cast<uint64_t>(batch) * ho * wo * groups;
+  for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < total; i += static_cast<uint64_t>(gridDim.x) * 256ull) {
+    const uint32_t g = static_cast<uint32_t>(i % groups);
+    uint64_t p = i / groups;
+    const uint32_t ox = static_cast<uint32_t>(p % wo);
+    p /= wo;
+    const uint32_t oy = static_cast<uint32_t>(p % ho), b = static_cast<uint32_t>(p / ho);
+    float m[kPer];
+#pragma unroll
+    for (int e = 0; e < kPer; ++e) m[e] = -__builtin_inff();
+    const int y0 = static_cast<int>(oy) * 2 - 1, x0 = static_cast<int>(ox) * 2 - 1;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      const int yy = y0 + dy;
+      if (yy < 0 || yy >= static_cast<int>(h)) continue;
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const int xx = x0 + dx;
+        if (xx < 0 || xx >= static_cast<int>(w)) continue;
+        const vuint4 v = *reinterpret_cast<const vuint4 *>(y + ((static_cast<uint64_t>(b) * h + yy) * w + xx) * c + g * kPer);
+#pragma unroll
+        for (int e = 0; e < kPer; ++e) {
+          const uint32_t hx = (v[e >> 1] >> (16 * (e & 1))) & 0xffffu;
+          const float f = std::is_same_v<T, BF16> ? bf16_bits_to_float(hx) : f16_bits_to_float(hx);
+          m[e] = (f > m[e] || f != f) ? f : m[e];            // NaN propagates, as torch's max_pool2d
+        }
+      }
+    }
+    vuint4 o;
+#pragma unroll
+    for (int e = 0; e < kPer; e += 2) {
+      float a0 = m[e] + bias[g * kPer + e], a1 = m[e + 1] + bias[g * kPer + e + 1];
+      if (kRelu) { a0 = a0 > 0.0f ? a0 : (a0 != a0 ? a0 : 0.0f); a1 = a1 > 0.0f ? a1 : (a1 != a1 ? a1 : 0.0f); }
+      o[e >> 1] = float_to_storage<T>(a0) | (float_to_storage<T>(a1) << 16);
+    }
+    *reinterpret_cast<vuint4 *>(out + ((static_cast<uint64_t>(b) * ho + oy) * wo + ox) * c + g * kPer) = o;
+  }
+}
+
 }  // namespace odtk

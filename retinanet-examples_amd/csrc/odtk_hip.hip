@@ -477,6 +477,31 @@ int odtk_snap_to_anchors(int batch_size, const float *targets, int n_max, const 
   return ODTK_OK;
 }
 
+int odtk_bias_act_maxpool(const void *y, const float *bias, void *out, int batch_size, int height, int width,
+                          int channels, int dtype, int relu, void *stream) {
+  if (!y || !bias || !out || batch_size <= 0 || height <= 0 || width <= 0 || channels <= 0) return ODTK_ERR_INVALID;
+  if (dtype != ODTK_BF16 && dtype != ODTK_F16) return ODTK_ERR_UNSUPPORTED;
+  if (channels % 8 != 0) return ODTK_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(out)) & 15u) return ODTK_ERR_INVALID;
+  const uint32_t ho = (static_cast<uint32_t>(height) + 1) / 2, wo = (static_cast<uint32_t>(width) + 1) / 2;
+  const uint64_t work = static_cast<uint64_t>(batch_size) * ho * wo * (channels / 8);
+  uint64_t blocks = (work + 255) / 256;
+  if (blocks > 256 * 32) blocks = 256 * 32;                              // grid-stride beyond 32 workgroups per CU
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  KernelTimer t(ODTK_KERNEL_EPILOGUE, s);
+  const uint16_t *in = static_cast<const uint16_t *>(y);
+  uint16_t *o = static_cast<uint16_t *>(out);
+#define ODTK_POOL(T, R)                                                                                               \
+  hipLaunchKernelGGL((odtk::bias_act_maxpool_kernel<T, R>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, in, \
+                     bias, o, static_cast<uint32_t>(batch_size), static_cast<uint32_t>(height),                       \
+                     static_cast<uint32_t>(width), static_cast<uint32_t>(channels), ho, wo)
+  if (dtype == ODTK_BF16) { if (relu) ODTK_POOL(odtk::BF16, true); else ODTK_POOL(odtk::BF16, false); }
+  else { if (relu) ODTK_POOL(odtk::F16, true); else ODTK_POOL(odtk::F16, false); }
+#undef ODTK_POOL
+  ODTK_HIP_TRY(hipGetLastError());
+  return ODTK_OK;
+}
+
 int odtk_gemm_init(const char *hipblaslt_path) { return odtk::lt::init(hipblaslt_path); }
 
 int odtk_gemm_bias_act(void *y, const void *x, const void *w, const float *bias, const void *residual, size_t m,

@@ -65,6 +65,8 @@ _SIGNATURES = {
     'odtk_bias_act': (ctypes.c_int, [_vp, _vp, _vp, _sz, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp]),
     'odtk_profile_enable': (ctypes.c_int, [ctypes.c_int]),
     'odtk_debug_set_trace': (ctypes.c_int, [_vp]),
+    'odtk_bias_act_maxpool': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                                             ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     'odtk_gemm_init': (ctypes.c_int, [ctypes.c_char_p]),
     'odtk_gemm_bias_act': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                           ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
@@ -353,6 +355,24 @@ def bias_act_(y, bias, residual=None, relu=True):
         _check(library().odtk_bias_act(y.data_ptr(), bias.data_ptr(), residual.data_ptr() if residual is not None else None,
                                        n * h * w, c, _DTYPES[y.dtype], 1 if relu else 0, stream), 'bias_act')
     return y
+
+
+def bias_act_maxpool(y, bias, relu=True):
+    """maxpool3x3/s2/p1(act(y + bias[c])) of a channels_last bf16/fp16 activation in one pass (the ResNet
+    stem after conv1); bit-identical to bias_act_ followed by F.max_pool2d(., 3, 2, 1)."""
+    if not y.is_cuda or y.dim() != 4 or y.dtype not in (torch.bfloat16, torch.float16):
+        raise RuntimeError('bias_act_maxpool: y must be a 4-d CUDA tensor of bfloat16/float16')
+    n, c, h, w = y.shape
+    if not y.is_contiguous(memory_format=torch.channels_last) or c % 8:
+        raise RuntimeError('bias_act_maxpool: y must be channels_last with channels % 8 == 0')
+    if bias.dtype != torch.float32 or bias.numel() != c or not bias.is_cuda:
+        raise RuntimeError('bias_act_maxpool: bias must be a float32 CUDA vector of length C')
+    out = torch.empty((n, c, (h + 1) // 2, (w + 1) // 2), dtype=y.dtype, device=y.device, memory_format=torch.channels_last)
+    with torch.cuda.device(y.device):
+        stream = torch.cuda.current_stream(y.device).cuda_stream
+        _check(library().odtk_bias_act_maxpool(y.data_ptr(), bias.data_ptr(), out.data_ptr(), n, h, w, c, _DTYPES[y.dtype],
+                                               1 if relu else 0, stream), 'bias_act_maxpool')
+    return out
 
 
 _GEMM_WORKSPACE = {}

@@ -50,16 +50,27 @@ class _Conv(nn.Module):
         self.register_buffer('bias', b.contiguous())
         self.stride, self.padding, self.relu = conv.stride, conv.padding, relu
         # pointwise: a GEMM over [N*H*W, Cin] with the whole epilogue fused (set False to A/B against MIOpen)
-        self.pointwise = (tuple(conv.kernel_size) == (1, 1) and tuple(conv.stride) == (1, 1)
-                          and tuple(conv.padding) == (0, 0) and conv.groups == 1 and tuple(conv.dilation) == (1, 1))
+        # (a strided 1x1 convolution -- the downsample branch -- is the same GEMM on the subsampled pixels)
+        self.pointwise = (tuple(conv.kernel_size) == (1, 1) and tuple(conv.padding) == (0, 0) and conv.groups == 1
+                          and tuple(conv.dilation) == (1, 1))
 
     def forward(self, x, residual=None):
         if self.pointwise:
+            if tuple(self.stride) != (1, 1):
+                x = x[:, :, ::self.stride[0], ::self.stride[1]].contiguous(memory_format=torch.channels_last)
             return _C.gemm_bias_act(x, self.weight, self.bias, residual, self.relu)
         y = F.conv2d(x, self.weight, None, self.stride, self.padding)
         if not y.is_contiguous(memory_format=torch.channels_last):
             y = y.contiguous(memory_format=torch.channels_last)
         return _C.bias_act_(y, self.bias, residual, self.relu)
+
+
+    def conv_then_pool(self, x):
+        """conv -> bias -> ReLU -> maxpool 3x3/s2 with the epilogue folded into the pooling pass."""
+        y = F.conv2d(x, self.weight, None, self.stride, self.padding)
+        if y.dtype in (torch.bfloat16, torch.float16) and y.shape[1] % 8 == 0:
+            return _C.bias_act_maxpool(y.contiguous(memory_format=torch.channels_last), self.bias, self.relu)
+        return F.max_pool2d(_C.bias_act_(y.contiguous(memory_format=torch.channels_last), self.bias, None, self.relu), 3, 2, 1)
 
 
 class _Block(nn.Module):
@@ -111,7 +122,7 @@ class FusedRetinaNet(nn.Module):
         self.box_head = head(model.box_head)
 
     def features(self, x):
-        x = F.max_pool2d(self.stem(x), 3, 2, 1)
+        x = self.stem.conv_then_pool(x)                                  # conv1 -> (bias + ReLU + maxpool, one pass)
         feats = []
         for level, layer in enumerate(self.layers, start=2):
             for block in layer:

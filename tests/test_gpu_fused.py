@@ -147,3 +147,20 @@ def test_gemm_bias_act_matches_conv1x1(shape, with_residual, relu):
     assert (err <= tol).all(), float((err - tol).max())
     # second call (plan cache hit) is bit-identical
     assert torch.equal(y, _C.gemm_bias_act(x, wt, bias, res if with_residual else None, relu))
+
+
+@pytest.mark.parametrize('shape', [(2, 64, 50, 70), (1, 8, 7, 9), (3, 32, 16, 16), (1, 16, 1, 1)])
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+def test_bias_act_maxpool_is_epilogue_then_pool(shape, dtype):
+    """The stem's fused bias + ReLU + 3x3/s2 max-pool equals bias_act_ followed by torch's max_pool2d
+    bit for bit (monotone epilogue commutes with the maximum), odd sizes and borders included."""
+    import torch.nn.functional as F
+    b, c, h, w = shape
+    g = torch.Generator().manual_seed(9)
+    y = torch.randn(b, c, h, w, generator=g).to(dtype).cuda().contiguous(memory_format=torch.channels_last)
+    bias = torch.randn(c, generator=g).cuda()
+    for relu in (True, False):
+        got = _C.bias_act_maxpool(y, bias, relu)
+        ref = F.max_pool2d(_C.bias_act_(y.clone(memory_format=torch.channels_last), bias, None, relu), 3, 2, 1)
+        assert got.shape == ref.shape and got.is_contiguous(memory_format=torch.channels_last)
+        assert torch.equal(got, ref)
