@@ -68,12 +68,18 @@ def shard_batch(global_batch, rank, world):
     return per, range(rank * per, (rank + 1) * per)
 
 
+def is_master():
+    return not (dist.is_available() and dist.is_initialized()) or dist.get_rank() == 0
+
+
 def pack_detections(scores, boxes, classes, ids, ratios):
     """[N, D], [N, D, nb], [N, D], [N], [N] -> one [N, D*(nb+2) + 2] float32 tensor, so the final
-    hand-off is ONE all_gather instead of the reference's five (infer.py:98-102)."""
+    hand-off is ONE all_gather instead of the reference's five (infer.py:98-102).  The image id rides as
+    the BIT PATTERN of an int32 (ids above 2^24 would not survive a float conversion)."""
     n, d = scores.shape
+    id_bits = ids.reshape(n, 1).to(torch.int32).view(torch.float32)
     return torch.cat([scores.reshape(n, -1), boxes.reshape(n, -1), classes.reshape(n, -1),
-                      ids.reshape(n, 1).to(scores.dtype), ratios.reshape(n, 1).to(scores.dtype)], 1)
+                      id_bits.to(scores.device), ratios.reshape(n, 1).to(scores.dtype)], 1)
 
 
 def unpack_detections(packed, detections, nb=4):
@@ -82,17 +88,25 @@ def unpack_detections(packed, detections, nb=4):
     scores = packed[:, :d]
     boxes = packed[:, d:d + d * nb].reshape(n, d, nb)
     classes = packed[:, d + d * nb:d + d * nb + d]
-    ids = packed[:, -2].round().long()
+    ids = packed[:, -2].contiguous().view(torch.int32).long()
     ratios = packed[:, -1]
     return scores, boxes, classes, ids, ratios
 
 
-def gather_detections(scores, boxes, classes, ids, ratios):
-    """All ranks' detections on every rank, rank-major (equal per-rank counts, as DistributedSampler
-    guarantees).  world == 1: returns the inputs."""
+def gather_packed(packed):
+    """Rank-major concatenation of every rank's packed rows (equal per-rank counts, as DistributedSampler
+    guarantees): ONE all_gather.  world == 1: the input."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-        return scores, boxes, classes, ids, ratios
-    packed = pack_detections(scores, boxes, classes, ids, ratios).contiguous()
+        return packed
+    packed = packed.contiguous()
     out = [torch.empty_like(packed) for _ in range(dist.get_world_size())]
     dist.all_gather(out, packed)
-    return unpack_detections(torch.cat(out, 0), scores.shape[1], boxes.shape[-1])
+    return torch.cat(out, 0)
+
+
+def gather_detections(scores, boxes, classes, ids, ratios):
+    """All ranks' detections on every rank, rank-major.  world == 1: returns the inputs."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return scores, boxes, classes, ids, ratios
+    packed = gather_packed(pack_detections(scores, boxes, classes, ids, ratios))
+    return unpack_detections(packed, scores.shape[1], boxes.shape[-1])
