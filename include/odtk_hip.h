@@ -127,6 +127,14 @@ typedef struct odtk_level {
   int32_t stride;           /* pixels per cell (the reference's `scale`)                     */
   int32_t channels_last;    /* 0: NCHW-contiguous, 1: NHWC-contiguous (torch.channels_last)  */
   const float *anchors;     /* HOST float[4*A]                                               */
+  /* Optional per-channel bias of the heads' last convolutions, folded into the kernels so that the
+   * caller can skip its bias pass over the largest activation of the network (both may be NULL):
+   *   cls_bias  DEVICE float32 [A*C]: logit = float(cls) + cls_bias[channel] in fp32, then the sigmoid.
+   *             Needs ODTK_FLAG_LOGITS, a 16-bit dtype, channels_last = 1 and A*C a multiple of 8;
+   *             otherwise ODTK_ERR_UNSUPPORTED.
+   *   box_bias  DEVICE float32 [A*nb]: delta = float(box) + box_bias[a*nb + k] in fp32. */
+  const float *cls_bias;
+  const float *box_bias;
 } odtk_level_t;
 
 /*

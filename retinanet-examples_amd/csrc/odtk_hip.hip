@@ -127,11 +127,11 @@ float logit_lower_bound(float thresh) {
 }
 
 template <typename T, bool kLogits>
-int launch_decode(bool rotated, uint32_t tiles, int n_seg, const odtk::ScanArgs &sa, const odtk::DecodeArgs &da,
-                  hipStream_t stream) {
+int launch_decode(bool rotated, uint32_t tiles, int n_seg, size_t scan_lds, const odtk::ScanArgs &sa,
+                  const odtk::DecodeArgs &da, hipStream_t stream) {
   {
     KernelTimer t(ODTK_KERNEL_PREFILTER, stream);
-    hipLaunchKernelGGL((odtk::prefilter_scan_kernel<T, kLogits>), dim3(tiles), dim3(odtk::kScanThreads), 0, stream, sa);
+    hipLaunchKernelGGL((odtk::prefilter_scan_kernel<T, kLogits>), dim3(tiles), dim3(odtk::kScanThreads), scan_lds, stream, sa);
   }
   ODTK_HIP_TRY(hipGetLastError());
   {
@@ -153,8 +153,16 @@ int decode_levels_impl(int batch, int n_levels, const odtk_level_t *levels, int 
   for (int l = 0; l < n_levels; ++l)
     if (levels[l].height <= 0 || levels[l].width <= 0) return ODTK_ERR_INVALID;
   if (dtype != ODTK_F32 && dtype != ODTK_BF16 && dtype != ODTK_F16) return ODTK_ERR_UNSUPPORTED;
-  for (int l = 0; l < n_levels; ++l)
+  size_t scan_lds = 0;                                     // per-channel threshold table of the prefilter
+  for (int l = 0; l < n_levels; ++l) {
     if (levels[l].channels_last != 0 && levels[l].channels_last != 1) return ODTK_ERR_INVALID;
+    if (levels[l].cls_bias) {
+      if (dtype == ODTK_F32 || !(flags & ODTK_FLAG_LOGITS) || !levels[l].channels_last || (A * C) % 8 != 0)
+        return ODTK_ERR_UNSUPPORTED;
+      scan_lds = align_up(static_cast<size_t>(A) * C * 2);
+      if (scan_lds > 48 * 1024) return ODTK_ERR_UNSUPPORTED;
+    }
+  }
 
   DecodeLayout lay;
   int rc = decode_layout(batch, n_levels, levels, A, C, &lay);
@@ -193,6 +201,7 @@ int decode_levels_impl(int batch, int n_levels, const odtk_level_t *levels, int 
     sa.lv[l].channels = static_cast<uint32_t>(A) * C;
     sa.lv[l].hw = static_cast<uint32_t>(levels[l].height) * levels[l].width;
     sa.lv[l].channels_last = static_cast<uint32_t>(levels[l].channels_last);
+    sa.lv[l].bias = levels[l].cls_bias;
     sa.lv[l].tiles = static_cast<uint32_t>((total + odtk::kTile - 1) / odtk::kTile);
     sa.lv[l].chunk = (sa.lv[l].tiles + batch - 1) / batch;
     sa.lv[l].chunk = (sa.lv[l].chunk + span - 1) / span * span;
@@ -207,6 +216,8 @@ int decode_levels_impl(int batch, int n_levels, const odtk_level_t *levels, int 
     da.lv[l].width = levels[l].width;
     da.lv[l].stride = static_cast<float>(levels[l].stride);
     da.lv[l].channels_last = static_cast<uint32_t>(levels[l].channels_last);
+    da.lv[l].cls_bias = levels[l].cls_bias;
+    da.lv[l].box_bias = levels[l].box_bias;
     std::memcpy(da.lv[l].anchors, levels[l].anchors, sizeof(float) * 4 * A);
   }
   sa.counts = counts;
@@ -234,13 +245,13 @@ int decode_levels_impl(int batch, int n_levels, const odtk_level_t *levels, int 
   ODTK_HIP_TRY(hipMemsetAsync(counts, 0, sizeof(uint32_t) * n_seg * odtk::kSubLists, stream));
   const bool rotated = (flags & ODTK_FLAG_ROTATED) != 0, logits = (flags & ODTK_FLAG_LOGITS) != 0;
   if (dtype == ODTK_F32)
-    return logits ? launch_decode<odtk::F32, true>(rotated, tiles, n_seg, sa, da, stream)
-                  : launch_decode<odtk::F32, false>(rotated, tiles, n_seg, sa, da, stream);
+    return logits ? launch_decode<odtk::F32, true>(rotated, tiles, n_seg, scan_lds, sa, da, stream)
+                  : launch_decode<odtk::F32, false>(rotated, tiles, n_seg, scan_lds, sa, da, stream);
   if (dtype == ODTK_BF16)
-    return logits ? launch_decode<odtk::BF16, true>(rotated, tiles, n_seg, sa, da, stream)
-                  : launch_decode<odtk::BF16, false>(rotated, tiles, n_seg, sa, da, stream);
-  return logits ? launch_decode<odtk::F16, true>(rotated, tiles, n_seg, sa, da, stream)
-                : launch_decode<odtk::F16, false>(rotated, tiles, n_seg, sa, da, stream);
+    return logits ? launch_decode<odtk::BF16, true>(rotated, tiles, n_seg, scan_lds, sa, da, stream)
+                  : launch_decode<odtk::BF16, false>(rotated, tiles, n_seg, scan_lds, sa, da, stream);
+  return logits ? launch_decode<odtk::F16, true>(rotated, tiles, n_seg, scan_lds, sa, da, stream)
+                : launch_decode<odtk::F16, false>(rotated, tiles, n_seg, scan_lds, sa, da, stream);
 }
 
 template <int NB>

@@ -59,6 +59,7 @@ struct ScanLevel {
   uint32_t tiles;        // tiles in this level = ceil(total / kTile)
   uint32_t chunk;        // tiles per interleave chunk = ceil(tiles / batch), a multiple of the span
   uint32_t pad_;
+  const float *bias;     // kLogits + channels_last only: per-channel bias of the head's last conv (null: none)
 };
 
 struct ScanArgs {
@@ -127,6 +128,34 @@ __device__ __forceinline__ uint32_t memory_offset(uint32_t i, uint32_t channels,
   return pix * channels + ch;
 }
 
+// Per-channel raw-domain threshold in the tensor's own storage type, rounded TOWARDS -inf so that the
+// stored value never exceeds the float threshold (the prefilter may only over-select).
+template <typename T>
+__device__ __forceinline__ typename T::storage threshold_to_storage(float t) {
+  if constexpr (std::is_same_v<T, F32>) {
+    return t;
+  } else if constexpr (std::is_same_v<T, BF16>) {
+    const uint32_t b = __float_as_uint(t);
+    uint32_t h = b >> 16;                                  // truncation: towards zero
+    if ((b & 0xffffu) && (b >> 31) && t == t) h += 1;      // negative with dropped bits: one step further down
+    return static_cast<uint16_t>(h);
+  } else {
+    _Float16 h = static_cast<_Float16>(t);                 // nearest
+    uint16_t bits = __builtin_bit_cast(uint16_t, h);
+    if (static_cast<float>(h) > t) {                       // landed above: one representable step down
+      if (bits == 0x0000u || bits == 0x8000u) bits = 0x8001u;
+      else bits = (bits & 0x8000u) ? bits + 1 : bits - 1;
+    }
+    return bits;
+  }
+}
+template <typename T>
+__device__ __forceinline__ float storage_to_float(typename T::storage v) {
+  if constexpr (std::is_same_v<T, F32>) return v;
+  else if constexpr (std::is_same_v<T, BF16>) return bf16_bits_to_float(v);
+  else return f16_bits_to_float(v);
+}
+
 // launch bounds: >= 8 waves/SIMD for the 16-bit forms (64 VGPRs, no spill), >= 6 for fp32 (80 VGPRs):
 // more workgroups in their load phase while others drain (measured bf16 52.6 -> 48.4 us)
 template <typename T, bool kLogits>
@@ -136,6 +165,9 @@ __global__ __launch_bounds__(kScanThreads, (sizeof(typename T::storage) == 2 ? 8
   __shared__ uint64_t s_stage[kStageCap];
   __shared__ uint32_t s_cnt;                               // raw hits staged this round
   __shared__ uint32_t s_ok;                                // of which pass the exact test
+  // head bias folded in (ScanLevel::bias): per-channel raw-domain thresholds, A*C entries of T::storage
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
+  typename T::storage *s_thr = reinterpret_cast<typename T::storage *>(s_dyn);
 
   const int tid = threadIdx.x;
   const int lane = tid & (kWave - 1);
@@ -164,6 +196,22 @@ __global__ __launch_bounds__(kScanThreads, (sizeof(typename T::storage) == 2 ? 8
   const uint32_t span_vec = span_len / kPer;               // whole 16-byte groups in this span
 
   if (tid == 0) { s_cnt = 0; s_ok = 0; }
+  // With a bias the logit of element r is raw[r] + bias[r % channels] (channels_last, channels % kPer
+  // == 0, checked by the host): "logit >= raw_lo" becomes "raw >= raw_lo - bias[c]" -- still ONE compare
+  // per element, against a per-channel threshold that a lane fetches with one 16-byte LDS read per load.
+  // (16-bit dtypes only -- the fp32 form has no registers to spare; the host rejects the combination)
+  const float *bias = (kLogits && !std::is_same_v<T, F32>) ? L.bias : nullptr;   // block-uniform
+  if (bias) {
+    // (built before the tile's loads are issued: moving it behind them costs registers -- 44 B of scratch
+    // and 49 -> 68 us on the common path, measured)
+    for (uint32_t c = tid; c < L.channels; c += kScanThreads) {
+      const float b = bias[c];
+      s_thr[c] = threshold_to_storage<T>(raw_thr - b - (1e-3f + 1e-6f * fabsf(b)));   // margin >> fp32 rounding of raw + b
+    }
+  }
+  auto logit_of = [&](float raw, uint64_t offset_in_level) -> float {   // exact-test input
+    return bias ? raw + bias[static_cast<uint32_t>(offset_in_level % L.channels)] : raw;
+  };
 
   // Every span appends to ONE of the segment's kSubLists sub-lists: ~15 k workgroups per launch all
   // want a slot reservation, so the returning atomics are spread over 16x more counter words
@@ -201,7 +249,7 @@ __global__ __launch_bounds__(kScanThreads, (sizeof(typename T::storage) == 2 ? 8
       else v[u] = std::is_same_v<T, F32> ? vuint4{0x7fc00000u, 0x7fc00000u, 0x7fc00000u, 0x7fc00000u}
                                          : vuint4{0x7fc07fc0u, 0x7fc07fc0u, 0x7fc07fc0u, 0x7fc07fc0u};   // NaNs
     }
-    if (t == 0) __syncthreads();                           // s_cnt = 0 visible; overlaps the load latency
+    if (t == 0) __syncthreads();                           // s_cnt = 0 (and the threshold table) visible; overlaps the load latency
 
     // element e of load u  <->  tile element kPer*(u*256+tid)+e
     auto raw_at = [&](int u, int e) -> float {
@@ -215,12 +263,33 @@ __global__ __launch_bounds__(kScanThreads, (sizeof(typename T::storage) == 2 ? 8
     };
     // hit mask over the lane's 64 elements: bit (kPer*u + e); one compare each, NaN fails >=
     uint64_t mask = 0;
+    if (!bias) {
 #pragma unroll
-    for (int u = 0; u < kVec; ++u) {
-      uint32_t m = 0;
+      for (int u = 0; u < kVec; ++u) {
+        uint32_t m = 0;
 #pragma unroll
-      for (int e = 0; e < kPer; ++e) m |= (raw_at(u, e) >= raw_thr ? 1u : 0u) << e;
-      mask |= static_cast<uint64_t>(m) << (kPer * u);
+        for (int e = 0; e < kPer; ++e) m |= (raw_at(u, e) >= raw_thr ? 1u : 0u) << e;
+        mask |= static_cast<uint64_t>(m) << (kPer * u);
+      }
+    } else {
+      // channel group (kPer consecutive channels) of the lane's load u: (first group of the tile + u*256 + tid) mod G
+      const uint32_t G = L.channels / kPer, step = kScanThreads % G;
+      uint32_t g = static_cast<uint32_t>((span_base / kPer + vec0 + tid) % G);
+#pragma unroll
+      for (int u = 0; u < kVec; ++u) {
+        const vuint4 tv = *reinterpret_cast<const vuint4 *>(s_dyn + static_cast<size_t>(g) * 16);
+        uint32_t m = 0;
+#pragma unroll
+        for (int e = 0; e < kPer; ++e) {
+          float te;
+          if constexpr (std::is_same_v<T, F32>) te = __uint_as_float(tv[e]);
+          else te = storage_to_float<T>(static_cast<uint16_t>((tv[e >> 1] >> (16 * (e & 1))) & 0xffffu));
+          m |= (raw_at(u, e) >= te ? 1u : 0u) << e;
+        }
+        mask |= static_cast<uint64_t>(m) << (kPer * u);
+        g += step;
+        if (g >= G) g -= G;
+      }
     }
     const uint32_t cnt = __popcll(mask);
     if (cnt) {
@@ -268,7 +337,8 @@ __global__ __launch_bounds__(kScanThreads, (sizeof(typename T::storage) == 2 ? 8
     uint32_t ok_here = 0;
     for (uint32_t i = tid; i < cnt_staged; i += kScanThreads) {        // exact test, one call site
       const uint64_t ent = s_stage[i];
-      const float s = score_of<T, kLogits>(bits_to_raw(static_cast<uint32_t>(ent >> 32)));
+      const float s = score_of<T, kLogits>(logit_of(bits_to_raw(static_cast<uint32_t>(ent >> 32)),
+                                                    span_base + static_cast<uint32_t>(ent)));
       uint64_t key = 0;
       if (!kLogits || s >= thr) {
         const uint32_t rr = r0 + static_cast<uint32_t>(ent);            // offset from image b0's start
@@ -327,7 +397,8 @@ __global__ __launch_bounds__(kScanThreads, (sizeof(typename T::storage) == 2 ? 8
         const uint32_t e = c0 + k * kScanThreads + tid;
         if (e < span_vec * kPer) {
           const float raw = load_raw<T>(span_ptr, e);
-          if (raw >= raw_thr) {
+          const float t_e = bias ? storage_to_float<T>(s_thr[static_cast<uint32_t>((span_base + e) % L.channels)]) : raw_thr;
+          if (raw >= t_e) {
             uint32_t bits;
             if constexpr (std::is_same_v<T, F32>) bits = __float_as_uint(raw);
             else bits = static_cast<const uint16_t *>(static_cast<const void *>(span_ptr))[e];
@@ -344,7 +415,7 @@ __global__ __launch_bounds__(kScanThreads, (sizeof(typename T::storage) == 2 ? 8
   const uint32_t tail = span_len - span_vec * kPer;
   if (tail && static_cast<uint32_t>(tid) < tail) {
     const uint32_t toff = span_vec * kPer + tid;
-    const float s = score_of<T, kLogits>(load_raw<T>(span_ptr, toff));
+    const float s = score_of<T, kLogits>(logit_of(load_raw<T>(span_ptr, toff), span_base + toff));
     if (s >= thr) {
       const uint64_t r = static_cast<uint64_t>(r0) + toff;
       const uint32_t b = b0 + static_cast<uint32_t>(r / n);

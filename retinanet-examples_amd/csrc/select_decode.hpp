@@ -39,6 +39,8 @@ struct DecodeLevel {
   int32_t height, width;
   float stride;
   uint32_t channels_last;
+  const float *cls_bias; // [A*C] added to the cls head values (logits) before the sigmoid, or null
+  const float *box_bias; // [A*NB] added to the gathered deltas, or null
   float anchors[ODTK_MAX_ANCHORS * 4];
 };
 
@@ -114,10 +116,13 @@ struct RawSource {    // the segment's raw head values (overflow path); walks me
   const void *image;  // first element of this image
   uint32_t n, channels, hw, channels_last;
   float thresh;
+  const float *bias;  // per-channel head bias (logits only) or null
   template <typename F>
   __device__ __forceinline__ void for_each(F &&f) const {
     for (uint32_t r = threadIdx.x; r < n; r += kSelThreads) {
-      const float s = score_of<T, kLogits>(load_raw<T>(image, r));
+      float raw = load_raw<T>(image, r);
+      if (kLogits && bias) raw += bias[channels_last ? r % channels : (r / hw) % channels];
+      const float s = score_of<T, kLogits>(raw);
       if (s >= thresh) {
         uint32_t i = r;
         if (channels_last) { const uint32_t pix = r / channels, ch = r - pix * channels; i = ch * hw + pix; }
@@ -307,7 +312,7 @@ __global__ __launch_bounds__(kSelThreads) void select_decode_kernel(const Decode
     lists.for_each([&](uint64_t key) { s_keys[atomicAdd(&s_misc[20], 1u)] = key; });   // order is irrelevant
     n_sort = count;
   } else {
-    const RawSource<T, kLogits> raw{cls_image, L.n, channels, hw, L.channels_last, a.thresh};
+    const RawSource<T, kLogits> raw{cls_image, L.n, channels, hw, L.channels_last, a.thresh, L.cls_bias};
     uint64_t T64 = 0;
     n_sort = count;                // count <= top_n: everything is wanted (overflow path only)
     if (count > top_n)
@@ -385,6 +390,7 @@ __global__ __launch_bounds__(kSelThreads) void select_decode_kernel(const Decode
         const uint64_t off = L.channels_last ? static_cast<uint64_t>(pix) * (A * NB) + an * NB + k
                                              : (static_cast<uint64_t>(an) * NB + k) * hw + pix;
         d[k] = load_raw<T>(box_image, off);
+        if (L.box_bias) d[k] += L.box_bias[an * NB + k];                  // head bias folded in (fp32 add)
       }
       // box.py:302  grid = [x, y, x, y] * stride + anchors[a]
       const float *anc = L.anchors + 4 * an;

@@ -38,7 +38,8 @@ _sz = ctypes.c_size_t
 class Level(ctypes.Structure):
     """odtk_level_t"""
     _fields_ = [('cls', _vp), ('box', _vp), ('height', ctypes.c_int32), ('width', ctypes.c_int32),
-                ('stride', ctypes.c_int32), ('channels_last', ctypes.c_int32), ('anchors', _fp)]
+                ('stride', ctypes.c_int32), ('channels_last', ctypes.c_int32), ('anchors', _fp),
+                ('cls_bias', _vp), ('box_bias', _vp)]
 
 
 _SIGNATURES = {
@@ -230,7 +231,7 @@ def _layout(t, name):
     raise RuntimeError('%s must be contiguous (NCHW or channels_last)' % name)
 
 
-def _levels(cls_heads, box_heads, anchors_list, strides, nb):
+def _levels(cls_heads, box_heads, anchors_list, strides, nb, cls_bias=None, box_bias=None):
     """Fill the odtk_level_t table.  Head tensors are taken AS THE CONVOLUTION WROTE THEM: float32 /
     bfloat16 / float16, NCHW or channels_last -- no .float(), no .contiguous() (reference
     model.py:160, box.py:263 make both copies)."""
@@ -263,18 +264,31 @@ def _levels(cls_heads, box_heads, anchors_list, strides, nb):
         arr[i].stride = int(s)
         arr[i].channels_last = lay
         arr[i].anchors = ctypes.cast(carr, _fp)
+        for name, bias, width in (('cls_bias', cls_bias, c.shape[1]), ('box_bias', box_bias, b.shape[1])):
+            if bias is None:
+                continue
+            t = bias[i] if isinstance(bias, (list, tuple)) else bias      # one tensor shared by all levels, or a list
+            if t is None:
+                continue
+            if not t.is_cuda or t.dtype != torch.float32 or t.numel() != width or not t.is_contiguous():
+                raise RuntimeError('decode_levels: %s must be a contiguous float32 CUDA vector of length %d' % (name, width))
+            keep.append(t)
+            setattr(arr[i], name, t.data_ptr())
     num_classes = cls_heads[0].shape[1] // num_anchors
     return arr, keep, batch, num_anchors, num_classes, _DTYPES[dtype]
 
 
 def decode_levels(cls_heads, box_heads, anchors_list, strides, score_thresh, top_n, rotated=False,
-                  return_indices=False, logits=False):
+                  return_indices=False, logits=False, cls_bias=None, box_bias=None):
     """All levels x whole batch in one enqueue; returns tensors already in the layout of
     `torch.cat(per_level, 1)` (odtk/model.py:164): [B, L*top_n], [B, L*top_n, nb], [B, L*top_n].
-    logits=True: cls_heads hold raw logits and the sigmoid is fused into the prefilter."""
+    logits=True: cls_heads hold raw logits and the sigmoid is fused into the prefilter.
+    cls_bias / box_bias: float32 CUDA vectors [A*C] / [A*nb] (or per-level lists) -- the bias of the heads'
+    last convolutions, added inside the kernels (cls_bias: logits, 16-bit channels_last heads only)."""
     lib = library()
     nb = 6 if rotated else 4
-    arr, keep, batch, num_anchors, num_classes, dtype = _levels(cls_heads, box_heads, anchors_list, strides, nb)
+    arr, keep, batch, num_anchors, num_classes, dtype = _levels(cls_heads, box_heads, anchors_list, strides, nb,
+                                                                cls_bias, box_bias)
     dev = cls_heads[0].device
     n = len(cls_heads)
     with torch.cuda.device(dev):
@@ -294,11 +308,12 @@ def decode_levels(cls_heads, box_heads, anchors_list, strides, score_thresh, top
 
 
 def detect(cls_heads, box_heads, anchors_list, strides, score_thresh, top_n, nms_thresh, detections_per_im,
-           rotated=False, logits=False):
+           rotated=False, logits=False, cls_bias=None, box_bias=None):
     """decode_levels + nms back to back (the whole of odtk/model.py:140-165), 3 kernel launches."""
     lib = library()
     nb = 6 if rotated else 4
-    arr, keep, batch, num_anchors, num_classes, dtype = _levels(cls_heads, box_heads, anchors_list, strides, nb)
+    arr, keep, batch, num_anchors, num_classes, dtype = _levels(cls_heads, box_heads, anchors_list, strides, nb,
+                                                                cls_bias, box_bias)
     dev = cls_heads[0].device
     n = len(cls_heads)
     with torch.cuda.device(dev):

@@ -287,12 +287,13 @@ def decode_levels(cls_heads, box_heads, strides, threshold, top_n, anchors_per_s
 
 
 def detect(cls_heads, box_heads, strides, anchors_per_stride, threshold=0.05, top_n=1000, nms=0.5,
-           ndetections=100, rotated=False, logits=False):
+           ndetections=100, rotated=False, logits=False, cls_bias=None, box_bias=None):
     """sigmoid (logits=True) + decode of all levels + nms: the whole inference post-processing of the
-    reference (model.py:140-165) in three kernel launches, reading the head tensors in place."""
+    reference (model.py:140-165) in three kernel launches, reading the head tensors in place.
+    cls_bias / box_bias: the heads' last-conv biases, added inside the kernels (see _C.decode_levels)."""
     anchors = [anchors_per_stride[s][0] if rotated else anchors_per_stride[s] for s in strides]
     for t in cls_heads:
         _require_gpu(t, 'detect')
     pairs = [_pair(c, b) for c, b in zip(cls_heads, box_heads)]
     return _C.detect([p[0] for p in pairs], [p[1] for p in pairs], anchors, strides, threshold, top_n, nms,
-                     ndetections, rotated, logits=logits)
+                     ndetections, rotated, logits=logits, cls_bias=cls_bias, box_bias=box_bias)

@@ -14,7 +14,11 @@ Measured on MI355X those passes cost more than the convolutions between them.  H
   * 1x1 stride-1 convolutions (two of the three convs of every bottleneck, the FPN laterals) are a
     plain GEMM on the channels_last activation: they run as ONE hipBLASLt call with bias, skip and ReLU
     in the GEMM epilogue (`odtk_gemm_bias_act`, csrc/gemm_lt.hpp) -- no epilogue pass at all;
-  * the post-processing reads the raw head tensors in place (odtk.box.detect(..., logits=True)).
+  * the post-processing reads the raw head tensors in place (odtk.box.detect(..., logits=True)); in
+    `forward` even the bias of the heads' LAST convolutions is not applied by a pass of its own: it is
+    handed to the post-processing kernels (`cls_bias` / `box_bias`), which add it in fp32 to the few values
+    they actually look at -- the largest activation of the network (245 MB at bs 8) is written once by
+    the convolution and read once by the prefilter.
 
 `FusedRetinaNet(model)` is a drop-in for `model.eval()` inference: same outputs up to the rounding of
 the folded weights (tests/test_gpu_fused_model.py).
@@ -53,6 +57,11 @@ class _Conv(nn.Module):
         # (a strided 1x1 convolution -- the downsample branch -- is the same GEMM on the subsampled pixels)
         self.pointwise = (tuple(conv.kernel_size) == (1, 1) and tuple(conv.padding) == (0, 0) and conv.groups == 1
                           and tuple(conv.dilation) == (1, 1))
+
+    def conv_only(self, x):
+        """The convolution without its epilogue (the caller owns the bias)."""
+        y = F.conv2d(x, self.weight, None, self.stride, self.padding)
+        return y if y.is_contiguous(memory_format=torch.channels_last) else y.contiguous(memory_format=torch.channels_last)
 
     def forward(self, x, residual=None):
         if self.pointwise:
@@ -152,12 +161,24 @@ class FusedRetinaNet(nn.Module):
         feats = self.features(x)
         return [self._run(self.cls_head, t) for t in feats], [self._run(self.box_head, t) for t in feats]
 
+    def heads_without_last_bias(self, x):
+        """Head tensors as the last convolutions wrote them (bias NOT added) + the two bias vectors."""
+        x = x.to(self.dtype).contiguous(memory_format=torch.channels_last)
+        feats = self.features(x)
+        cls = [self.cls_head[-1].conv_only(self._run(self.cls_head[:-1], t)) for t in feats]
+        box = [self.box_head[-1].conv_only(self._run(self.box_head[:-1], t)) for t in feats]
+        return cls, box, self.cls_head[-1].bias, self.box_head[-1].bias
+
     @torch.no_grad()
     def forward(self, x):
         m = self.model[0]
-        cls_heads, box_heads = self.heads(x)
+        fold = self.dtype in (torch.bfloat16, torch.float16) and self.cls_head[-1].bias.numel() % 8 == 0
+        if fold:
+            cls_heads, box_heads, cls_bias, box_bias = self.heads_without_last_bias(x)
+        else:
+            (cls_heads, box_heads), cls_bias, box_bias = self.heads(x), None, None
         strides = [x.shape[-1] // c.shape[-1] for c in cls_heads]
         for s in strides:
             m.level_anchors(s)
         return box_ops.detect(cls_heads, box_heads, strides, m.anchors, m.threshold, m.top_n, m.nms, m.detections,
-                              m.rotated_bbox, logits=True)
+                              m.rotated_bbox, logits=True, cls_bias=cls_bias, box_bias=box_bias)

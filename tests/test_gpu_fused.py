@@ -164,3 +164,41 @@ def test_bias_act_maxpool_is_epilogue_then_pool(shape, dtype):
         ref = F.max_pool2d(_C.bias_act_(y.clone(memory_format=torch.channels_last), bias, None, relu), 3, 2, 1)
         assert got.shape == ref.shape and got.is_contiguous(memory_format=torch.channels_last)
         assert torch.equal(got, ref)
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16], ids=['bf16', 'fp16'])
+@pytest.mark.parametrize('rotated', [False, True], ids=['axis', 'rotated'])
+def test_head_bias_folded_into_the_kernels(dtype, rotated):
+    """decode_levels(raw heads, cls_bias, box_bias) == the strict op on torch-materialised inputs:
+    scores = sigmoid(float(raw) + bias) rounded to the head dtype, deltas = float(raw) + bias.
+    Biases spread over several units so that per-channel thresholds matter; indices bit-exact."""
+    a, c = (27, 8) if rotated else (9, 16)
+    nb = 6 if rotated else 4
+    g = torch.Generator().manual_seed(77)
+    shapes, strides = [(37, 53), (19, 27), (5, 7)], [8, 16, 32]
+    cls_bias = (torch.randn(a * c, generator=g) * 1.5 - 3.0).cuda()
+    box_bias = (torch.randn(a * nb, generator=g) * 0.3).cuda()
+    cls, box_h = [], []
+    for h, w in shapes:
+        cls.append((torch.randn(2, a * c, h, w, generator=g) * 1.2).to(dtype).cuda().contiguous(memory_format=torch.channels_last))
+        box_h.append((torch.randn(2, a * nb, h, w, generator=g) * 0.3).to(dtype).cuda().contiguous(memory_format=torch.channels_last))
+    if rotated:
+        import math
+        anchors = {s: box.generate_anchors_rotated(s, [1.0, 2.0, 0.5], [4 * 2 ** (i / 3) for i in range(3)],
+                                                   [-math.pi / 6, 0, math.pi / 6])[0] for s in strides}
+    else:
+        anchors = {s: box.generate_anchors(s, [1.0, 2.0, 0.5], [4 * 2 ** (i / 3) for i in range(3)]) for s in strides}
+    alist = [anchors[s] for s in strides]
+    got = _C.decode_levels(cls, box_h, alist, strides, 0.05, 300, rotated, return_indices=True, logits=True,
+                           cls_bias=cls_bias, box_bias=box_bias)
+    scores = [(x.float() + cls_bias.view(1, -1, 1, 1)).sigmoid().to(dtype).float().contiguous() for x in cls]
+    deltas = [(x.float() + box_bias.view(1, -1, 1, 1)).contiguous() for x in box_h]
+    ref = _C.decode_levels(scores, deltas, alist, strides, 0.05, 300, rotated, return_indices=True)
+    assert torch.equal(got[3], ref[3]), 'indices'
+    assert torch.equal(got[0], ref[0]) and torch.equal(got[2], ref[2])
+    assert torch.equal(got[1], ref[1])                    # same fp32 deltas into the same box arithmetic
+    assert (got[0] > 0).sum().item() > 300                # the case is not vacuous
+    # the fold is refused where it cannot be exact-by-construction
+    with pytest.raises(RuntimeError):
+        _C.decode_levels([x.float() for x in cls], [x.float() for x in box_h], alist, strides, 0.05, 300, rotated,
+                         logits=True, cls_bias=cls_bias)

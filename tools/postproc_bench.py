@@ -39,6 +39,7 @@ def main():
     ap.add_argument('--dtype', default='fp32', choices=['fp32', 'bf16', 'fp16'])
     ap.add_argument('--logits', action='store_true', help='feed raw logits (sigmoid fused into the prefilter)')
     ap.add_argument('--channels-last', action='store_true')
+    ap.add_argument('--bias', action='store_true', help='pass the last-conv biases to the kernels (cls_bias / box_bias)')
     ap.add_argument('--torch-baselines', action='store_true', help='also time torch read-only / copy passes')
     args = ap.parse_args()
 
@@ -76,9 +77,14 @@ def main():
     cand = [int(((c.float().sigmoid() if args.logits else c.float()) >= args.threshold).sum().item()) // args.batch
             for c in cls]
 
+    cls_bias = box_bias = None
+    if args.bias:
+        cls_bias = torch.randn(args.anchors * args.classes, generator=g, device=dev) * 0.05
+        box_bias = torch.randn(args.anchors * nb, generator=g, device=dev) * 0.05
+
     def run():
         return box.detect(cls, dl, list(strides), anchors, args.threshold, 1000, 0.5, args.ndet, args.rotated,
-                          logits=args.logits)
+                          logits=args.logits, cls_bias=cls_bias, box_bias=box_bias)
 
     for _ in range(args.warmup):
         out = run()
