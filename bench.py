@@ -95,6 +95,8 @@ def main():
     ap.add_argument('--no-fuse', action='store_true',
                     help='run the eager nn.Module graph under autocast instead of the BN-folded graph with the HIP '
                          'bias/skip/ReLU epilogue (odtk/fused.py)')
+    ap.add_argument('--no-level-streams', action='store_true',
+                    help='run the head towers of all pyramid levels on one stream (default: small levels on side streams)')
     ap.add_argument('--postproc', default='fused', choices=['fused', 'reference'],
                     help="fused: sigmoid+decode+nms read the bf16 channels_last head tensors in place (3 launches); "
                          "reference: the reference's op sequence (sigmoid, .contiguous(), .float(), decode x5, cat, nms)")
@@ -129,6 +131,7 @@ def main():
     if fuse_graph:
         from odtk.fused import FusedRetinaNet
         engine = FusedRetinaNet(model, dtype=amp_dtype or torch.float32).to(dev)
+        engine.level_streams = not args.no_level_streams
 
         def step():
             return engine(x)
@@ -194,7 +197,10 @@ def main():
         roofline = {'kernel': 'prefilter_scan_kernel', 'bound': 'hbm', 'achieved': round(achieved, 1),
                     'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
                     'traffic': traffic, 'traffic_source': 'profiles/r01_pmc_traffic.json (rocprofv3 --pmc, same workload)'
-                    if traffic else None, 'alg_bytes_per_launch': alg_bytes, 'bytes_per_score': bytes_per_score, 'avg_ms': round(avg_ms, 5), 'launches': n}
+                    if traffic else None, 'alg_bytes_per_launch': alg_bytes, 'bytes_per_score': bytes_per_score, 'avg_ms': round(avg_ms, 5), 'launches': n,
+                    'note': ('the head bias is folded into this launch (per-channel thresholds, +3.5 us measured back to back) '
+                             'in exchange for the 2 x %.1f MB bias pass it removes from the step' % (alg_bytes / 1e6))
+                    if fuse_graph and bytes_per_score == 2 else None}
     kernels = {k: {'avg_us': round(v[0] / v[1] * 1e3, 2), 'launches': v[1]} for k, v in prof.items() if v[1]}
     conv_tflops = flops_img * (value / world) / 1e12
     conv_roofline = {'bound': 'mfma', 'achieved': round(conv_tflops, 1), 'peak': MFMA_BF16_PEAK_TFLOPS,
@@ -242,7 +248,7 @@ def main():
                        'global_batch': args.batch * world, 'image': [args.height, args.width],
                        'parallelism': 'replicas x%d (no data-path collective)' % world,
                        'memory_format': 'channels_last', 'miopen_find': miopen_find, 'postproc': args.postproc,
-                       'graph': 'BN folded into conv weights + HIP bias/skip/ReLU epilogue' if fuse_graph
+                       'graph': 'BN folded into conv weights + HIP bias/skip/ReLU epilogue + 1x1 convs as fused GEMMs' if fuse_graph
                                 else 'eager nn.Module under autocast'},
             'roofline': roofline, 'conv_roofline': conv_roofline, 'kernels': kernels,
             'candidates_per_image_per_level': candidates,

@@ -129,6 +129,8 @@ class FusedRetinaNet(nn.Module):
 
         self.cls_head = head(model.cls_head)
         self.box_head = head(model.box_head)
+        self.level_streams = True                                       # small pyramid levels on side HIP streams
+        self._streams = None
 
     def features(self, x):
         x = self.stem.conv_then_pool(x)                                  # conv1 -> (bias + ReLU + maxpool, one pass)
@@ -156,17 +158,50 @@ class FusedRetinaNet(nn.Module):
             t = c(t)
         return t
 
+    def _towers(self, feats, last_bias):
+        """Both head towers on every pyramid level.  The levels are independent and the small ones (P5-P7:
+        8000 / 2080 / 560 pixels at bs 8) cannot fill 256 CUs on their own, so they run on side HIP streams
+        next to P3's convolutions: [P3] on the caller's stream, [P4] and [P5, P6, P7] on two others."""
+        def level(t):
+            if last_bias:
+                return self._run(self.cls_head, t), self._run(self.box_head, t)
+            return (self.cls_head[-1].conv_only(self._run(self.cls_head[:-1], t)),
+                    self.box_head[-1].conv_only(self._run(self.box_head[:-1], t)))
+
+        if not self.level_streams or not feats[0].is_cuda or len(feats) < 3:
+            out = [level(t) for t in feats]
+            return [o[0] for o in out], [o[1] for o in out]
+        main = torch.cuda.current_stream(feats[0].device)
+        if self._streams is None or self._streams[0].device != feats[0].device:
+            self._streams = [torch.cuda.Stream(feats[0].device) for _ in range(2)]
+        groups = [[1], list(range(2, len(feats)))]                      # side-stream work; level 0 stays on `main`
+        ready = torch.cuda.Event()
+        ready.record(main)
+        out = [None] * len(feats)
+        done = []
+        for stream, group in zip(self._streams, groups):
+            stream.wait_event(ready)                                    # the pyramid is complete
+            with torch.cuda.stream(stream):
+                for i in group:
+                    out[i] = level(feats[i])
+                    for t in out[i]:
+                        t.record_stream(main)                           # consumed by the post-processing on `main`
+                e = torch.cuda.Event()
+                e.record(stream)
+                done.append(e)
+        out[0] = level(feats[0])
+        for e in done:
+            main.wait_event(e)
+        return [o[0] for o in out], [o[1] for o in out]
+
     def heads(self, x):
         x = x.to(self.dtype).contiguous(memory_format=torch.channels_last)
-        feats = self.features(x)
-        return [self._run(self.cls_head, t) for t in feats], [self._run(self.box_head, t) for t in feats]
+        return self._towers(self.features(x), True)
 
     def heads_without_last_bias(self, x):
         """Head tensors as the last convolutions wrote them (bias NOT added) + the two bias vectors."""
         x = x.to(self.dtype).contiguous(memory_format=torch.channels_last)
-        feats = self.features(x)
-        cls = [self.cls_head[-1].conv_only(self._run(self.cls_head[:-1], t)) for t in feats]
-        box = [self.box_head[-1].conv_only(self._run(self.box_head[:-1], t)) for t in feats]
+        cls, box = self._towers(self.features(x), False)
         return cls, box, self.cls_head[-1].bias, self.box_head[-1].bias
 
     @torch.no_grad()
