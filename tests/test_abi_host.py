@@ -114,3 +114,30 @@ def test_delta_roundtrip_matches_oracle():
     back = box.box2delta(mine, anchors)
     inside = ((mine > 0) & (mine < torch.tensor([319., 199., 319., 199.]))).all(1)
     assert torch.allclose(back[inside], deltas[inside], atol=1e-4)
+
+
+def test_new_entry_points_validate_before_touching_the_device():
+    lib = _C.library()
+    # odtk_gemm_bias_act: null / aliased / misaligned pointers and bad sizes are rejected on the host
+    assert lib.odtk_gemm_bias_act(None, None, None, None, None, 16, 8, 8, _C.BF16, 1, None, 0, None) == _C.ERR_INVALID
+    assert lib.odtk_gemm_bias_act(256, 512, 768, 1024, 256, 16, 8, 8, _C.BF16, 1, None, 0, None) == _C.ERR_INVALID   # residual == y
+    assert lib.odtk_gemm_bias_act(256, 512, 768, 1024, None, 16, 0, 8, _C.BF16, 1, None, 0, None) == _C.ERR_INVALID
+    assert lib.odtk_gemm_bias_act(264, 512, 768, 1024, None, 16, 8, 8, _C.BF16, 1, None, 0, None) == _C.ERR_INVALID   # 16-B alignment
+    assert lib.odtk_gemm_bias_act(256, 512, 768, 1024, None, 16, 8, 8, 9, 1, None, 0, None) == _C.ERR_UNSUPPORTED
+    # odtk_bias_act_maxpool: 16-bit dtypes, channels % 8 == 0
+    assert lib.odtk_bias_act_maxpool(256, 512, 768, 1, 4, 4, 8, _C.F32, 1, None) == _C.ERR_UNSUPPORTED
+    assert lib.odtk_bias_act_maxpool(256, 512, 768, 1, 4, 4, 12, _C.BF16, 1, None) == _C.ERR_UNSUPPORTED
+    assert lib.odtk_bias_act_maxpool(None, 512, 768, 1, 4, 4, 8, _C.BF16, 1, None) == _C.ERR_INVALID
+    # head bias fold: logits + 16-bit + channels_last + A*C % 8 == 0, otherwise refused (never silently ignored)
+    anchors = (ctypes.c_float * 36)(*[0.0] * 36)
+    lv = (_C.Level * 1)()
+    lv[0].height, lv[0].width, lv[0].stride, lv[0].channels_last = 5, 7, 8, 1
+    lv[0].anchors = ctypes.cast(anchors, ctypes.POINTER(ctypes.c_float))
+    lv[0].cls_bias = 4096
+    ok = lib.odtk_decode_levels(2, 1, lv, 9, 80, _C.BF16, _C.FLAG_LOGITS, 0.05, 100, None, 0, None, 0, None)
+    assert ok > 0
+    assert lib.odtk_decode_levels(2, 1, lv, 9, 80, _C.BF16, 0, 0.05, 100, None, 0, None, 0, None) == _C.ERR_UNSUPPORTED
+    assert lib.odtk_decode_levels(2, 1, lv, 9, 80, _C.F32, _C.FLAG_LOGITS, 0.05, 100, None, 0, None, 0, None) == _C.ERR_UNSUPPORTED
+    assert lib.odtk_decode_levels(2, 1, lv, 9, 3, _C.BF16, _C.FLAG_LOGITS, 0.05, 100, None, 0, None, 0, None) == _C.ERR_UNSUPPORTED
+    lv[0].channels_last = 0
+    assert lib.odtk_decode_levels(2, 1, lv, 9, 80, _C.BF16, _C.FLAG_LOGITS, 0.05, 100, None, 0, None, 0, None) == _C.ERR_UNSUPPORTED

@@ -80,3 +80,46 @@ def test_single_process_is_a_noop():
     assert torch.equal(u[0], s) and torch.equal(u[1], b) and torch.equal(u[2], c) and u[3].tolist() == [4, 9]
     with pytest.raises(RuntimeError):
         parallel.shard_batch(10, 0, 4)
+
+
+class _Stub:
+    """Detections that encode (image id's batch position, rank) so the gathered order can be checked."""
+    def __init__(self, rank):
+        self.rank = rank
+
+    def __call__(self, images):
+        n = images.shape[0]
+        scores = torch.tensor([[0.9, 0.5, 0.0]]).repeat(n, 1) + 0.01 * self.rank
+        scores[:, 2] = 0
+        boxes = torch.zeros(n, 3, 4)
+        boxes[:, :, 2:] = 10 + self.rank
+        return scores, boxes, torch.full((n, 3), float(self.rank))
+
+
+def _infer_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    from odtk import infer
+    parallel.init_from_env('gloo')
+    # rank r owns images 100*r + {0, 1, 2, 3} in two batches of two
+    batches = [(torch.zeros(2, 3, 4, 4), torch.tensor([100 * rank + 2 * k, 100 * rank + 2 * k + 1]), torch.ones(2)) for k in range(2)]
+    dets = infer.infer(_Stub(rank), batches)
+    q.put((rank, None if dets is None else [(d['image_id'], d['category_id'], d['bbox'][2]) for d in dets]))
+    dist.destroy_process_group()
+
+
+def test_infer_driver_two_ranks_one_gather():
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_infer_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res[1] is None                                    # only the master converts
+    ids = [d[0] for d in res[0]]
+    assert ids == [i for r in range(2) for k in range(4) for i in [100 * r + k] * 2]   # rank-major, 2 detections each
+    assert all(cat == (0 if i < 100 else 1) and w == (11.0 if i < 100 else 12.0) for i, cat, w in res[0])
