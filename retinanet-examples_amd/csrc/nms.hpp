@@ -101,10 +101,10 @@ __device__ __forceinline__ bool axis_suppresses(const float *m, const float *j, 
   return !(iou <= thr);
 }
 
-template <int NB>
+template <int NB, bool kReject = true>
 __device__ __forceinline__ bool box_suppresses(const float *m, const float *j, float thr, bool own_angle, float2 *q) {
   if constexpr (NB == 4) return axis_suppresses(m, j, thr);
-  else return rotated_suppresses(m, j, thr, own_angle, q);
+  else return rotated_suppresses<kReject>(m, j, thr, own_angle, q);
 }
 
 // Does any box kept at ranks q0, q0 + step, ... (< q1) suppress candidate (jb, jc)?  Class words are
@@ -114,12 +114,13 @@ template <int NB>
 __device__ __forceinline__ bool pull_against_kept(const float *s_kcls, const float *s_kbox, int q0, int q1, int step,
                                                   const float *jb, float jc, bool alive, float thr, bool own_angle,
                                                   float2 *clip) {
-  for (int q = q0; q < q1 && alive; q += 8 * step) {
-    float kc[8];
+  constexpr int kBatch = NB == 6 ? 2 : 8;        // rotated: the IoU + its reject need the registers (8 spills, 2 does not)
+  for (int q = q0; q < q1 && alive; q += kBatch * step) {
+    float kc[kBatch];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) kc[u] = (q + u * step < q1) ? s_kcls[q + u * step] : __builtin_nanf("");   // NaN equals nothing
+    for (int u = 0; u < kBatch; ++u) kc[u] = (q + u * step < q1) ? s_kcls[q + u * step] : __builtin_nanf("");   // NaN equals nothing
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < kBatch; ++u) {
       if (alive && kc[u] == jc) {                               // box.py:351: a different class keeps
         float mb[NB];
 #pragma unroll

@@ -122,8 +122,28 @@ __device__ __forceinline__ float overlap_from(const Pt *I, const Pt *M, float2 *
 
 // Does the kept box m suppress the lower-scored box j?  boxes are [x1,y1,x2,y2,sin,cos].
 // Reference default (nms_iou.cu:186-193): BOTH quads are rotated by j's (sin, cos).
+template <bool kReject = true>
 __device__ __forceinline__ bool rotated_suppresses(const float *m, const float *j, float thr, bool own_angle,
                                                    float2 *q) {
+  // Cheap reject before the polygon clip: every corner of a quad lies within its half diagonal (scaled by
+  // |(sin, cos)|, which the network does not normalise) of the box centre, so two quads whose centres are
+  // further apart -- along x or along y -- than an upper bound of the two radii cannot intersect: the clip would return an empty polygon, overlap 0,
+  // and `0 > thr` is false for thr >= 0.  The margin (0.1 % + 2 px + 4e-6 * coordinate^2) is far above
+  // the fp32 error of the clip's line equations as long as the kept quad is properly oriented with edges
+  // of at least one pixel (otherwise, and for any NaN / inf, the full path decides).  In an NMS almost
+  // all same-class pairs are far apart, and a wave only pays for the clip if one of its lanes needs it.
+  if (kReject && thr >= 0.0f) {
+    const float sm = own_angle ? m[4] : j[4], cm = own_angle ? m[5] : j[5];
+    const float wm = m[2] - m[0], hm = m[3] - m[1];
+    const float kj = fabsf(j[4]) + fabsf(j[5]), km = fabsf(sm) + fabsf(cm);           // >= |(sin, cos)|: no sqrt needed
+    const float rr = 0.5f * ((fabsf(j[2] - j[0]) + fabsf(j[3] - j[1])) * kj + (fabsf(wm) + fabsf(hm)) * km);   // >= r_j + r_m
+    const float sxm = m[0] + m[2], sym = m[1] + m[3];                                 // twice the kept centre
+    const float far = 0.5f * fmaxf(fabsf((j[0] + j[2]) - sxm), fabsf((j[1] + j[3]) - sym));
+    const float reach = 0.5f * (fabsf(sxm) + fabsf(sym)) + far + rr;                  // >= |any coordinate| of both quads
+    // |(sin, cos)| >= (|sin| + |cos|) / sqrt 2: edges of the kept quad are at least one pixel long
+    const bool proper = wm * km >= 1.5f && hm * km >= 1.5f;                          // implies wm, hm > 0 (km >= 0)
+    if (proper && far > rr * 1.001f + 2.0f + 4e-6f * reach * reach) return false;
+  }
   Pt I[4], M[4];
   rotated_corners(j, j[4], j[5], I);
   rotated_corners(m, own_angle ? m[4] : j[4], own_angle ? m[5] : j[5], M);
