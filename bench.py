@@ -63,12 +63,15 @@ def conv_flops_per_image(model, x):
     return total[0]
 
 
-def calibrate_cls_head(model, x, target_sigma, amp_dtype):
+def calibrate_cls_head(model, x, target_sigma, amp_dtype, heads=None):
     """Random-init heads score ~0.01 everywhere (class prior) = zero detections, so decode/NMS would
     have nothing to do.  Rescale the LAST classification conv so its logits follow the
-    'sparse-realistic' distribution of SURVEY.md 8(d): N(-ln 99, 0.573^2)."""
+    'sparse-realistic' distribution of SURVEY.md 8(d): N(-ln 99, 0.573^2).  `heads`: the function that
+    produces the head tensors of the path being TIMED (the fused engine's, when there is one: the eager
+    autocast graph runs 14 % low on this stack -- DESIGN.md section 5 -- so calibrating on it would hand
+    the timed path a denser distribution than the specified one)."""
     with torch.no_grad(), torch.autocast('cuda', dtype=amp_dtype, enabled=amp_dtype is not None):
-        cls_heads, _ = model.heads(x)
+        cls_heads, _ = (heads or model.heads)(x)
         bias = model.cls_head[-1].bias.view(1, -1, 1, 1)
         centred = torch.cat([(c.float() - bias).flatten() for c in cls_heads])
         sigma = centred.std().item()
@@ -125,13 +128,19 @@ def main():
     x = torch.randn(args.batch, 3, args.height, args.width, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
 
     flops_img = conv_flops_per_image(model, x[:1])
-    sigma0 = calibrate_cls_head(model, x, args.sigma, amp_dtype)
-
     fuse_graph = not args.no_fuse and args.postproc == 'fused'
     if fuse_graph:
         from odtk.fused import FusedRetinaNet
-        engine = FusedRetinaNet(model, dtype=amp_dtype or torch.float32).to(dev)
+        probe = FusedRetinaNet(model, dtype=amp_dtype or torch.float32).to(dev)
+        sigma0 = calibrate_cls_head(model, x, args.sigma, None, probe.heads)      # on the timed path's own tensors
+        del probe
+        engine = FusedRetinaNet(model, dtype=amp_dtype or torch.float32).to(dev)  # rebuilt from the rescaled weights
         engine.level_streams = not args.no_level_streams
+        timed_heads, heads_amp = engine.heads, None
+    else:
+        sigma0 = calibrate_cls_head(model, x, args.sigma, amp_dtype)
+        timed_heads, heads_amp = model.heads, amp_dtype
+    if fuse_graph:
 
         def step():
             return engine(x)
@@ -170,8 +179,8 @@ def main():
     value = images / elapsed
 
     # ---- roofline of the dominant hand-written kernel ----
-    with torch.no_grad(), torch.autocast('cuda', dtype=amp_dtype, enabled=amp_dtype is not None):
-        cls_heads, _ = model.heads(x)
+    with torch.no_grad(), torch.autocast('cuda', dtype=heads_amp, enabled=heads_amp is not None):
+        cls_heads, _ = timed_heads(x)                        # the tensors the timed post-processing reads
     scores_per_batch = sum(c.numel() for c in cls_heads)
     with torch.no_grad():
         candidates = [int((c.float().sigmoid() >= model.threshold).sum().item()) // args.batch for c in cls_heads]
