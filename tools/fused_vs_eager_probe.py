@@ -1,5 +1,14 @@
-import sys, os, torch
-ROOT='/root/repo'
+"""Numerical fidelity of the fused bf16 engine vs the eager autocast graph vs fp32,
+and the rounding mode of the bf16 convolution kernels.
+
+    python tools/fused_vs_eager_probe.py
+"""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, 'retinanet-examples_amd')):
     sys.path.insert(0, p)
 import bench
