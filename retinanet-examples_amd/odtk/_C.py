@@ -397,14 +397,22 @@ _GEMM_READY = []
 def _gemm_setup(device):
     """Bind hipBLASLt (the copy PyTorch ships, so that one copy of the soname serves the process) and
     keep one 32 MiB scratch buffer per device."""
-    if not _GEMM_READY:
-        shipped = os.path.join(os.path.dirname(torch.__file__), 'lib', 'libhipblaslt.so')
-        path = shipped if os.path.exists(shipped) else None
-        _check(library().odtk_gemm_init(path.encode() if path else None), 'gemm_init')
-        _GEMM_READY.append(True)
+    if not gemm_available():
+        raise RuntimeError('gemm_bias_act: hipBLASLt could not be bound (odtk_gemm_init failed)')
     if device not in _GEMM_WORKSPACE:
         _GEMM_WORKSPACE[device] = torch.empty(32 << 20, dtype=torch.uint8, device=device)
     return _GEMM_WORKSPACE[device]
+
+
+def gemm_available():
+    """True when hipBLASLt could be bound (it ships with ROCm and with PyTorch-ROCm).  When it cannot, the
+    fused graph keeps its 1x1 convolutions on MIOpen + the HIP epilogue -- slower, same results."""
+    if not _GEMM_READY:
+        shipped = os.path.join(os.path.dirname(torch.__file__), 'lib', 'libhipblaslt.so')
+        path = shipped if os.path.exists(shipped) else None
+        rc = library().odtk_gemm_init(path.encode() if path else None)
+        _GEMM_READY.append(rc == OK)
+    return _GEMM_READY[0]
 
 
 def gemm_bias_act(x, weight, bias, residual=None, relu=True):

@@ -64,7 +64,7 @@ class _Conv(nn.Module):
         return y if y.is_contiguous(memory_format=torch.channels_last) else y.contiguous(memory_format=torch.channels_last)
 
     def forward(self, x, residual=None):
-        if self.pointwise:
+        if self.pointwise and _C.gemm_available():
             if tuple(self.stride) != (1, 1):
                 x = x[:, :, ::self.stride[0], ::self.stride[1]].contiguous(memory_format=torch.channels_last)
             return _C.gemm_bias_act(x, self.weight, self.bias, residual, self.relu)
