@@ -100,6 +100,7 @@ def main():
                          'bias/skip/ReLU epilogue (odtk/fused.py)')
     ap.add_argument('--no-level-streams', action='store_true',
                     help='run the head towers of all pyramid levels on one stream (default: small levels on side streams)')
+    ap.add_argument('--tower-plan', type=int, default=0, help='assignment of pyramid levels to HIP streams (odtk/fused.py)')
     ap.add_argument('--postproc', default='fused', choices=['fused', 'reference'],
                     help="fused: sigmoid+decode+nms read the bf16 channels_last head tensors in place (3 launches); "
                          "reference: the reference's op sequence (sigmoid, .contiguous(), .float(), decode x5, cat, nms)")
@@ -136,6 +137,7 @@ def main():
         del probe
         engine = FusedRetinaNet(model, dtype=amp_dtype or torch.float32).to(dev)  # rebuilt from the rescaled weights
         engine.level_streams = not args.no_level_streams
+        engine.tower_plan = args.tower_plan
         timed_heads, heads_amp = engine.heads, None
     else:
         sigma0 = calibrate_cls_head(model, x, args.sigma, amp_dtype)
