@@ -15,9 +15,17 @@ Pinning status
   restatement in box_oracle.py reproduces them bit-for-bit
   (tests/test_oracle_golden.py).  Anchors are additionally pinned to the rounded
   known-answer table embedded in the reference at extras/cppapi/export.cpp:69-75.
-* rotated decode / rotated IoU / rotated NMS: PARITY UNPINNED.  The reference has
-  no runnable CPU implementation (odtk/box.py:408 NameError, box.py:303 shape bug)
-  and its CUDA sources cannot be built here (nvcc/thrust/cub/TensorRT absent), so
-  oracle/c/odtk_oracle.c restates csrc/cuda/nms_iou.cu + decode_rotate.cu and is
-  cross-checked only against an independent float64 convex-polygon clipper.
+* rotated IoU / rotated NMS: PINNED to the reference's own source.  The native library as a whole
+  cannot be built here (nvcc / thrust / cub / TensorRT absent), but the device code that does the
+  geometry -- Vector / Line / IntersectionArea, nms_rotate_kernel, iou_cuda_kernel
+  (csrc/cuda/nms_iou.cu:41-258, :324-375) -- is plain C++ once a dozen CUDA names exist:
+  oracle/ref_build/build_ref.py reads those lines from /root/reference where they lie, wraps them
+  between prelude.hpp and harness.cpp and builds oracle/_ref/libodtk_ref_rotated.so with g++ in IEEE
+  mode (the reference's nvcc build used --use_fast_math, whose bits nothing else reproduces).
+  tests/golden/rotated_ref_*.npz hold its outputs (oracle/gen_golden_rotated.py); the C restatement
+  oracle/c/odtk_oracle.c reproduces them bit for bit, live runs included
+  (tests/test_oracle_rotated_ref.py), and so do the HIP kernels (tests/test_gpu_rotated.py).
+* rotated decode: PARITY UNPINNED.  csrc/cuda/decode_rotate.cu is thrust/cub host code around one
+  device lambda and has no runnable CPU counterpart (odtk/box.py:303 shape bug); oracle/c restates
+  it with box.py's conventions and is checked against the axis-aligned decode on the shared arithmetic.
 """

@@ -1,8 +1,8 @@
 """ctypes wrapper over oracle/c/libodtk_oracle.so (TEST INFRASTRUCTURE ONLY).
 
 numpy in / numpy out.  See oracle/c/odtk_oracle.c for what is restated and from which reference
-lines.  The rotated functions are the only oracle the rotated path has ("parity unpinned": the
-reference has no runnable CPU rotated implementation and its CUDA sources cannot be built here)."""
+lines.  The rotated IoU / NMS functions are pinned bit for bit to the reference's own device code compiled
+for the CPU (oracle/ref_rotated.py, tests/test_oracle_rotated_ref.py); rotated decode is unpinned."""
 import ctypes
 import os
 import subprocess

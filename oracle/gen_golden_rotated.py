@@ -1,0 +1,71 @@
+#!/usr/bin/env python
+"""Golden vectors for the rotated path, produced by the reference's OWN device code compiled for the CPU
+(oracle/ref_build/build_ref.py -> oracle/_ref/libodtk_ref_rotated.so): tests/golden/rotated_ref_*.npz.
+Run in the build container (needs /root/reference to build the library); the fixtures travel instead of it.
+
+    python oracle/gen_golden_rotated.py
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import ref_rotated                                   # noqa: E402
+from oracle.ref_build import build_ref                           # noqa: E402
+
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+
+
+def quads(r, n, lo, hi, size):
+    ctr = r.uniform(lo, hi, (n, 2))
+    wh = r.uniform(size[0], size[1], (n, 2))
+    th = r.uniform(-1.5, 1.5, n)
+    c, s = np.cos(th), np.sin(th)
+    dx = np.stack([-wh[:, 0], wh[:, 0], wh[:, 0], -wh[:, 0]], 1) / 2
+    dy = np.stack([-wh[:, 1], -wh[:, 1], wh[:, 1], wh[:, 1]], 1) / 2
+    x = dx * c[:, None] - dy * s[:, None] + ctr[:, 0:1]
+    y = dy * c[:, None] + dx * s[:, None] + ctr[:, 1:2]
+    return np.stack([x, y], 2).reshape(n, 8).astype(np.float32)
+
+
+def boxes6(r, k, span, size, unit=True):
+    ctr = r.uniform(20, span, (k, 2))
+    wh = r.uniform(size[0], size[1], (k, 2))
+    th = r.uniform(-1.5, 1.5, k)
+    scale = 1.0 if unit else r.uniform(0.6, 1.4, k)               # the network does not normalise (sin, cos)
+    return np.concatenate([ctr - wh / 2, ctr + wh / 2, (np.sin(th) * scale)[:, None], (np.cos(th) * scale)[:, None]],
+                          1).astype(np.float32)
+
+
+def main():
+    build_ref.build()
+    r = np.random.default_rng(20240924)
+    # pairwise IoU: ground-truth quads x anchor quads (training-side target assignment)
+    for name, n, m, lo, hi, size in (('a', 23, 300, 40, 400, (8, 160)), ('b', 1, 64, 100, 200, (30, 90)),
+                                     ('c', 40, 40, 0, 120, (4, 60))):
+        b, a = quads(r, n, lo, hi, size), quads(r, m, lo, hi, size)
+        if name == 'c':
+            a[:10] = b[:10]                                        # identical quads: the 0.001 pad rule
+            a[10:14, :2] = b[10:14, :2]                            # one shared corner
+        np.savez_compressed(os.path.join(GOLDEN, 'rotated_ref_iou_%s.npz' % name), boxes=b, anchors=a,
+                            iou=ref_rotated.iou_pairs(b, a))
+    # rotated NMS, one image each
+    for name, k, span, size, n_cls, thr, ndet, unit in (('a', 600, 320, (4, 90), 3, 0.5, 100, True),
+                                                        ('b', 1000, 500, (8, 200), 80, 0.3, 100, True),
+                                                        ('c', 300, 150, (10, 120), 1, 0.0, 300, True),
+                                                        ('d', 800, 400, (6, 150), 2, 0.7, 50, False)):
+        bx = boxes6(r, k, span, size, unit)
+        sc = (r.permutation(k).astype(np.float32) + 1) / k        # tie-free
+        sc[r.random(k) < 0.15] = 0
+        cl = r.integers(0, n_cls, k).astype(np.float32)
+        s, b, c, idx = ref_rotated.nms_rotate(sc, bx, cl, thr, ndet)
+        np.savez_compressed(os.path.join(GOLDEN, 'rotated_ref_nms_%s.npz' % name), scores=sc, boxes=bx, classes=cl,
+                            thresh=np.float32(thr), ndet=np.int32(ndet), out_scores=s, out_boxes=b, out_classes=c,
+                            out_index=idx)
+    print('wrote', sorted(f for f in os.listdir(GOLDEN) if f.startswith('rotated_ref_')))
+
+
+if __name__ == '__main__':
+    main()

@@ -1,6 +1,7 @@
 """Rotated path on the GPU (decode_rotate, rotated NMS, pairwise IoU) against the C restatement of
-csrc/cuda/decode_rotate.cu + nms_iou.cu (oracle/c, "parity unpinned": the reference has no runnable
-rotated implementation outside CUDA).  Both sides evaluate the same IEEE fp32 expressions in the
+csrc/cuda/decode_rotate.cu + nms_iou.cu (oracle/c; its rotated IoU / NMS are pinned bit for bit to the
+reference's own device code compiled for the CPU, tests/test_oracle_rotated_ref.py -- the fixtures of
+that pinning are also applied to the HIP kernels directly at the end of this file).  Both sides evaluate the same IEEE fp32 expressions in the
 same order, so everything -- including IoU values -- is compared BIT FOR BIT; axis-aligned boxes
 are also compared bit-for-bit here (the C oracle uses the same correctly rounded exp)."""
 import numpy as np
@@ -104,3 +105,29 @@ def test_pairwise_iou_vs_c_oracle():
     # empty inputs are a no-op
     empty = _C.iou(torch.empty(0, device='cuda'), torch.from_numpy(an).cuda().view(-1))[0]
     assert tuple(empty.shape) == (3000, 0)
+
+
+# ---- fixtures produced by the reference's own device code (oracle/ref_build, tests/test_oracle_rotated_ref.py) ----
+import glob
+import os
+
+_GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+@pytest.mark.parametrize('path', sorted(glob.glob(os.path.join(_GOLDEN, 'rotated_ref_iou_*.npz'))), ids=os.path.basename)
+def test_hip_pairwise_iou_equals_reference_source_fixture(path):
+    z = np.load(path)
+    out = _C.iou(torch.from_numpy(z['boxes']).cuda().reshape(-1), torch.from_numpy(z['anchors']).cuda().reshape(-1))[0]
+    assert np.array_equal(out.cpu().numpy().view(np.uint32), z['iou'].view(np.uint32))
+
+
+@pytest.mark.parametrize('path', sorted(glob.glob(os.path.join(_GOLDEN, 'rotated_ref_nms_*.npz'))), ids=os.path.basename)
+def test_hip_rotated_nms_equals_reference_source_fixture(path):
+    z = np.load(path)
+    out = _C.nms(torch.from_numpy(z['scores'])[None].cuda(), torch.from_numpy(z['boxes'])[None].cuda(),
+                 torch.from_numpy(z['classes'])[None].cuda(), float(z['thresh']), int(z['ndet']), True, return_indices=True)
+    kept = z['out_index'] >= 0
+    assert np.array_equal(out[3][0].cpu().numpy().astype(np.int64), z['out_index'])
+    assert np.array_equal(out[0][0].cpu().numpy().view(np.uint32), z['out_scores'].view(np.uint32))
+    assert np.array_equal(out[1][0].cpu().numpy()[kept].view(np.uint32), z['out_boxes'][kept].view(np.uint32))
+    assert np.array_equal(out[2][0].cpu().numpy()[kept], z['out_classes'][kept])
