@@ -64,7 +64,20 @@ def main():
         np.savez_compressed(os.path.join(GOLDEN, 'rotated_ref_nms_%s.npz' % name), scores=sc, boxes=bx, classes=cl,
                             thresh=np.float32(thr), ndet=np.int32(ndet), out_scores=s, out_boxes=b, out_classes=c,
                             out_index=idx)
-    print('wrote', sorted(f for f in os.listdir(GOLDEN) if f.startswith('rotated_ref_')))
+    # axis-aligned NMS through the reference's CUDA nms_kernel (csrc/cuda/nms.cu:44-80): the CPU path
+    # (odtk/box.py) is normative for this repo, this pins that both of the reference's paths agree with it
+    for name, k, span, size, n_cls, thr, ndet in (('a', 1500, 600, (8, 200), 80, 0.5, 100), ('b', 400, 200, (10, 150), 2, 0.3, 400)):
+        ctr = r.uniform(20, span, (k, 2))
+        wh = r.uniform(size[0], size[1], (k, 2))
+        bx = np.concatenate([ctr - wh / 2, ctr + wh / 2], 1).astype(np.float32)
+        sc = (r.permutation(k).astype(np.float32) + 1) / k
+        sc[r.random(k) < 0.15] = 0
+        cl = r.integers(0, n_cls, k).astype(np.float32)
+        s, b, c, idx = ref_rotated.nms_axis(sc, bx, cl, thr, ndet)
+        np.savez_compressed(os.path.join(GOLDEN, 'axis_ref_nms_%s.npz' % name), scores=sc, boxes=bx, classes=cl,
+                            thresh=np.float32(thr), ndet=np.int32(ndet), out_scores=s, out_boxes=b, out_classes=c,
+                            out_index=idx)
+    print('wrote', sorted(f for f in os.listdir(GOLDEN) if '_ref_' in f))
 
 
 if __name__ == '__main__':

@@ -3,6 +3,47 @@
 // suppression loop are the reference's code; only the thin host steps around the NMS kernel (which the
 // reference does with thrust/cub, csrc/cuda/nms_iou.cu:286-319) are restated with the C++ standard library.
 
+// reference: odtk::cuda::nms / nms_rotate for ONE image (nms.cu:115-157, nms_iou.cu:286-319):
+//   discard scores <= 0, stable descending sort by score (cub radix sort is stable), the NMS kernel,
+//   stable re-sort with the zeroed scores, first `detections_per_im` entries, zero padding.
+// One emulated thread with num_per_thread = num_detections is the kernel's own schedule serialised:
+// inside one m-iteration threads only read scores[m] and write scores[i > m], so the barrier version
+// and the serial version produce the same memory.
+// out_index[k] = position of output k in the input (-1 for zero-score rows).  Returns the number of outputs.
+template <int NB, typename Kernel>
+static int run_nms(const float *scores, const float *boxes, const float *classes, int count, int detections_per_im,
+                   float *out_scores, float *out_boxes, float *out_classes, int *out_index, Kernel kernel) {
+  std::vector<int> indices;
+  for (int i = 0; i < count; ++i)
+    if (scores[i] > 0.0f) indices.push_back(i);
+  int num = static_cast<int>(indices.size());
+  std::stable_sort(indices.begin(), indices.end(), [&](int a, int b) { return scores[a] > scores[b]; });
+  std::vector<float> sorted(num);
+  for (int k = 0; k < num; ++k) sorted[k] = scores[indices[k]];
+
+  threadIdx = {0, 0, 0}; blockIdx = {0, 0, 0}; blockDim = {1, 1, 1}; gridDim = {1, 1, 1};
+  kernel(num, indices.data(), sorted.data());
+
+  std::vector<int> order(num);
+  std::iota(order.begin(), order.end(), 0);
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return sorted[a] > sorted[b]; });
+  const int n_out = std::min(detections_per_im, num);
+  for (int k = 0; k < detections_per_im; ++k) {
+    out_scores[k] = 0.0f;
+    out_classes[k] = 0.0f;
+    for (int c = 0; c < NB; ++c) out_boxes[NB * k + c] = 0.0f;
+    out_index[k] = -1;
+  }
+  for (int k = 0; k < n_out; ++k) {
+    const int src = indices[order[k]];
+    out_scores[k] = sorted[order[k]];
+    out_classes[k] = classes[src];
+    for (int c = 0; c < NB; ++c) out_boxes[NB * k + c] = boxes[NB * src + c];
+    out_index[k] = sorted[order[k]] > 0.0f ? src : -1;
+  }
+  return n_out;
+}
+
 extern "C" {
 
 // reference: odtk::cuda::iou (nms_iou.cu:377-387) launching iou_cuda_kernel (:324-375) -- with the SAME
@@ -16,47 +57,23 @@ void odtk_ref_iou(const float *boxes, const float *anchors, float *out, int num_
                               reinterpret_cast<const float2 *>(boxes), out);
 }
 
-// reference: odtk::cuda::nms_rotate for ONE image (nms_iou.cu:286-319):
-//   discard scores <= 0 (:295-299), stable descending sort by score (:303-304, cub radix sort is
-//   stable), nms_rotate_kernel (:308-309), stable re-sort with the zeroed scores (:311-312), first
-//   `detections_per_im` entries, zero padding (:314-319).
-// One emulated thread with num_per_thread = num_detections is the kernel's own schedule serialised:
-// inside one m-iteration threads only read scores[m] and write scores[ii > m], so the barrier version
-// and the serial version produce the same memory.
-// out_index[k] = position of output k in the input (-1 padding).  Returns the number of outputs.
 int odtk_ref_nms_rotate(const float *scores, const float *boxes, const float *classes, int count, float nms_thresh,
                         int detections_per_im, float *out_scores, float *out_boxes, float *out_classes,
                         int *out_index) {
-  std::vector<int> indices;
-  for (int i = 0; i < count; ++i)
-    if (scores[i] > 0.0f) indices.push_back(i);
-  int num = static_cast<int>(indices.size());
-  std::stable_sort(indices.begin(), indices.end(), [&](int a, int b) { return scores[a] > scores[b]; });
-  std::vector<float> sorted(num);
-  for (int k = 0; k < num; ++k) sorted[k] = scores[indices[k]];
+  return run_nms<6>(scores, boxes, classes, count, detections_per_im, out_scores, out_boxes, out_classes, out_index,
+                    [&](int num, const int *indices, float *sorted) {
+                      odtk::cuda::nms_rotate_kernel(num, nms_thresh, num, indices, sorted, classes,
+                                                    reinterpret_cast<const float6 *>(boxes));
+                    });
+}
 
-  threadIdx = {0, 0, 0}; blockIdx = {0, 0, 0}; blockDim = {1, 1, 1}; gridDim = {1, 1, 1};
-  odtk::cuda::nms_rotate_kernel(num, nms_thresh, num, indices.data(), sorted.data(), classes,
-                                reinterpret_cast<const float6 *>(boxes));
-
-  std::vector<int> order(num);
-  std::iota(order.begin(), order.end(), 0);
-  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return sorted[a] > sorted[b]; });
-  const int n_out = std::min(detections_per_im, num);
-  for (int k = 0; k < detections_per_im; ++k) {
-    out_scores[k] = 0.0f;
-    out_classes[k] = 0.0f;
-    for (int c = 0; c < 6; ++c) out_boxes[6 * k + c] = 0.0f;
-    out_index[k] = -1;
-  }
-  for (int k = 0; k < n_out; ++k) {
-    const int src = indices[order[k]];
-    out_scores[k] = sorted[order[k]];
-    out_classes[k] = classes[src];
-    for (int c = 0; c < 6; ++c) out_boxes[6 * k + c] = boxes[6 * src + c];
-    out_index[k] = sorted[order[k]] > 0.0f ? src : -1;
-  }
-  return n_out;
+int odtk_ref_nms(const float *scores, const float *boxes, const float *classes, int count, float nms_thresh,
+                 int detections_per_im, float *out_scores, float *out_boxes, float *out_classes, int *out_index) {
+  return run_nms<4>(scores, boxes, classes, count, detections_per_im, out_scores, out_boxes, out_classes, out_index,
+                    [&](int num, const int *indices, float *sorted) {
+                      odtk::cuda::nms_kernel(num, nms_thresh, num, indices, sorted, classes,
+                                             reinterpret_cast<const float4 *>(boxes));
+                    });
 }
 
 }  // extern "C"

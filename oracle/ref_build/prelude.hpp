@@ -1,5 +1,5 @@
 // prelude.hpp -- TEST INFRASTRUCTURE ONLY.  The few CUDA names the reference's device code uses
-// (csrc/cuda/nms_iou.cu:41-258, :324-375 and the float6 struct of csrc/cuda/utils.h), provided for a
+// (csrc/cuda/nms_iou.cu:41-258, :324-375, csrc/cuda/nms.cu:44-80 and the float6 struct of csrc/cuda/utils.h), provided for a
 // plain host C++ compiler so that the reference's OWN rotated-IoU / rotated-NMS source can be compiled
 // with g++ and run on the CPU (oracle/ref_build/build_ref.py splices: this file + the reference lines
 // read from /root/reference at build time + harness.cpp -> oracle/_ref/, never into the repository).
@@ -28,3 +28,5 @@ static inline void __syncthreads() {}
 
 using std::abs;
 using std::isnan;
+using std::max;
+using std::min;

@@ -26,6 +26,8 @@ def library():
         lib.odtk_ref_iou.argtypes = [_f, _f, _f, ctypes.c_int, ctypes.c_int]
         lib.odtk_ref_nms_rotate.restype = ctypes.c_int
         lib.odtk_ref_nms_rotate.argtypes = [_f, _f, _f, ctypes.c_int, ctypes.c_float, ctypes.c_int, _f, _f, _f, _i]
+        lib.odtk_ref_nms.restype = ctypes.c_int
+        lib.odtk_ref_nms.argtypes = lib.odtk_ref_nms_rotate.argtypes
         _lib = lib
     return _lib
 
@@ -46,13 +48,24 @@ def iou_pairs(boxes, anchors):
 def nms_rotate(scores, boxes, classes, thresh, ndet):
     """One image: scores [K], boxes [K, 6], classes [K] -> (scores [ndet], boxes [ndet, 6], classes [ndet],
     kept input positions [ndet], -1 padded), following odtk::cuda::nms_rotate."""
+    return _nms(scores, boxes, classes, thresh, ndet, 6)
+
+
+def nms_axis(scores, boxes, classes, thresh, ndet):
+    """Same with [K, 4] boxes through the reference's nms_kernel (csrc/cuda/nms.cu:44-80)."""
+    return _nms(scores, boxes, classes, thresh, ndet, 4)
+
+
+def _nms(scores, boxes, classes, thresh, ndet, nb):
     scores, boxes, classes = _c(scores), _c(boxes), _c(classes)
     k = scores.shape[0]
+    assert boxes.shape == (k, nb)
     s = np.empty(ndet, np.float32)
-    b = np.empty((ndet, 6), np.float32)
+    b = np.empty((ndet, nb), np.float32)
     c = np.empty(ndet, np.float32)
     idx = np.empty(ndet, np.int32)
-    library().odtk_ref_nms_rotate(scores.ctypes.data_as(_f), boxes.ctypes.data_as(_f), classes.ctypes.data_as(_f), k,
+    fn = library().odtk_ref_nms_rotate if nb == 6 else library().odtk_ref_nms
+    fn(scores.ctypes.data_as(_f), boxes.ctypes.data_as(_f), classes.ctypes.data_as(_f), k,
                                   float(thresh), int(ndet), s.ctypes.data_as(_f), b.ctypes.data_as(_f),
                                   c.ctypes.data_as(_f), idx.ctypes.data_as(_i))
     return s, b, c, idx.astype(np.int64)

@@ -131,3 +131,14 @@ def test_hip_rotated_nms_equals_reference_source_fixture(path):
     assert np.array_equal(out[0][0].cpu().numpy().view(np.uint32), z['out_scores'].view(np.uint32))
     assert np.array_equal(out[1][0].cpu().numpy()[kept].view(np.uint32), z['out_boxes'][kept].view(np.uint32))
     assert np.array_equal(out[2][0].cpu().numpy()[kept], z['out_classes'][kept])
+
+
+@pytest.mark.parametrize('path', sorted(glob.glob(os.path.join(_GOLDEN, 'axis_ref_nms_*.npz'))), ids=os.path.basename)
+def test_hip_axis_nms_equals_reference_cuda_kernel_fixture(path):
+    z = np.load(path)
+    out = _C.nms(torch.from_numpy(z['scores'])[None].cuda(), torch.from_numpy(z['boxes'])[None].cuda(),
+                 torch.from_numpy(z['classes'])[None].cuda(), float(z['thresh']), int(z['ndet']), False, return_indices=True)
+    kept = z['out_index'] >= 0
+    assert np.array_equal(out[3][0].cpu().numpy().astype(np.int64), z['out_index'])
+    assert np.array_equal(out[0][0].cpu().numpy().view(np.uint32), z['out_scores'].view(np.uint32))
+    assert np.array_equal(out[1][0].cpu().numpy()[kept].view(np.uint32), z['out_boxes'][kept].view(np.uint32))

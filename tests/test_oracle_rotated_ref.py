@@ -45,9 +45,28 @@ def test_c_oracle_rotated_nms_equals_reference_source(path):
     assert 0 < kept.sum() and (kept.sum() < (z['scores'] > 0).sum())   # something kept, something suppressed
 
 
+@pytest.mark.parametrize('path', sorted(glob.glob(os.path.join(GOLDEN, 'axis_ref_nms_*.npz'))), ids=os.path.basename)
+def test_axis_nms_oracles_equal_the_reference_cuda_kernel(path):
+    """csrc/cuda/nms.cu:44-80 compiled for the CPU: on tie-free finite inputs the reference's CUDA path and
+    its CPU path (normative here) keep the same detections; both oracles reproduce them."""
+    import torch
+    from oracle import box_oracle
+    z = np.load(path)
+    ndet, thr = int(z['ndet']), float(z['thresh'])
+    kept = z['out_index'] >= 0
+    s, b, c, idx = c_oracle.nms(z['scores'][None], z['boxes'][None], z['classes'][None], thr, ndet)
+    assert np.array_equal(idx[0], z['out_index']) and np.array_equal(_bits(s[0]), _bits(z['out_scores']))
+    assert np.array_equal(_bits(b[0][kept]), _bits(z['out_boxes'][kept]))
+    t = box_oracle.nms(torch.from_numpy(z['scores'])[None], torch.from_numpy(z['boxes'])[None],
+                       torch.from_numpy(z['classes'])[None], thr, ndet, return_indices=True)
+    assert np.array_equal(t[3][0].numpy(), z['out_index']) and np.array_equal(_bits(t[0][0].numpy()), _bits(z['out_scores']))
+    assert 0 < kept.sum() < (z['scores'] > 0).sum()
+
+
 def test_fixture_set_is_complete():
     assert len(glob.glob(os.path.join(GOLDEN, 'rotated_ref_iou_*.npz'))) == 3
     assert len(glob.glob(os.path.join(GOLDEN, 'rotated_ref_nms_*.npz'))) == 4
+    assert len(glob.glob(os.path.join(GOLDEN, 'axis_ref_nms_*.npz'))) == 2
 
 
 @pytest.mark.skipif(not ref_rotated.available(), reason='oracle/_ref/libodtk_ref_rotated.so not built (needs /root/reference)')
