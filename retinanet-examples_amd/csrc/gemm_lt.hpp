@@ -173,7 +173,14 @@ inline int gemm_bias_act(void *y, const void *x, const void *w, const float *bia
   if (it == plans().end()) {
     Plan p;
     const int rc = make_plan(&p, y, x, w, bias, residual, m, n, k, dtype, relu, workspace, workspace_size, stream);
-    if (rc != ODTK_OK) return rc;
+    if (rc != ODTK_OK) {                           // nothing half-built stays behind
+      Api &a = api();
+      if (p.a) a.LayoutDestroy(p.a);
+      if (p.b) a.LayoutDestroy(p.b);
+      if (p.c) a.LayoutDestroy(p.c);
+      if (p.desc) a.DescDestroy(p.desc);
+      return rc;
+    }
     it = plans().emplace(key, p).first;
   }
   Plan &p = it->second;
