@@ -25,7 +25,12 @@ Pinning status
   tests/golden/rotated_ref_*.npz hold its outputs (oracle/gen_golden_rotated.py); the C restatement
   oracle/c/odtk_oracle.c reproduces them bit for bit, live runs included
   (tests/test_oracle_rotated_ref.py), and so do the HIP kernels (tests/test_gpu_rotated.py).
-* rotated decode: PARITY UNPINNED.  csrc/cuda/decode_rotate.cu is thrust/cub host code around one
-  device lambda and has no runnable CPU counterpart (odtk/box.py:303 shape bug); oracle/c restates
-  it with box.py's conventions and is checked against the axis-aligned decode on the shared arithmetic.
+* rotated (and axis-aligned) decode, CUDA path: the per-detection gather + box lambdas of
+  csrc/cuda/decode.cu:121-159 and decode_rotate.cu:116-167 are compiled the same way and applied to the
+  indices the CPU-convention selection keeps (tests/golden/decode_ref_*.npz): index decomposition, delta
+  gather layout, classes, scores and the sin/cos passthrough are reproduced exactly; the box agrees
+  within 1e-4 once the CPU path's two-sided clamp is applied (the CUDA lambda clamps one side, sums the
+  centre in another order and uses a float exp -- documented conventions, the CPU path is normative).
+  Threshold / top-k selection of the rotated decode has no runnable reference of its own; it is the
+  same code as the axis-aligned selection, which is pinned to box.py.
 """

@@ -77,6 +77,29 @@ def main():
         np.savez_compressed(os.path.join(GOLDEN, 'axis_ref_nms_%s.npz' % name), scores=sc, boxes=bx, classes=cl,
                             thresh=np.float32(thr), ndet=np.int32(ndet), out_scores=s, out_boxes=b, out_classes=c,
                             out_index=idx)
+    # decode: the reference's CUDA gather + box lambdas (decode.cu:121-159, decode_rotate.cu:116-167) applied to the
+    # indices the CPU-convention selection keeps.  Index decomposition, gather layout and sin/cos passthrough must be
+    # exact; the box differs from the CPU path only by documented conventions (one- vs two-sided clamp, the order of
+    # the centre sum, float exp) -- tests apply the two-sided clamp and a 1e-4 tolerance.
+    import math
+    sys.path.insert(0, os.path.join(ROOT, 'retinanet-examples_amd'))
+    from odtk import box as box_ops
+    from oracle import c_oracle
+    ratios, scales = [1.0, 2.0, 0.5], [4 * 2 ** (i / 3) for i in range(3)]
+    for name, rotated, n_cls, h, w, stride, thr, top_n in (('axis', False, 7, 19, 23, 16, 0.4, 500), ('rotated', True, 5, 11, 14, 32, 0.5, 300)):
+        if rotated:
+            anchors = box_ops.generate_anchors_rotated(stride, ratios, scales, [-math.pi / 6, 0, math.pi / 6])[0].numpy()
+        else:
+            anchors = box_ops.generate_anchors(stride, ratios, scales).numpy()
+        a, nb = anchors.shape[0], 6 if rotated else 4
+        cls = r.random((a * n_cls, h, w)).astype(np.float32)
+        dl = (r.standard_normal((a * nb, h, w)) * 0.3).astype(np.float32)
+        idx = c_oracle.decode(cls[None], dl[None], stride, thr, top_n, anchors, rotated=rotated)[3][0]
+        idx = idx[idx >= 0].astype(np.int32)
+        s, b, c = ref_rotated.decode_gather(idx, cls, dl, stride, anchors, n_cls, rotated)
+        np.savez_compressed(os.path.join(GOLDEN, 'decode_ref_%s.npz' % name), cls=cls, deltas=dl, anchors=anchors,
+                            stride=np.int32(stride), thresh=np.float32(thr), top_n=np.int32(top_n), num_classes=np.int32(n_cls),
+                            indices=idx, out_scores=s, out_boxes=b, out_classes=c)
     print('wrote', sorted(f for f in os.listdir(GOLDEN) if '_ref_' in f))
 
 

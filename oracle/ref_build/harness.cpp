@@ -76,4 +76,29 @@ int odtk_ref_nms(const float *scores, const float *boxes, const float *classes, 
                     });
 }
 
+// reference: the gather + box lambda of odtk::cuda::decode / decode_rotate applied to `count` flat score indices
+// of ONE image (decode.cu:119-159, decode_rotate.cu:114-167).  Which indices survive and in which order is the
+// caller's business (threshold / top-k are thrust/cub host code); this is the part that turns an index into
+// (score, box, class): index decomposition, delta gather layout, anchor arithmetic, clamps, sin/cos passthrough.
+void odtk_ref_decode_gather(const int *indices, int count, int rotated, const float *in_scores, const float *in_boxes,
+                            int height, int width, int scale, int num_anchors, int num_classes, const float *anchors,
+                            float *out_scores, float *out_boxes, float *out_classes) {
+  std::vector<float> a(anchors, anchors + 4 * num_anchors);
+  for (int k = 0; k < count; ++k) {
+    if (rotated) {
+      auto t = odtk::cuda::decode_rotate_gather(indices[k], height, width, scale, num_anchors, num_classes, true, a.data(),
+                                                in_scores, in_boxes);
+      out_scores[k] = t.score; out_classes[k] = static_cast<float>(t.cls);
+      const float v[6] = {t.box.x1, t.box.y1, t.box.x2, t.box.y2, t.box.s, t.box.c};
+      for (int c = 0; c < 6; ++c) out_boxes[6 * k + c] = v[c];
+    } else {
+      auto t = odtk::cuda::decode_gather(indices[k], height, width, scale, num_anchors, num_classes, true, a.data(),
+                                         in_scores, in_boxes);
+      out_scores[k] = t.score; out_classes[k] = static_cast<float>(t.cls);
+      const float v[4] = {t.box.x, t.box.y, t.box.z, t.box.w};
+      for (int c = 0; c < 4; ++c) out_boxes[4 * k + c] = v[c];
+    }
+  }
+}
+
 }  // extern "C"

@@ -27,6 +27,13 @@ static odtk_ref_dim3 threadIdx = {0, 0, 0}, blockIdx = {0, 0, 0}, blockDim = {1,
 static inline void __syncthreads() {}
 
 using std::abs;
+using std::exp;        // exp(float) must stay a float function, as in device code
 using std::isnan;
 using std::max;
 using std::min;
+
+// what the decode lambdas return: thrust::make_tuple(score, box, class)
+template <typename Box> struct odtk_ref_tuple { float score; Box box; int cls; };
+namespace thrust {
+template <typename Box> static inline odtk_ref_tuple<Box> make_tuple(float s, Box b, int c) { return odtk_ref_tuple<Box>{s, b, c}; }
+}

@@ -28,6 +28,8 @@ def library():
         lib.odtk_ref_nms_rotate.argtypes = [_f, _f, _f, ctypes.c_int, ctypes.c_float, ctypes.c_int, _f, _f, _f, _i]
         lib.odtk_ref_nms.restype = ctypes.c_int
         lib.odtk_ref_nms.argtypes = lib.odtk_ref_nms_rotate.argtypes
+        lib.odtk_ref_decode_gather.restype = None
+        lib.odtk_ref_decode_gather.argtypes = [_i, ctypes.c_int, ctypes.c_int, _f, _f] + [ctypes.c_int] * 5 + [_f, _f, _f, _f]
         _lib = lib
     return _lib
 
@@ -69,3 +71,21 @@ def _nms(scores, boxes, classes, thresh, ndet, nb):
                                   float(thresh), int(ndet), s.ctypes.data_as(_f), b.ctypes.data_as(_f),
                                   c.ctypes.data_as(_f), idx.ctypes.data_as(_i))
     return s, b, c, idx.astype(np.int64)
+
+
+def decode_gather(indices, scores, deltas, stride, anchors, num_classes, rotated=False):
+    """The reference's own per-detection lambda (decode.cu:121-159 / decode_rotate.cu:116-167) on ONE image:
+    flat score indices [K] -> (scores [K], boxes [K, 4|6], classes [K]).  scores [A*C, H, W], deltas [A*nb, H, W]."""
+    scores, deltas, anchors = _c(scores), _c(deltas), _c(anchors).reshape(-1, 4)
+    idx = np.ascontiguousarray(indices, dtype=np.int32)
+    nb = 6 if rotated else 4
+    a = anchors.shape[0]
+    _, h, w = scores.shape
+    assert scores.shape[0] == a * num_classes and deltas.shape == (a * nb, h, w)
+    k = idx.shape[0]
+    s, b, c = np.empty(k, np.float32), np.empty((k, nb), np.float32), np.empty(k, np.float32)
+    library().odtk_ref_decode_gather(idx.ctypes.data_as(_i), k, 1 if rotated else 0, scores.ctypes.data_as(_f),
+                                     deltas.ctypes.data_as(_f), h, w, int(stride), a, int(num_classes),
+                                     anchors.ctypes.data_as(_f), s.ctypes.data_as(_f), b.ctypes.data_as(_f),
+                                     c.ctypes.data_as(_f))
+    return s, b, c

@@ -142,3 +142,15 @@ def test_hip_axis_nms_equals_reference_cuda_kernel_fixture(path):
     assert np.array_equal(out[3][0].cpu().numpy().astype(np.int64), z['out_index'])
     assert np.array_equal(out[0][0].cpu().numpy().view(np.uint32), z['out_scores'].view(np.uint32))
     assert np.array_equal(out[1][0].cpu().numpy()[kept].view(np.uint32), z['out_boxes'][kept].view(np.uint32))
+
+
+@pytest.mark.parametrize('name', ['axis', 'rotated'])
+def test_hip_decode_against_the_reference_cuda_lambda(name):
+    from test_oracle_rotated_ref import _check_decode_against_reference_lambda
+    z = np.load(os.path.join(_GOLDEN, 'decode_ref_%s.npz' % name))
+    rotated = name == 'rotated'
+    out = _C.decode_levels([torch.from_numpy(z['cls'])[None].cuda()], [torch.from_numpy(z['deltas'])[None].cuda()],
+                           [torch.from_numpy(z['anchors'])], [int(z['stride'])], float(z['thresh']), int(z['top_n']), rotated,
+                           return_indices=True)
+    _check_decode_against_reference_lambda(z, out[0][0].cpu().numpy(), out[1][0].cpu().numpy(), out[2][0].cpu().numpy(),
+                                           out[3][0].cpu().numpy().astype(np.int64))

@@ -63,10 +63,41 @@ def test_axis_nms_oracles_equal_the_reference_cuda_kernel(path):
     assert 0 < kept.sum() < (z['scores'] > 0).sum()
 
 
+def _check_decode_against_reference_lambda(z, s, b, c, idx):
+    """(s, b, c, idx) = one image's decode output of the implementation under test."""
+    n = len(z['indices'])
+    assert np.array_equal(idx[:n], z['indices']) and (idx[n:] < 0).all()
+    assert np.array_equal(_bits(s[:n]), _bits(z['out_scores'])) and np.array_equal(c[:n], z['out_classes'])
+    h, w = z['cls'].shape[1:]
+    lim = np.array([w, h, w, h], np.float32) * np.float32(z['stride']) - 1
+    ref = np.clip(z['out_boxes'][:, :4], 0, lim)                        # the CPU path's two-sided clamp (box.py:105-111)
+    assert np.abs(b[:n, :4] - ref).max() <= 1e-4                        # centre-sum order + float exp: a few ulp
+    if z['out_boxes'].shape[1] == 6:
+        assert np.array_equal(_bits(b[:n, 4:]), _bits(z['out_boxes'][:, 4:]))   # sin, cos pass through untouched
+    assert (z['out_boxes'][:, :4] != ref).any()                         # the clamp convention is exercised
+
+
+@pytest.mark.parametrize('name', ['axis', 'rotated'])
+def test_decode_oracles_against_the_reference_cuda_lambda(name):
+    """decode.cu:121-159 / decode_rotate.cu:116-167 compiled for the CPU: flat index -> (score, box, class)."""
+    z = np.load(os.path.join(GOLDEN, 'decode_ref_%s.npz' % name))
+    rotated = name == 'rotated'
+    s, b, c, idx = c_oracle.decode(z['cls'][None], z['deltas'][None], int(z['stride']), float(z['thresh']), int(z['top_n']),
+                                   z['anchors'], rotated=rotated)
+    _check_decode_against_reference_lambda(z, s[0], b[0], c[0], idx[0])
+    if not rotated:                                                      # the torch restatement (pinned to box.py) as well
+        import torch
+        from oracle import box_oracle
+        t = box_oracle.decode(torch.from_numpy(z['cls'])[None], torch.from_numpy(z['deltas'])[None], int(z['stride']),
+                              float(z['thresh']), int(z['top_n']), torch.from_numpy(z['anchors']), return_indices=True)
+        _check_decode_against_reference_lambda(z, t[0][0].numpy(), t[1][0].numpy(), t[2][0].numpy(), t[3][0].numpy())
+
+
 def test_fixture_set_is_complete():
     assert len(glob.glob(os.path.join(GOLDEN, 'rotated_ref_iou_*.npz'))) == 3
     assert len(glob.glob(os.path.join(GOLDEN, 'rotated_ref_nms_*.npz'))) == 4
     assert len(glob.glob(os.path.join(GOLDEN, 'axis_ref_nms_*.npz'))) == 2
+    assert len(glob.glob(os.path.join(GOLDEN, 'decode_ref_*.npz'))) == 2
 
 
 @pytest.mark.skipif(not ref_rotated.available(), reason='oracle/_ref/libodtk_ref_rotated.so not built (needs /root/reference)')
