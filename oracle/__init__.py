@@ -20,11 +20,11 @@ Pinning status
   geometry -- Vector / Line / IntersectionArea, nms_rotate_kernel, iou_cuda_kernel
   (csrc/cuda/nms_iou.cu:41-258, :324-375) -- is plain C++ once a dozen CUDA names exist:
   oracle/ref_build/build_ref.py reads those lines from /root/reference where they lie, wraps them
-  between prelude.hpp and harness.cpp and builds oracle/_ref/libodtk_ref_rotated.so with g++ in IEEE
+  between prelude.hpp and harness.cpp and builds oracle/_ref/libodtk_ref_native.so with g++ in IEEE
   mode (the reference's nvcc build used --use_fast_math, whose bits nothing else reproduces).
-  tests/golden/rotated_ref_*.npz hold its outputs (oracle/gen_golden_rotated.py); the C restatement
+  tests/golden/rotated_ref_*.npz hold its outputs (oracle/gen_golden_native.py); the C restatement
   oracle/c/odtk_oracle.c reproduces them bit for bit, live runs included
-  (tests/test_oracle_rotated_ref.py), and so do the HIP kernels (tests/test_gpu_rotated.py).
+  (tests/test_oracle_native_ref.py), and so do the HIP kernels (tests/test_gpu_rotated.py).
 * rotated (and axis-aligned) decode, CUDA path: the per-detection gather + box lambdas of
   csrc/cuda/decode.cu:121-159 and decode_rotate.cu:116-167 are compiled the same way and applied to the
   indices the CPU-convention selection keeps (tests/golden/decode_ref_*.npz): index decomposition, delta

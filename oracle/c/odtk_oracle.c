@@ -4,7 +4,7 @@
  * ctypes by oracle/c_oracle.py, used by tests/ as a checker.  Never linked into the product.
  *
  * Pinning: the rotated IoU / rotated NMS below reproduce, bit for bit, the reference's own nms_iou.cu device
- * code compiled for the CPU (oracle/ref_build, tests/test_oracle_rotated_ref.py); decode / axis nms are
+ * code compiled for the CPU (oracle/ref_build, tests/test_oracle_native_ref.py); decode / axis nms are
  * tied to the torch restatement that is pinned to the reference's box.py (tests/test_oracle_c.py).
  *
  * What is restated, and from where (paths relative to /root/reference):

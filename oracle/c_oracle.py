@@ -2,7 +2,7 @@
 
 numpy in / numpy out.  See oracle/c/odtk_oracle.c for what is restated and from which reference
 lines.  The rotated IoU / NMS functions are pinned bit for bit to the reference's own device code compiled
-for the CPU (oracle/ref_rotated.py, tests/test_oracle_rotated_ref.py), the decode gather / box step to its
+for the CPU (oracle/ref_native.py, tests/test_oracle_native_ref.py), the decode gather / box step to its
 decode lambdas (exact layout, boxes within 1e-4 after aligning the clamp convention)."""
 import ctypes
 import os

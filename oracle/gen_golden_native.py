@@ -1,9 +1,9 @@
 #!/usr/bin/env python
 """Golden vectors for the rotated path, produced by the reference's OWN device code compiled for the CPU
-(oracle/ref_build/build_ref.py -> oracle/_ref/libodtk_ref_rotated.so): tests/golden/rotated_ref_*.npz.
+(oracle/ref_build/build_ref.py -> oracle/_ref/libodtk_ref_native.so): tests/golden/rotated_ref_*.npz.
 Run in the build container (needs /root/reference to build the library); the fixtures travel instead of it.
 
-    python oracle/gen_golden_rotated.py
+    python oracle/gen_golden_native.py
 """
 import os
 import sys
@@ -12,7 +12,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from oracle import ref_rotated                                   # noqa: E402
+from oracle import ref_native                                   # noqa: E402
 from oracle.ref_build import build_ref                           # noqa: E402
 
 GOLDEN = os.path.join(ROOT, 'tests', 'golden')
@@ -50,7 +50,7 @@ def main():
             a[:10] = b[:10]                                        # identical quads: the 0.001 pad rule
             a[10:14, :2] = b[10:14, :2]                            # one shared corner
         np.savez_compressed(os.path.join(GOLDEN, 'rotated_ref_iou_%s.npz' % name), boxes=b, anchors=a,
-                            iou=ref_rotated.iou_pairs(b, a))
+                            iou=ref_native.iou_pairs(b, a))
     # rotated NMS, one image each
     for name, k, span, size, n_cls, thr, ndet, unit in (('a', 600, 320, (4, 90), 3, 0.5, 100, True),
                                                         ('b', 1000, 500, (8, 200), 80, 0.3, 100, True),
@@ -60,7 +60,7 @@ def main():
         sc = (r.permutation(k).astype(np.float32) + 1) / k        # tie-free
         sc[r.random(k) < 0.15] = 0
         cl = r.integers(0, n_cls, k).astype(np.float32)
-        s, b, c, idx = ref_rotated.nms_rotate(sc, bx, cl, thr, ndet)
+        s, b, c, idx = ref_native.nms_rotate(sc, bx, cl, thr, ndet)
         np.savez_compressed(os.path.join(GOLDEN, 'rotated_ref_nms_%s.npz' % name), scores=sc, boxes=bx, classes=cl,
                             thresh=np.float32(thr), ndet=np.int32(ndet), out_scores=s, out_boxes=b, out_classes=c,
                             out_index=idx)
@@ -73,7 +73,7 @@ def main():
         sc = (r.permutation(k).astype(np.float32) + 1) / k
         sc[r.random(k) < 0.15] = 0
         cl = r.integers(0, n_cls, k).astype(np.float32)
-        s, b, c, idx = ref_rotated.nms_axis(sc, bx, cl, thr, ndet)
+        s, b, c, idx = ref_native.nms_axis(sc, bx, cl, thr, ndet)
         np.savez_compressed(os.path.join(GOLDEN, 'axis_ref_nms_%s.npz' % name), scores=sc, boxes=bx, classes=cl,
                             thresh=np.float32(thr), ndet=np.int32(ndet), out_scores=s, out_boxes=b, out_classes=c,
                             out_index=idx)
@@ -96,7 +96,7 @@ def main():
         dl = (r.standard_normal((a * nb, h, w)) * 0.3).astype(np.float32)
         idx = c_oracle.decode(cls[None], dl[None], stride, thr, top_n, anchors, rotated=rotated)[3][0]
         idx = idx[idx >= 0].astype(np.int32)
-        s, b, c = ref_rotated.decode_gather(idx, cls, dl, stride, anchors, n_cls, rotated)
+        s, b, c = ref_native.decode_gather(idx, cls, dl, stride, anchors, n_cls, rotated)
         np.savez_compressed(os.path.join(GOLDEN, 'decode_ref_%s.npz' % name), cls=cls, deltas=dl, anchors=anchors,
                             stride=np.int32(stride), thresh=np.float32(thr), top_n=np.int32(top_n), num_classes=np.int32(n_cls),
                             indices=idx, out_scores=s, out_boxes=b, out_classes=c)

@@ -1,14 +1,15 @@
-"""ctypes wrapper over oracle/_ref/libodtk_ref_rotated.so (TEST INFRASTRUCTURE ONLY): the reference's OWN
-rotated-IoU / rotated-NMS device code (csrc/cuda/nms_iou.cu:41-258, :324-375), compiled for the CPU by
-oracle/ref_build/build_ref.py.  Used to pin oracle/c/odtk_oracle.c (and through it the HIP kernels) to the
-reference source itself, and to generate tests/golden/rotated_ref_*.npz (oracle/gen_golden_rotated.py).
+"""ctypes wrapper over oracle/_ref/libodtk_ref_native.so (TEST INFRASTRUCTURE ONLY): the reference's OWN
+device code -- rotated IoU / rotated NMS (csrc/cuda/nms_iou.cu:41-258, :324-375), the axis-aligned nms_kernel
+(nms.cu:44-80) and the decode gather lambdas (decode.cu:121-159, decode_rotate.cu:116-167) -- compiled for
+the CPU by oracle/ref_build/build_ref.py.  Used to pin oracle/c/odtk_oracle.c (and through it the HIP kernels) to the
+reference source itself, and to generate tests/golden/rotated_ref_*.npz (oracle/gen_golden_native.py).
 `available()` is False where the library was not built (e.g. /root/reference absent and no prebuilt .so)."""
 import ctypes
 import os
 
 import numpy as np
 
-_SO = os.path.join(os.path.dirname(os.path.abspath(__file__)), '_ref', 'libodtk_ref_rotated.so')
+_SO = os.path.join(os.path.dirname(os.path.abspath(__file__)), '_ref', 'libodtk_ref_native.so')
 _lib = None
 _f = ctypes.POINTER(ctypes.c_float)
 _i = ctypes.POINTER(ctypes.c_int)

@@ -1,6 +1,6 @@
 """Rotated path on the GPU (decode_rotate, rotated NMS, pairwise IoU) against the C restatement of
 csrc/cuda/decode_rotate.cu + nms_iou.cu (oracle/c; its rotated IoU / NMS are pinned bit for bit to the
-reference's own device code compiled for the CPU, tests/test_oracle_rotated_ref.py -- the fixtures of
+reference's own device code compiled for the CPU, tests/test_oracle_native_ref.py -- the fixtures of
 that pinning are also applied to the HIP kernels directly at the end of this file).  Both sides evaluate the same IEEE fp32 expressions in the
 same order, so everything -- including IoU values -- is compared BIT FOR BIT; axis-aligned boxes
 are also compared bit-for-bit here (the C oracle uses the same correctly rounded exp)."""
@@ -107,7 +107,7 @@ def test_pairwise_iou_vs_c_oracle():
     assert tuple(empty.shape) == (3000, 0)
 
 
-# ---- fixtures produced by the reference's own device code (oracle/ref_build, tests/test_oracle_rotated_ref.py) ----
+# ---- fixtures produced by the reference's own device code (oracle/ref_build, tests/test_oracle_native_ref.py) ----
 import glob
 import os
 
@@ -146,7 +146,7 @@ def test_hip_axis_nms_equals_reference_cuda_kernel_fixture(path):
 
 @pytest.mark.parametrize('name', ['axis', 'rotated'])
 def test_hip_decode_against_the_reference_cuda_lambda(name):
-    from test_oracle_rotated_ref import _check_decode_against_reference_lambda
+    from test_oracle_native_ref import _check_decode_against_reference_lambda
     z = np.load(os.path.join(_GOLDEN, 'decode_ref_%s.npz' % name))
     rotated = name == 'rotated'
     out = _C.decode_levels([torch.from_numpy(z['cls'])[None].cuda()], [torch.from_numpy(z['deltas'])[None].cuda()],

@@ -14,7 +14,7 @@ import os
 import numpy as np
 import pytest
 
-from oracle import c_oracle, ref_rotated
+from oracle import c_oracle, ref_native
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 
@@ -100,7 +100,7 @@ def test_fixture_set_is_complete():
     assert len(glob.glob(os.path.join(GOLDEN, 'decode_ref_*.npz'))) == 2
 
 
-@pytest.mark.skipif(not ref_rotated.available(), reason='oracle/_ref/libodtk_ref_rotated.so not built (needs /root/reference)')
+@pytest.mark.skipif(not ref_native.available(), reason='oracle/_ref/libodtk_ref_native.so not built (needs /root/reference)')
 @pytest.mark.parametrize('seed', range(6))
 def test_live_against_the_compiled_reference(seed):
     r = np.random.default_rng(900 + seed)
@@ -114,7 +114,7 @@ def test_live_against_the_compiled_reference(seed):
     scores[r.random(k) < 0.2] = 0
     classes = r.integers(0, int(r.choice([1, 4, 80])), k).astype(np.float32)
     thr, ndet = float(r.choice([0.0, 0.2, 0.5, 0.8])), int(r.choice([20, 100]))
-    rs, rb, rc, ri = ref_rotated.nms_rotate(scores, boxes, classes, thr, ndet)
+    rs, rb, rc, ri = ref_native.nms_rotate(scores, boxes, classes, thr, ndet)
     s, b, c, idx = c_oracle.nms(scores[None], boxes[None], classes[None], thr, ndet, rotated=True)
     assert np.array_equal(idx[0], ri) and np.array_equal(_bits(s[0]), _bits(rs))
     # pairwise: corners of the same boxes, rotated about their centres
@@ -126,4 +126,4 @@ def test_live_against_the_compiled_reference(seed):
         y = dy * bx[:, 5:6] + dx * bx[:, 4:5] + cy[:, None]
         return np.stack([x, y], 2).reshape(-1, 8).astype(np.float32)
     q = corners(boxes[:40])
-    assert np.array_equal(_bits(c_oracle.iou_pairs(q[:15], q)), _bits(ref_rotated.iou_pairs(q[:15], q)))
+    assert np.array_equal(_bits(c_oracle.iou_pairs(q[:15], q)), _bits(ref_native.iou_pairs(q[:15], q)))
