@@ -5,8 +5,8 @@ The reference's native library cannot be built here (nvcc, thrust, cub, TensorRT
 part of csrc/cuda/nms_iou.cu that does the geometry -- Vector / Line / rotateLeft / IntersectionArea,
 nms_rotate_kernel and iou_cuda_kernel -- and the axis-aligned nms_kernel of csrc/cuda/nms.cu are plain C++
 once a dozen CUDA names exist.  This recipe reads
-those line ranges from /root/reference WHERE THEY LIE, splices them between prelude.hpp and harness.cpp
-into oracle/_ref/ref_native.cpp (git-ignored, never committed) and builds oracle/_ref/libodtk_ref_native.so
+those line ranges from /root/reference WHERE THEY LIE, splices them between prelude.hpp and harness.cpp in
+memory, pipes the translation unit to the compiler and builds oracle/_ref/libodtk_ref_native.so
 with g++ -O2 -ffp-contract=off (IEEE reading of the source; the reference's nvcc build used --use_fast_math).
 
     python oracle/ref_build/build_ref.py          # no-op with a message when /root/reference is absent
@@ -56,26 +56,22 @@ def build(verbose=True):
     pairwise = _between(cu_lines, r'^__global__ void iou_cuda_kernel', r'^int iou\(', 'iou kernel')  # nms_iou.cu:324-375
     axis = _between(open(ax).read().split('\n'), r'^__global__ void nms_kernel', r'^int nms\(', 'nms kernel')   # nms.cu:44-80
     os.makedirs(OUT, exist_ok=True)
-    src = os.path.join(OUT, 'ref_native.cpp')
-    with open(src, 'w') as f:
-        f.write('// GENERATED by oracle/ref_build/build_ref.py from %s -- do not commit.\n' % REF)
-        f.write(open(os.path.join(HERE, 'prelude.hpp')).read())
-        f.write('\n'.join(float6) + '\n')
-        f.write('\n'.join(device) + '\n')
-        f.write('\n'.join(pairwise) + '\n')
-        f.write('\n'.join(axis) + '\n')
-        # the per-detection gather + box lambdas of decode.cu:121-159 / decode_rotate.cu:116-167, each
-        # given a name and the variables it captures (same names and types as in the enclosing function)
-        capt = ('(int i, size_t height, size_t width, size_t scale, size_t num_anchors, size_t num_classes, '
-                'bool has_anchors, float *anchors_d, const float *in_scores, const float *in_boxes)')
-        f.write('static odtk_ref_tuple<float4> decode_gather' + capt + ' {\n' + '\n'.join(_lambda_body(dec, 'decode lambda')) + '\n}\n')
-        f.write('static odtk_ref_tuple<float6> decode_rotate_gather' + capt + ' {\n'
-                + '\n'.join(_lambda_body(decr, 'decode_rotate lambda')) + '\n}\n')
-        f.write('}  // namespace cuda\n}  // namespace odtk\n')
-        f.write(open(os.path.join(HERE, 'harness.cpp')).read())
+    # capture lists of the decode lambdas: same names and types as in the enclosing reference functions
+    capt = ('(int i, size_t height, size_t width, size_t scale, size_t num_anchors, size_t num_classes, '
+            'bool has_anchors, float *anchors_d, const float *in_scores, const float *in_boxes)')
+    unit = '\n'.join([
+        open(os.path.join(HERE, 'prelude.hpp')).read(),
+        '\n'.join(float6), '\n'.join(device), '\n'.join(pairwise), '\n'.join(axis),
+        'static odtk_ref_tuple<float4> decode_gather' + capt + ' {', '\n'.join(_lambda_body(dec, 'decode lambda')), '}',
+        'static odtk_ref_tuple<float6> decode_rotate_gather' + capt + ' {', '\n'.join(_lambda_body(decr, 'decode_rotate lambda')), '}',
+        '}  // namespace cuda', '}  // namespace odtk',
+        open(os.path.join(HERE, 'harness.cpp')).read()])
     so = os.path.join(OUT, 'libodtk_ref_native.so')
-    cmd = ['g++', '-O2', '-std=c++14', '-ffp-contract=off', '-fno-fast-math', '-fPIC', '-shared', '-w', '-o', so, src]
-    subprocess.run(cmd, check=True)
+    # the spliced translation unit goes to the compiler through a pipe: no copy of reference source is ever
+    # written anywhere, oracle/_ref holds the binary only
+    cmd = ['g++', '-O2', '-std=c++14', '-ffp-contract=off', '-fno-fast-math', '-fPIC', '-shared', '-w', '-x', 'c++', '-',
+           '-o', so]
+    subprocess.run(cmd, input=unit.encode(), check=True)
     if verbose:
         print('[ref_build] built %s from %s' % (so, cu))
     return so

@@ -2,7 +2,7 @@
 // (csrc/cuda/nms_iou.cu:41-258, :324-375, csrc/cuda/nms.cu:44-80 and the float6 struct of csrc/cuda/utils.h), provided for a
 // plain host C++ compiler so that the reference's OWN rotated-IoU / rotated-NMS source can be compiled
 // with g++ and run on the CPU (oracle/ref_build/build_ref.py splices: this file + the reference lines
-// read from /root/reference at build time + harness.cpp -> oracle/_ref/, never into the repository).
+// read from /root/reference at build time + harness.cpp, piped to g++ -> oracle/_ref/*.so; nothing is written out).
 // Built with -ffp-contract=off and without fast-math: this is the IEEE reading of the reference source
 // (the reference's own build used nvcc --use_fast_math, whose bits no other compiler reproduces).
 #include <algorithm>
