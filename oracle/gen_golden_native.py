@@ -100,6 +100,24 @@ def main():
         np.savez_compressed(os.path.join(GOLDEN, 'decode_ref_%s.npz' % name), cls=cls, deltas=dl, anchors=anchors,
                             stride=np.int32(stride), thresh=np.float32(thr), top_n=np.int32(top_n), num_classes=np.int32(n_cls),
                             indices=idx, out_scores=s, out_boxes=b, out_classes=c)
+    # rotated target assignment: the reference's own snap_to_anchors_rotated (odtk/box.py:192-252) run on the CPU
+    # with its `iou_cuda` bound to its own iou kernel (oracle/ref_loader.py:ref_snap_to_anchors_rotated)
+    import warnings
+    import torch
+    from oracle import ref_loader
+    warnings.filterwarnings('ignore')
+    angles = [-math.pi / 6, 0, math.pi / 6]
+    for name, seed, stride, size, n, n_cls in (('a', 61, 16, (160, 128), 6, 7), ('b', 62, 32, (256, 192), 12, 80), ('c', 63, 8, (64, 48), 0, 5)):
+        g = torch.Generator().manual_seed(seed)
+        anchors = ref_loader.ref_generate_anchors_rotated(stride, ratios, scales, angles)
+        xy = torch.rand(n, 2, generator=g) * torch.tensor([size[0] * 0.7, size[1] * 0.7])
+        wh = torch.rand(n, 2, generator=g) * torch.tensor([size[0] * 0.4, size[1] * 0.4]) + 12
+        th = (torch.rand(n, 1, generator=g) - 0.5) * 1.4
+        boxes = torch.cat([xy, wh, th, torch.randint(0, n_cls, (n, 1), generator=g).float()], 1)
+        cls_t, box_t, depth = ref_loader.ref_snap_to_anchors_rotated(boxes, list(size), stride, anchors, n_cls, [0.4, 0.5])
+        np.savez_compressed(os.path.join(GOLDEN, 'snaprot_ref_%s.npz' % name), boxes=boxes.numpy(), size=np.array(size),
+                            stride=np.int32(stride), classes=np.int32(n_cls), ious=np.array([0.4, 0.5], np.float32),
+                            cls_target=cls_t.numpy(), box_target=box_t.numpy(), depth=depth.numpy())
     print('wrote', sorted(f for f in os.listdir(GOLDEN) if '_ref_' in f))
 
 

@@ -97,3 +97,24 @@ def ref_generate_anchors(stride, ratios, scales):
 
 def ref_generate_anchors_rotated(stride, ratios, scales, angles):
     return reference_box().generate_anchors_rotated(stride, ratios, scales, angles)
+
+
+def ref_snap_to_anchors_rotated(boxes, size, stride, anchors, num_classes, anchor_ious):
+    """reference odtk/box.py:192-252, unmodified, on the CPU.  The function only knows a CUDA `iou`
+    (box.py:220-223: `if torch.cuda.is_available(): iou = iou_cuda`), so for the duration of the call
+    `iou_cuda` is bound to the reference's OWN iou kernel compiled for the CPU (oracle/ref_native.py) and
+    `torch.cuda.is_available` answers True; every other line runs as written."""
+    from . import ref_native
+    box = reference_box()
+
+    def iou_native(boxes_flat, anchors_flat):
+        out = ref_native.iou_pairs(boxes_flat.detach().cpu().numpy().reshape(-1, 8),
+                                   anchors_flat.detach().cpu().numpy().reshape(-1, 8))
+        return [torch.from_numpy(out)]
+
+    saved_iou, saved_avail = box.iou_cuda, torch.cuda.is_available
+    box.iou_cuda, torch.cuda.is_available = iou_native, (lambda: True)
+    try:
+        return box.snap_to_anchors_rotated(boxes, size, stride, anchors, num_classes, 'cpu', anchor_ious)
+    finally:
+        box.iou_cuda, torch.cuda.is_available = saved_iou, saved_avail

@@ -149,3 +149,68 @@ def test_training_loss_fused_equals_torch_targets():
         long_target = torch.cat([target, torch.full((2, 1100, 5), -1.0, device='cuda')], 1)   # > 1024 rows: torch path
         plain = m._compute_loss(data, *heads, long_target)
     assert torch.allclose(fused[0], plain[0], rtol=1e-6) and torch.allclose(fused[1], plain[1], rtol=1e-5)
+
+
+# ---- rotated target assignment against the reference's OWN snap_to_anchors_rotated (odtk/box.py:192-252), run on the
+# CPU with its iou_cuda bound to its own iou kernel compiled for the CPU (oracle/ref_loader.py, oracle/ref_native.py) ----
+SNAPROT = sorted(glob.glob(os.path.join(GOLDEN, 'snaprot_ref_*.npz')))
+ANGLES = [-np.pi / 6, 0, np.pi / 6]
+
+
+def _oracle_iou(boxes_flat, anchors_flat):
+    from oracle import c_oracle           # bit-identical to the HIP op (tests/test_gpu_rotated.py) and to the reference kernel
+    return [torch.from_numpy(c_oracle.iou_pairs(boxes_flat.cpu().numpy().reshape(-1, 8), anchors_flat.cpu().numpy().reshape(-1, 8)))]
+
+
+def _rotated_case(path):
+    with np.load(path) as z:
+        g = {k: z[k] for k in z.files}
+    stride = int(g['stride'])
+    anchors = box.generate_anchors_rotated(stride, RATIOS, SCALES, ANGLES)
+    return g, torch.from_numpy(g['boxes']).view(-1, 6), [int(v) for v in g['size']], stride, anchors, int(g['classes']), [float(v) for v in g['ious']]
+
+
+@pytest.mark.parametrize('path', SNAPROT, ids=os.path.basename)
+def test_snap_to_anchors_rotated_matches_reference_fixture(path, monkeypatch):
+    """The torch logic of the product function (rotate_boxes, cell anchors, arg-max, deltas, depth, class map) with
+    the HIP iou op stood in by the oracle: equal to the reference's function bit for bit."""
+    assert len(SNAPROT) == 3
+    g, boxes, size, stride, anchors, classes, ious = _rotated_case(path)
+    monkeypatch.setattr(box, '_require_gpu', lambda *a: None)
+    monkeypatch.setattr(box._C, 'iou', _oracle_iou)
+    out = box.snap_to_anchors_rotated(boxes, size, stride, anchors, classes, 'cpu', ious)
+    for o, k in zip(out, ('cls_target', 'box_target', 'depth')):
+        assert o.shape == tuple(g[k].shape) and np.array_equal(_bits(o.numpy()), _bits(g[k])), k
+
+
+@pytest.mark.skipif(not ref_loader.available() or torch.cuda.is_available(), reason='reference tree only in the build container')
+def test_snap_to_anchors_rotated_live_reference(monkeypatch):
+    from oracle import ref_native
+    if not ref_native.available():
+        pytest.skip('oracle/_ref not built')
+    warnings.filterwarnings('ignore')
+    monkeypatch.setattr(box, '_require_gpu', lambda *a: None)
+    monkeypatch.setattr(box._C, 'iou', _oracle_iou)
+    g = torch.Generator().manual_seed(17)
+    for stride, size, n in [(8, (96, 64), 4), (64, (320, 256), 9)]:
+        xy = torch.rand(n, 2, generator=g) * torch.tensor([size[0] * 0.7, size[1] * 0.7])
+        wh = torch.rand(n, 2, generator=g) * 50 + 10
+        boxes = torch.cat([xy, wh, (torch.rand(n, 1, generator=g) - 0.5) * 1.5, torch.randint(0, 20, (n, 1), generator=g).float()], 1)
+        ref = ref_loader.ref_snap_to_anchors_rotated(boxes, list(size), stride,
+                                                     ref_loader.ref_generate_anchors_rotated(stride, RATIOS, SCALES, ANGLES), 20, [0.4, 0.5])
+        got = box.snap_to_anchors_rotated(boxes, list(size), stride, box.generate_anchors_rotated(stride, RATIOS, SCALES, ANGLES),
+                                          20, 'cpu', [0.4, 0.5])
+        for r, o in zip(ref, got):
+            assert np.array_equal(_bits(r.numpy()), _bits(o.numpy()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('path', SNAPROT, ids=os.path.basename)
+def test_snap_to_anchors_rotated_on_gpu_matches_reference_fixture(path):
+    """The real path: HIP iou op + torch on the GPU.  Class map and depth exact; deltas differ from the CPU
+    reference only through the GPU's log()."""
+    g, boxes, size, stride, anchors, classes, ious = _rotated_case(path)
+    out = box.snap_to_anchors_rotated(boxes.cuda(), size, stride, anchors, classes, 'cuda', ious)
+    assert np.array_equal(_bits(out[0].cpu().numpy()), _bits(g['cls_target']))
+    assert np.array_equal(_bits(out[2].cpu().numpy()), _bits(g['depth']))
+    assert np.allclose(out[1].cpu().numpy(), g['box_target'], rtol=1e-5, atol=1e-5)
