@@ -9,8 +9,9 @@ divergence check :136-138, checkpoint every 60 s :145-183) without apex.  What i
     `broadcast_buffers=False`; `gradient_as_bucket_view=True` (no grad<->bucket copies);
     `static_graph=True`; 151.7 MB of fp32 gradients per step for RN50FPN go out in ~25 MB buckets
     while backward is still running.
-  * the two per-step loss all-reduces of the reference (:127-131) are ONE 2-element all-reduce,
-    issued only on logging steps.
+  * the two per-step loss all-reduces of the reference (:127-131) are ONE 3-element all-reduce,
+    issued only on logging steps; which steps those are is decided from the iteration counter alone,
+    so every rank enters the collective at the same iteration (see `train`).
 
 The data source is any iterator of (images [B,3,H,W], targets [B,N,5|6] padded with -1) batches;
 `SyntheticBatches` is the seeded stand-in used by tests and benchmarks (no dataset exists here).
@@ -75,7 +76,9 @@ def prepare(model, device, lr=0.01, world=1, rank=0, warmup=1000, milestones=(),
     if device.type == 'cuda':
         model = model.to(memory_format=torch.channels_last)
     model.freeze_unused_params()
-    optimizer = SGD([p for p in model.parameters() if p.requires_grad], lr=lr, weight_decay=0.0001, momentum=0.9)
+    # every parameter, frozen ones included, exactly like the reference (train.py:34): the param-group layout is
+    # part of the checkpoint format (optimizer.load_state_dict), and SGD skips parameters without a gradient
+    optimizer = SGD(model.parameters(), lr=lr, weight_decay=0.0001, momentum=0.9)
     net = model
     if world > 1:
         net = DistributedDataParallel(model, device_ids=[device.index] if device.type == 'cuda' else None,
@@ -108,43 +111,82 @@ def train_step(net, optimizer, scheduler, scaler, data, target, amp_dtype=None):
     return cls_loss.detach(), box_loss.detach()
 
 
-def reduce_losses(cls_loss, box_loss, world):
-    """Mean over ranks of both losses with ONE collective (reference: two, train.py:127-131)."""
-    both = torch.stack([cls_loss, box_loss]).float()
+def reduce_losses(cls_loss, box_loss, world, extra=None):
+    """Mean over ranks of both losses with ONE collective (reference: two per step, train.py:127-131).
+    `extra`: an optional scalar that only rank 0 contributes (summed, so every rank reads rank 0's value)
+    riding in the same message."""
+    parts = [cls_loss.detach().float().reshape(()), box_loss.detach().float().reshape(())]
+    if extra is not None:
+        parts.append(torch.as_tensor(float(extra), dtype=torch.float32, device=parts[0].device))
+    both = torch.stack(parts)
     if world > 1:
         dist.all_reduce(both)
-        both /= world
+        both[:2] /= world
     return both
 
 
 def train(model, state, batches, iterations, device, lr=0.01, warmup=1000, milestones=(), gamma=0.1, world=1,
-          rank=0, mixed_precision=True, log_every=60.0, save_path=None, verbose=True):
-    """The training loop of reference train.py:18-214 minus apex / DALI / TensorBoard."""
+          rank=0, mixed_precision=True, log_every=60.0, save_path=None, verbose=True, log_interval=None):
+    """The training loop of reference train.py:18-214 minus apex / DALI / TensorBoard.
+
+    Logging / checkpoint cadence.  The reference all-reduces both losses and tests them on the host EVERY
+    step (train.py:126-138: two collectives + one host sync per iteration).  Here the losses are summed on
+    the device and reduced once per logging step.  Whether a step is a logging step must be the SAME
+    decision on every rank (a collective that only some ranks enter would pair with another rank's
+    gradient all-reduce), so it is a function of the iteration counter only: every `interval` iterations,
+    where `interval` starts at `log_interval` (default 10) and is re-derived at each logging step from
+    RANK 0's measured step time (target: one report per `log_every` seconds) and handed to every rank
+    inside the loss all-reduce itself."""
     model, net, optimizer, scheduler = prepare(model, device, lr, world, rank, warmup, milestones, gamma, state)
     amp_dtype = torch.float16 if (mixed_precision and device.type == 'cuda') else None
     scaler = torch.amp.GradScaler('cuda', enabled=amp_dtype is not None) if amp_dtype is not None else None
     iteration = state.get('iteration', 0) if state else 0
-    last_log, seen = time.time(), 0
-    for data, target in batches:
-        if iteration >= iterations:
-            break
-        if device.type == 'cuda':
-            data = data.contiguous(memory_format=torch.channels_last)
-        cls_loss, box_loss = train_step(net, optimizer, scheduler, scaler, data.to(device), target.to(device), amp_dtype)
-        iteration += 1
-        seen += data.shape[0] * world
+    interval = max(1, int(log_interval)) if log_interval else 10
+    adaptive = log_interval is None
+    next_log = iteration + interval
+    t_mark, n_mark = time.time(), 0
+    cls_sum = box_sum = None
+
+    def report():
+        nonlocal interval, next_log, t_mark, n_mark, cls_sum, box_sum
         now = time.time()
-        if now - last_log >= log_every or iteration == iterations:
-            both = reduce_losses(cls_loss, box_loss, world)
-            total = float(both.sum())
-            if not math.isfinite(total):
-                raise RuntimeError('Loss is diverging!\nTry lowering the learning rate.')
-            if rank == 0 and verbose:
-                print('[{:{w}}/{}] focal loss: {:.3f}, box loss: {:.3f}, {:.1f} im/s, lr: {:.2g}'.format(
-                    iteration, iterations, float(both[0]), float(both[1]), seen / max(now - last_log, 1e-9),
-                    scheduler.get_last_lr()[0], w=len(str(iterations))), flush=True)
-            if rank == 0 and save_path:
-                model.save({'path': save_path, 'iteration': iteration, 'optimizer': optimizer.state_dict(),
-                            'scheduler': scheduler.state_dict()})
-            last_log, seen = time.time(), 0
+        per_step = (now - t_mark) / max(n_mark, 1)
+        proposal = max(1, min(100000, int(round(log_every / max(per_step, 1e-6))))) if adaptive else interval
+        both = reduce_losses(cls_sum / n_mark, box_sum / n_mark, world, proposal if rank == 0 else 0.0)
+        cls_mean, box_mean, agreed = (float(v) for v in both)       # the only host sync of the interval
+        if not math.isfinite(cls_mean + box_mean):
+            raise RuntimeError('Loss is diverging!\nTry lowering the learning rate.')
+        if rank == 0 and verbose:
+            print('[{:{w}}/{}] focal loss: {:.3f}, box loss: {:.3f}, {:.3f}s/{}-batch, {:.1f} im/s, lr: {:.2g}'.format(
+                iteration, iterations, cls_mean, box_mean, per_step, seen // max(n_mark, 1), seen / max(now - t_mark, 1e-9),
+                scheduler.get_last_lr()[0], w=len(str(iterations))), flush=True)
+        if rank == 0 and save_path:
+            model.save({'path': save_path, 'iteration': iteration, 'optimizer': optimizer.state_dict(),
+                        'scheduler': scheduler.state_dict()})
+        interval = max(1, int(round(agreed)))
+        next_log = iteration + interval
+        t_mark, n_mark, cls_sum, box_sum = time.time(), 0, None, None
+
+    seen = 0
+    while iteration < iterations:                                    # epochs (reference train.py:93)
+        progressed = False
+        for data, target in batches:
+            if iteration >= iterations:
+                break
+            progressed = True
+            if device.type == 'cuda':
+                data = data.contiguous(memory_format=torch.channels_last)
+            cls_loss, box_loss = train_step(net, optimizer, scheduler, scaler, data.to(device), target.to(device), amp_dtype)
+            iteration += 1
+            n_mark += 1
+            seen += data.shape[0] * world
+            cls_sum = cls_loss if cls_sum is None else cls_sum + cls_loss
+            box_sum = box_loss if box_sum is None else box_sum + box_loss
+            if iteration >= next_log or iteration == iterations:
+                report()
+                seen = 0
+        if not progressed:                                           # empty data source: nothing will ever change
+            break
+    if n_mark:                                                       # the source ran dry between two reports
+        report()
     return iteration

@@ -6,6 +6,7 @@ import copy
 import os
 import socket
 
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -96,3 +97,154 @@ def test_lr_schedule_and_synthetic_batches():
     assert a[0].shape == (2, 3, 64, 96) and a[1].shape == (2, 20, 5) and not torch.equal(a[0], b[0])
     valid = a[1][a[1][:, :, 4] >= 0]
     assert (valid[:, 0] + valid[:, 2] <= 96 + 1e-3).all() and (valid[:, 1] + valid[:, 3] <= 64 + 1e-3).all()
+
+
+# ---------------------------------------------------------------------------------------------------
+# train(): the whole loop on two ranks (the logging collective must be entered by every rank
+# at the same iteration whatever each rank's own clock says; epochs must wrap; checkpoints must carry
+# the reference's optimizer layout = ALL parameters)
+# ---------------------------------------------------------------------------------------------------
+class _SlowFiniteSource:
+    """3 batches per epoch; rank 1 is slower than rank 0, so wall-clock based decisions would diverge."""
+
+    def __init__(self, rank, world):
+        self.src = T.SyntheticBatches(2, 128, 128, classes=4, max_boxes=4, seed=5, rank=rank, world=world)
+        self.items = [self.src.batch() for _ in range(3)]
+        self.rank = rank
+        self.epochs = 0
+
+    def __iter__(self):
+        import time
+        self.epochs += 1
+        for item in self.items:
+            time.sleep(0.05 * self.rank)
+            yield item
+
+
+def _train_worker(rank, world, port, q, tmp):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    model = _build()
+    source = _SlowFiniteSource(rank, world)
+    path = os.path.join(tmp, 'ckpt.pth')
+    # log_every far below one step: a per-rank clock would fire on different iterations on the two ranks
+    done = T.train(model, {}, source, 8, torch.device('cpu'), lr=0.001, warmup=4, world=world, rank=rank,
+                   mixed_precision=False, log_every=0.01, save_path=path, verbose=False)
+    flat = torch.cat([p.detach().flatten() for p in model.parameters()])
+    gathered = [torch.empty_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    q.put((rank, done, source.epochs, bool(torch.equal(gathered[0], gathered[1])), bool(torch.isfinite(flat).all())))
+    dist.destroy_process_group()
+
+
+def test_train_loop_two_ranks_gloo(tmp_path):
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_train_worker, args=(r, world, port, q, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=900) for _ in range(world))
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    for rank, done, epochs, same, finite in res:
+        assert done == 8                      # all iterations ran although an epoch holds only 3 batches
+        assert epochs == 3                    # 3 + 3 + 2
+        assert same and finite                # replicas identical after 8 steps: no collective was mispaired
+    # the checkpoint resumes: optimizer state covers EVERY parameter (reference layout, train.py:34)
+    model, state = Model.load(os.path.join(str(tmp_path), 'ckpt.pth'))
+    assert state['iteration'] == 8
+    m2, net, opt, sched = T.prepare(model, torch.device('cpu'), lr=0.001, warmup=4, state=state)   # load_state_dict ok
+    n_params = len(list(m2.parameters()))                    # frozen-BN conversion turns BN affines into buffers
+    assert any(not p.requires_grad for p in m2.parameters())  # the unused `fc` is frozen, yet part of the layout
+    assert len(state['optimizer']['param_groups'][0]['params']) == n_params
+    assert sched.last_epoch == 8
+
+
+def _trajectory_worker(rank, world, port, q, steps, every_level):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    dev = torch.device('cpu')
+    data, target = _trajectory_batches(steps, every_level)
+    model, net, opt, sched = T.prepare(_build(), dev, lr=0.01, world=world, rank=rank, warmup=2)
+    losses = []
+    for s in range(steps):
+        c, b = T.train_step(net, opt, sched, None, data[s][rank:rank + 1], target[s][rank:rank + 1])
+        losses.append(T.reduce_losses(c, b, world).tolist())
+    q.put((rank, losses, torch.cat([p.detach().flatten() for p in model.parameters()])))
+    dist.destroy_process_group()
+
+
+def _trajectory_batches(steps, every_level=True):
+    """Global batches of 2 images.
+
+    every_level=True: both images carry the SAME five boxes, one sitting exactly on an anchor of each
+    pyramid level.  The reference normalises the loss by the foreground count of the rank's OWN batch,
+    clamped to >= 1 PER LEVEL (model.py:196, :206-209), so a data-parallel run equals the single-process
+    bs-2 run exactly when the per-rank foreground counts agree and no level is empty -- which this
+    construction guarantees.  every_level=False: random boxes (levels without foreground exist)."""
+    g = torch.Generator().manual_seed(11)
+    data, target = [], []
+    for _ in range(steps):
+        d = torch.randn(2, 3, 128, 128, generator=g)
+        if every_level:
+            rows = [[-1.5 * s, -1.5 * s, 4.0 * s + 1, 4.0 * s + 1, float(i % 4)] for i, s in enumerate((8, 16, 32, 64, 128))]
+            t = torch.tensor(rows).unsqueeze(0).repeat(2, 1, 1)
+        else:
+            t = torch.full((2, 4, 5), -1.0)
+            for i in range(2):
+                n = int(torch.randint(1, 4, (1,), generator=g))
+                wh = torch.rand(n, 2, generator=g) * 60 + 20
+                xy = torch.rand(n, 2, generator=g) * (128 - wh)
+                t[i, :n] = torch.cat([xy, wh, torch.randint(0, 4, (n, 1), generator=g).float()], 1)
+        data.append(d)
+        target.append(t)
+    return data, target
+
+
+def _single_process_trajectory(steps, every_level):
+    data, target = _trajectory_batches(steps, every_level)
+    model, net, opt, sched = T.prepare(_build(), torch.device('cpu'), lr=0.01, world=1, warmup=2)
+    single = []
+    for s in range(steps):
+        if every_level:
+            c, b = T.train_step(net, opt, sched, None, data[s], target[s])        # ONE bs-2 forward
+        else:
+            # two micro-batches of one image, gradients averaged: what data parallelism computes by definition
+            opt.zero_grad(set_to_none=True)
+            parts = [net([data[s][i:i + 1], target[s][i:i + 1]]) for i in range(2)]
+            c = (parts[0][0] + parts[1][0]) / 2
+            b = (parts[0][1] + parts[1][1]) / 2
+            (c + b).backward()
+            opt.step()
+            sched.step()
+        single.append([float(c.detach()), float(b.detach())])
+    return single, torch.cat([p.detach().flatten() for p in model.parameters()])
+
+
+@pytest.mark.parametrize('every_level', [True, False], ids=['vs-one-bs2-forward', 'vs-accumulated-microbatches'])
+def test_two_ranks_reproduce_one_rank_trajectory(every_level):
+    """2 ranks x 1 image == 1 rank x 2 images, loss for loss, for 3 steps."""
+    steps, world, port = 3, 2, _free_port()
+    single, single_params = _single_process_trajectory(steps, every_level)
+
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_trajectory_worker, args=(r, world, port, q, steps, every_level)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=900) for _ in range(world)), key=lambda r: r[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert res[0][1] == res[1][1]
+    for got, want in zip(res[0][1], single):
+        for g_, w_ in zip(got, want):
+            assert abs(g_ - w_) <= 2e-5 * max(1.0, abs(w_)), (res[0][1], single)
+    scale = single_params.abs().max().item()
+    assert (res[0][2] - single_params).abs().max().item() <= 1e-5 * scale
