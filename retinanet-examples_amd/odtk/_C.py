@@ -247,6 +247,8 @@ def _levels(cls_heads, box_heads, anchors_list, strides, nb, cls_bias=None, box_
     num_anchors = None
     for i, (c, b, a, s) in enumerate(zip(cls_heads, box_heads, anchors_list, strides)):
         lay = _layout(c, 'cls_head[%d]' % i)
+        if c.shape[2] * c.shape[3] == 1 and cls_bias is not None:
+            lay = 1       # a 1x1 level is NCHW- and NHWC-contiguous at once; the bias fold wants the channels_last reading
         if _layout(b, 'box_head[%d]' % i) != lay and b.shape[2] * b.shape[3] > 1:
             raise RuntimeError('cls_head[%d] and box_head[%d] must share one memory format' % (i, i))
         if c.dtype != dtype or b.dtype != dtype:

@@ -7,11 +7,16 @@ nms :312, nms_rotated :370), so `odtk.model.Model.forward` and user code keep ca
 nms, ndetections)` unchanged.
 
 Differences, all deliberate:
-  * decode / nms / nms_rotated ALWAYS run the hand-written HIP kernels (libodtk_hip.so via
-    odtk._C).  There is no CPU fallback: CPU tensors raise.  (The reference's CPU branch is kept,
-    restated, under oracle/ as the test oracle only.)
+  * GPU tensors ALWAYS run the hand-written HIP kernels (libodtk_hip.so via odtk._C); a missing
+    library raises, nothing falls back silently.
+  * CPU tensors take the pure-torch branch below (`_decode_cpu`, `_nms_cpu`) -- the reference's own
+    "no GPU" plumbing path (box.py:266-309, :319-367; BASELINE config 0), with the integer divisions
+    written as floor divisions (the reference's `/` on index tensors broke with torch >= 1.5) and the
+    canonical tie order (stable sorts).  The reference dispatches on `torch.cuda.is_available()`;
+    here the tensor's device decides.  Rotated boxes have no CPU path (the reference's is dead code:
+    box.py:408 calls an undefined `iou`).
   * `decode_levels` / `detect` are additions: all pyramid levels x the whole batch in one
-    enqueue, with no host synchronisation.
+    enqueue, with no host synchronisation (GPU only).
 """
 import math
 
@@ -226,8 +231,75 @@ def snap_to_anchors_rotated(boxes, size, stride, anchors, num_classes, device, a
 
 def _require_gpu(t, what):
     if not t.is_cuda:
-        raise RuntimeError('odtk.box.%s: tensors must be on the GPU -- the MI355X build has no CPU path '
-                           '(the reference CPU algorithm lives in oracle/ as the test oracle)' % what)
+        raise RuntimeError('odtk.box.%s: tensors must be on the GPU (only the axis-aligned decode / nms have a '
+                           'pure-torch CPU branch)' % what)
+
+
+def _decode_cpu(cls_heads, box_heads, stride, threshold, top_n, anchors):
+    """CPU branch of `decode` (reference box.py:266-309): per image keep `score >= threshold`, take the
+    `top_n` best in (score desc, flat NCHW index asc) order, decode their boxes with `delta2box`."""
+    cls_heads, box_heads = cls_heads.float(), box_heads.float()
+    anchors = anchors.to(cls_heads.device, torch.float32)
+    batch, channels, height, width = cls_heads.shape
+    num_anchors = anchors.shape[0]
+    num_classes = channels // num_anchors
+    scores_out = cls_heads.new_zeros((batch, top_n))
+    boxes_out = cls_heads.new_zeros((batch, top_n, 4))
+    classes_out = cls_heads.new_zeros((batch, top_n))
+    flat_scores = cls_heads.reshape(batch, -1)
+    deltas_by_cell = box_heads.reshape(batch, num_anchors, 4, height, width)
+    for image in range(batch):
+        row = flat_scores[image]
+        candidates = torch.nonzero(row >= threshold).view(-1)                 # ascending flat index
+        if candidates.numel() == 0:
+            continue
+        ranked = torch.argsort(row[candidates], descending=True, stable=True)[:top_n]
+        index = candidates[ranked]
+        k = index.numel()
+        a, c, y, x = torch.unravel_index(index, (num_anchors, num_classes, height, width))
+        cell = torch.stack([x, y, x, y], 1).to(torch.float32) * stride + anchors[a]
+        scores_out[image, :k] = row[index]
+        boxes_out[image, :k] = delta2box(deltas_by_cell[image, a, :, y, x], cell, [width, height], stride)
+        classes_out[image, :k] = c.to(torch.float32)
+    return scores_out, boxes_out, classes_out
+
+
+def _nms_cpu(all_scores, all_boxes, all_classes, nms, ndetections):
+    """CPU branch of `nms` (reference box.py:319-367): greedy, class-aware, +1 pixel IoU.  The reference
+    compacts its arrays after every kept box; here one `alive` mask over the score-sorted candidates does
+    the same bookkeeping: the i-th kept box is the i-th alive entry, and it retires every alive entry that
+    fails the reference's survivor test `score > s_i  or  IoU <= nms  or  class != c_i`."""
+    all_scores, all_boxes, all_classes = all_scores.float(), all_boxes.float(), all_classes.float()
+    batch = all_scores.shape[0]
+    scores_out = all_scores.new_zeros((batch, ndetections))
+    boxes_out = all_scores.new_zeros((batch, ndetections, 4))
+    classes_out = all_scores.new_zeros((batch, ndetections))
+    for image in range(batch):
+        positive = torch.nonzero(all_scores[image] > 0).view(-1)
+        if positive.numel() == 0:
+            continue
+        order = positive[torch.argsort(all_scores[image, positive], descending=True, stable=True)]
+        scores, boxes, classes = all_scores[image, order], all_boxes[image, order], all_classes[image, order]
+        area = (boxes[:, 2] - boxes[:, 0] + 1) * (boxes[:, 3] - boxes[:, 1] + 1)
+        alive = torch.ones_like(scores, dtype=torch.bool)
+        kept = 0
+        while kept < ndetections:
+            remaining = torch.nonzero(alive).view(-1)
+            if kept >= remaining.numel():
+                break
+            i = int(remaining[kept])
+            lo = torch.max(boxes[:, :2], boxes[i, :2])
+            hi = torch.min(boxes[:, 2:], boxes[i, 2:])
+            inter = torch.prod((hi - lo + 1).clamp(0), 1)
+            survives = (scores > scores[i]) | (inter / (area + area[i] - inter) <= nms) | (classes != classes[i])
+            survives[i] = True
+            alive &= survives
+            kept += 1
+        winners = torch.nonzero(alive).view(-1)[:kept]
+        scores_out[image, :kept] = scores[winners]
+        boxes_out[image, :kept] = boxes[winners]
+        classes_out[image, :kept] = classes[winners]
+    return scores_out, boxes_out, classes_out
 
 
 def decode(all_cls_head, all_box_head, stride=1, threshold=0.05, top_n=1000, anchors=None, rotated=False):
@@ -237,14 +309,18 @@ def decode(all_cls_head, all_box_head, stride=1, threshold=0.05, top_n=1000, anc
     boxes [B, top_n, {4|6}], classes [B, top_n] (score-descending, zero padded)."""
     if rotated:
         anchors = anchors[0]
-    _require_gpu(all_cls_head, 'decode')
+    if not all_cls_head.is_cuda:
+        if rotated:
+            _require_gpu(all_cls_head, 'decode(rotated=True)')
+        return _decode_cpu(all_cls_head, all_box_head, stride, threshold, top_n, anchors)
     return _C.decode(all_cls_head.float().contiguous(), all_box_head.float().contiguous(),
                      anchors.reshape(-1).tolist(), stride, threshold, top_n, rotated)
 
 
 def nms(all_scores, all_boxes, all_classes, nms=0.5, ndetections=100):
     """Batched class-aware greedy NMS (reference box.py:312-367)."""
-    _require_gpu(all_scores, 'nms')
+    if not all_scores.is_cuda:
+        return _nms_cpu(all_scores, all_boxes, all_classes, nms, ndetections)
     return _C.nms(all_scores.float().contiguous(), all_boxes.float().contiguous(),
                   all_classes.float().contiguous(), nms, ndetections, False)
 

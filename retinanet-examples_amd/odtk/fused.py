@@ -104,10 +104,24 @@ class _Block(nn.Module):
 
 
 class FusedRetinaNet(nn.Module):
+    @staticmethod
+    def supports(model):
+        """One ResNet-FPN backbone made of Bottleneck / BasicBlock stages taking C3..C5."""
+        if len(model.backbones) != 1:
+            return False
+        fpn = next(iter(model.backbones.values()))
+        net = getattr(fpn, 'features', None)
+        if net is None or not all(hasattr(net, n) for n in ('conv1', 'bn1', 'layer1', 'layer2', 'layer3', 'layer4')):
+            return False
+        if list(getattr(net, 'outputs', [])) != [3, 4, 5]:
+            return False
+        return all(isinstance(b, (Bottleneck, BasicBlock)) for layer in (net.layer1, net.layer2, net.layer3, net.layer4)
+                   for b in layer)
+
     def __init__(self, model, dtype=torch.bfloat16):
         super().__init__()
-        if len(model.backbones) != 1:
-            raise ValueError('FusedRetinaNet supports a single FPN backbone')
+        if not self.supports(model):
+            raise ValueError('FusedRetinaNet supports a single ResNet-FPN backbone')
         fpn = next(iter(model.backbones.values()))
         net = fpn.features
         self.dtype = dtype

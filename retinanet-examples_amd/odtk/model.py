@@ -5,14 +5,18 @@ in train / eval mode, `save` / `load` with the same checkpoint keys, reference o
 training scripts and checkpoints carry over.  What runs where:
 
   backbone + FPN + the two 5-conv heads + losses   stock PyTorch-ROCm modules (MIOpen owns the MFMA work)
-  eval post-processing                              `odtk.box.detect`: sigmoid + decode of all five levels
-                                                    + batched NMS, hand-written HIP, 3 launches, no host
-                                                    sync, head tensors read in place (bf16/fp16/fp32,
-                                                    NCHW or channels_last)
+  eval forward on a GPU (the default)               the BN-folded inference engine (odtk/fused.py: folded
+                                                    weights, HIP bias/skip/ReLU epilogues, 1x1 convs as
+                                                    fused GEMMs) + `odtk.box.detect`: sigmoid + decode of all
+                                                    five levels + batched NMS, hand-written HIP, 3 launches,
+                                                    no host sync, head tensors read in place.  Built lazily
+                                                    from the current weights, rebuilt when they change.
+  `fused_graph = False`                             the eager nn.Module graph (what training uses) + the same
+                                                    fused post-processing
   `fused_postprocess = False`                       the reference's own op sequence (model.py:140-165)
                                                     on the same kernels, for A/B checks
-  `fuse()`                                          BN-folded inference graph with the HIP bias/skip/ReLU
-                                                    epilogue (odtk/fused.py)
+  CPU tensors                                       eager graph + the pure-torch decode / nms branch of
+                                                    odtk/box.py (BASELINE config 0: no GPU needed)
 """
 import math
 import os.path
@@ -79,6 +83,8 @@ class Model(nn.Module):
         self.detections = config.get('detections', 100)
         self.exporting = False
         self.fused_postprocess = True
+        self.fused_graph = True                             # eval on a GPU runs the BN-folded engine (odtk/fused.py)
+        self.__dict__['_engine_cache'] = {}                 # (not a submodule: keeps state_dict / checkpoints unchanged)
 
         self.num_anchors = len(ratios) * len(scales) * (len(self.angles) if rotated_bbox else 1)
         box_params = 6 if rotated_bbox else 4               # rotated: (dx, dy, dw, dh, sin, cos)
@@ -148,6 +154,31 @@ class Model(nn.Module):
         from .fused import FusedRetinaNet
         return FusedRetinaNet(self, dtype)
 
+    def _apply(self, fn, *args, **kwargs):
+        self.__dict__['_engine_cache'].clear()              # .to() / .cuda() / .float(): new storages
+        return super()._apply(fn, *args, **kwargs)
+
+    def inference_engine(self, dtype):
+        """The cached BN-folded engine for `dtype`; None when this model has no fused form (several
+        backbones, exotic blocks).  The engine is a SNAPSHOT of the weights, so it remembers the tensors it
+        was folded from together with their version counters and storage addresses, and is rebuilt when
+        any of them moved: optimizer steps and load_state_dict write in place (version bump), .to() /
+        .cuda() swap storages (cache dropped in `_apply`)."""
+        from .fused import FusedRetinaNet
+        cache = self.__dict__['_engine_cache']
+        hit = cache.get(dtype)
+        if hit is not None:
+            tensors, stamp, engine = hit
+            if [t._version for t in tensors] + [t.data_ptr() for t in tensors] == stamp:
+                return engine
+        if not FusedRetinaNet.supports(self):
+            return None
+        cache.clear()                                       # one engine at a time: it holds a copy of the weights
+        tensors = list(self.parameters()) + list(self.buffers())
+        engine = FusedRetinaNet(self, dtype)
+        cache[dtype] = (tensors, [t._version for t in tensors] + [t.data_ptr() for t in tensors], engine)
+        return engine
+
     # ------------------------------------------------------------------ forward
     def level_anchors(self, stride):
         if stride not in self.anchors:
@@ -168,6 +199,14 @@ class Model(nn.Module):
             cls_heads, box_heads = self.heads(images)
             return self._compute_loss(images, cls_heads, box_heads, targets.float())
 
+        if self.fused_graph and self.fused_postprocess and x.is_cuda and not self.exporting:
+            # the default inference path: same function as the eager graph below up to the rounding of the
+            # folded weights (tests/test_gpu_fused_model.py, tests/test_gpu_detection_parity.py)
+            dtype = torch.get_autocast_dtype('cuda') if torch.is_autocast_enabled('cuda') else self.cls_head[0].weight.dtype
+            engine = self.inference_engine(dtype)
+            if engine is not None:
+                return engine(x)
+
         cls_heads, box_heads = self.heads(x)
         strides = [x.shape[-1] // c.shape[-1] for c in cls_heads]
         if self.exporting:
@@ -179,11 +218,12 @@ class Model(nn.Module):
 
     def postprocess(self, cls_heads, box_heads, strides):
         """Raw head tensors -> (scores [B, D], boxes [B, D, 4|6], classes [B, D])."""
-        if self.fused_postprocess:
+        if self.fused_postprocess and cls_heads[0].is_cuda:
             # sigmoid + decode x5 + nms on the head tensors as the convolutions wrote them
             return box_ops.detect(cls_heads, box_heads, strides, self.anchors, self.threshold, self.top_n,
                                   self.nms, self.detections, self.rotated_bbox, logits=True)
-        # the reference's sequence, call for call (model.py:140, :153-165)
+        # the reference's sequence, call for call (model.py:140, :153-165); on CPU tensors this is the
+        # pure-torch branch of odtk/box.py
         suppress = box_ops.nms_rotated if self.rotated_bbox else box_ops.nms
         per_level = [box_ops.decode(c.sigmoid().contiguous(), b.contiguous(), s, self.threshold, self.top_n,
                                     self.anchors[s], self.rotated_bbox)

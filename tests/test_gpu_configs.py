@@ -38,6 +38,7 @@ def test_config0_resnet18fpn_512_plumbing():
     with torch.no_grad():
         cached = model.heads(x)
         model.heads = lambda _x: cached
+        model.fused_graph = False          # this test pins the post-processing on GIVEN head tensors (eager graph)
         fused = model(x)
         model.fused_postprocess = False
         plain = model(x)
@@ -69,6 +70,7 @@ def test_config4_rotated_model():
     with torch.no_grad():
         cls_heads, box_heads = model.heads(x)
         model.heads = lambda _x: (cls_heads, box_heads)
+        model.fused_graph = False          # post-processing on GIVEN head tensors
         out = model(x)
     assert out[1].shape == (2, 100, 6)
     strides = [320 // c.shape[-1] for c in cls_heads]
