@@ -228,12 +228,39 @@ int odtk_gemm_bias_act(void *y, const void *x, const void *w, const float *bias,
  *   targets     float32 [batch, n_max, 5] = (x, y, w, h, class); rows with class < 0 are padding
  *   anchors     HOST float[4*num_anchors]
  *   cls_target  float32 [batch, A, C, H, W]   box_target [batch, A, 4, H, W]   depth [batch, A, 1, H, W]
- * n_max <= 1024.
+ * Any n_max (rows go through LDS 1024 at a time).  cls_target may be NULL when the caller feeds
+ * odtk_retina_loss_* (which derives the class target from depth) and does not need the one-hot map.
  */
 int odtk_snap_to_anchors(int batch_size, const float *targets, int n_max, const float *anchors,
                          int num_anchors, int num_classes, int height, int width, int stride,
                          float iou_background, float iou_foreground,
                          float *cls_target, float *box_target, float *depth, void *stream);
+
+/*
+ * odtk_retina_loss_forward / odtk_retina_loss_backward -- fused, masked FocalLoss + SmoothL1 reduction of ONE
+ * pyramid level for the whole batch (the step after target assignment in training).
+ * Replaces, per level, reference odtk/model.py:193-209 + odtk/loss.py:13-31 (focal loss, smooth-L1, the two
+ * masks, the three sums: ~20 elementwise torch kernels over the classification head and their autograd twins).
+ *   cls         [batch, A*C, H, W] logits          dtype ODTK_F32 / BF16 / F16, NCHW or channels_last,
+ *   box         [batch, A*box_params, H, W]        same dtype and layout as cls, 16-byte aligned
+ *   depth       float32 [batch, A, 1, H, W]        -1 ignore / 0 background / class + 1 (odtk_snap_to_anchors)
+ *   box_target  float32 [batch, A, box_params, H, W]
+ * The one-hot class target is not an input: under the mask `depth >= 0` it equals `c == depth - 1`.
+ * forward:  sums = DEVICE double[3], overwritten with { sum of masked focal losses, sum of masked smooth-L1
+ *           losses, number of foreground anchors (depth > 0) }.
+ * backward: grad_cls_sum / grad_box_sum = DEVICE float32 scalars (upstream gradients of the two sums; NULL = 0);
+ *           dcls / dbox receive d(out)/d(cls) and d(out)/d(box) in the dtype and layout of cls / box.
+ * Nothing is read back to the host.  batch*A*C*H*W must be < 2^32.
+ */
+int odtk_retina_loss_forward(const void *cls, const void *box, const float *depth, const float *box_target,
+                             int batch_size, int num_anchors, int num_classes, int height, int width,
+                             int box_params, int dtype, int channels_last, float alpha, float gamma, float beta,
+                             double *sums, void *stream);
+int odtk_retina_loss_backward(const void *cls, const void *box, const float *depth, const float *box_target,
+                              int batch_size, int num_anchors, int num_classes, int height, int width,
+                              int box_params, int dtype, int channels_last, float alpha, float gamma, float beta,
+                              const float *grad_cls_sum, const float *grad_box_sum, void *dcls, void *dbox,
+                              void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Measurement hooks (used by bench.py; off by default, zero cost when off).
@@ -248,7 +275,10 @@ int odtk_snap_to_anchors(int batch_size, const float *targets, int n_max, const 
 #define ODTK_KERNEL_EPILOGUE  4   /* bias_act_kernel                               */
 #define ODTK_KERNEL_TARGETS   5   /* snap_to_anchors_kernel                        */
 #define ODTK_KERNEL_GEMM      6   /* hipBLASLt kernels behind odtk_gemm_bias_act    */
-#define ODTK_KERNEL_COUNT     7
+#define ODTK_KERNEL_LOSS      7   /* retina_loss_kernel (forward and backward)      */
+#define ODTK_KERNEL_SELHIST   8   /* select_hist_kernel (both histogram passes)     */
+#define ODTK_KERNEL_SELFILTER 9   /* select_filter_kernel                           */
+#define ODTK_KERNEL_COUNT     10
 /* on: 0 = off, otherwise a bit mask of kernel ids (1 << ODTK_KERNEL_*), -1 = all.  An event pair
  * is a queue marker before and after the kernel: cheap for the 3 post-processing launches of a step,
  * measurably NOT free for the ~110 epilogue launches (about 10 % of an 8.7 ms step), so time those

@@ -21,6 +21,7 @@
 #include "prefilter.hpp"
 #include "select_decode.hpp"
 #include "targets.hpp"
+#include "loss.hpp"
 #include "gemm_lt.hpp"
 
 namespace {
@@ -341,6 +342,48 @@ int bias_act_dispatch(void *y, const float *bias, const void *res, uint64_t n, u
   return bias_act_typed<odtk::F16>(y, bias, res, n, c, relu, s);
 }
 
+int retina_loss_launch(bool backward, const void *cls, const void *box, const float *depth, const float *box_target,
+                       int batch, int A, int C, int height, int width, int nb, int dtype, int channels_last, float alpha,
+                       float gamma, float beta, double *sums, const float *g_cls, const float *g_box, void *dcls,
+                       void *dbox, hipStream_t stream) {
+  if (!cls || !box || !depth || !box_target || batch <= 0 || A <= 0 || C <= 0 || height <= 0 || width <= 0 || nb <= 0)
+    return ODTK_ERR_INVALID;
+  if (dtype != ODTK_F32 && dtype != ODTK_BF16 && dtype != ODTK_F16) return ODTK_ERR_UNSUPPORTED;
+  if (channels_last != 0 && channels_last != 1) return ODTK_ERR_INVALID;
+  if ((reinterpret_cast<uintptr_t>(cls) | reinterpret_cast<uintptr_t>(box)) & 15u) return ODTK_ERR_INVALID;   // 16-B vector loads
+  const unsigned long long n = 1ull * batch * A * C * height * width;
+  if (n >= (1ull << 32)) return ODTK_ERR_INVALID;
+  odtk::LossArgs la;
+  std::memset(&la, 0, sizeof la);
+  la.cls = cls; la.box = box; la.depth = depth; la.box_target = box_target;
+  la.acc = sums; la.g_cls = g_cls; la.g_box = g_box; la.dcls = dcls; la.dbox = dbox;
+  la.batch = batch; la.num_anchors = A; la.num_classes = C; la.hw = static_cast<uint32_t>(height) * width; la.nb = nb;
+  la.channels_last = channels_last;
+  la.alpha = alpha; la.gamma = gamma; la.beta = beta;
+  const unsigned per = dtype == ODTK_F32 ? 4u : 8u;
+  unsigned long long cls_blocks = (n / per + odtk::kLossThreads * 4ull - 1) / (odtk::kLossThreads * 4ull);   // ~4 vectors per lane
+  if (cls_blocks < 1) cls_blocks = 1;
+  if (cls_blocks > 256 * 16) cls_blocks = 256 * 16;
+  unsigned long long box_blocks = (1ull * batch * A * height * width + odtk::kLossThreads - 1) / odtk::kLossThreads;
+  if (box_blocks > 1024) box_blocks = 1024;
+  la.cls_blocks = static_cast<uint32_t>(cls_blocks);
+  const dim3 grid(static_cast<unsigned>(cls_blocks + box_blocks)), block(odtk::kLossThreads);
+  {
+    KernelTimer t(ODTK_KERNEL_LOSS, stream);
+#define ODTK_LOSS(T)                                                                                     \
+  do {                                                                                                   \
+    if (backward) hipLaunchKernelGGL((odtk::retina_loss_kernel<T, true>), grid, block, 0, stream, la);   \
+    else hipLaunchKernelGGL((odtk::retina_loss_kernel<T, false>), grid, block, 0, stream, la);           \
+  } while (0)
+    if (dtype == ODTK_F32) ODTK_LOSS(odtk::F32);
+    else if (dtype == ODTK_BF16) ODTK_LOSS(odtk::BF16);
+    else ODTK_LOSS(odtk::F16);
+#undef ODTK_LOSS
+  }
+  ODTK_HIP_TRY(hipGetLastError());
+  return ODTK_OK;
+}
+
 int decode_single(bool rotated, int batch, const void *const *inputs, void *const *outputs, size_t height,
                   size_t width, size_t scale, size_t A, size_t C, const float *anchors, size_t anchors_len,
                   float thresh, int top_n, void *workspace, size_t workspace_size, void *stream) {
@@ -458,10 +501,10 @@ int odtk_iou(const void *const *inputs, void *const *outputs, int num_boxes, int
 int odtk_snap_to_anchors(int batch_size, const float *targets, int n_max, const float *anchors, int num_anchors,
                          int num_classes, int height, int width, int stride, float iou_background,
                          float iou_foreground, float *cls_target, float *box_target, float *depth, void *stream) {
-  if (batch_size <= 0 || n_max < 0 || n_max > odtk::kSnapMaxBoxes || num_anchors <= 0 ||
-      num_anchors > ODTK_MAX_ANCHORS || num_classes <= 0 || height <= 0 || width <= 0)
+  if (batch_size <= 0 || n_max < 0 || num_anchors <= 0 || num_anchors > ODTK_MAX_ANCHORS || num_classes <= 0 ||
+      height <= 0 || width <= 0)
     return ODTK_ERR_INVALID;
-  if (!anchors || !cls_target || !box_target || !depth || (n_max > 0 && !targets)) return ODTK_ERR_INVALID;
+  if (!anchors || !box_target || !depth || (n_max > 0 && !targets)) return ODTK_ERR_INVALID;   // cls_target may be null
   odtk::SnapArgs sa;
   std::memset(&sa, 0, sizeof sa);
   sa.targets = targets;
@@ -486,6 +529,29 @@ int odtk_snap_to_anchors(int batch_size, const float *targets, int n_max, const 
   }
   ODTK_HIP_TRY(hipGetLastError());
   return ODTK_OK;
+}
+
+int odtk_retina_loss_forward(const void *cls, const void *box, const float *depth, const float *box_target,
+                             int batch_size, int num_anchors, int num_classes, int height, int width, int box_params,
+                             int dtype, int channels_last, float alpha, float gamma, float beta, double *sums,
+                             void *stream) {
+  if (!sums) return ODTK_ERR_INVALID;
+  ODTK_HIP_TRY(hipMemsetAsync(sums, 0, 3 * sizeof(double), static_cast<hipStream_t>(stream)));
+  return retina_loss_launch(false, cls, box, depth, box_target, batch_size, num_anchors, num_classes, height, width,
+                            box_params, dtype, channels_last, alpha, gamma, beta, sums, nullptr, nullptr, nullptr, nullptr,
+                            static_cast<hipStream_t>(stream));
+}
+
+int odtk_retina_loss_backward(const void *cls, const void *box, const float *depth, const float *box_target,
+                              int batch_size, int num_anchors, int num_classes, int height, int width, int box_params,
+                              int dtype, int channels_last, float alpha, float gamma, float beta,
+                              const float *grad_cls_sum, const float *grad_box_sum, void *dcls, void *dbox,
+                              void *stream) {
+  if (!dcls || !dbox) return ODTK_ERR_INVALID;
+  if ((reinterpret_cast<uintptr_t>(dcls) | reinterpret_cast<uintptr_t>(dbox)) & 15u) return ODTK_ERR_INVALID;
+  return retina_loss_launch(true, cls, box, depth, box_target, batch_size, num_anchors, num_classes, height, width,
+                            box_params, dtype, channels_last, alpha, gamma, beta, nullptr, grad_cls_sum, grad_box_sum, dcls,
+                            dbox, static_cast<hipStream_t>(stream));
 }
 
 int odtk_bias_act_maxpool(const void *y, const float *bias, void *out, int batch_size, int height, int width,

@@ -63,6 +63,9 @@ _SIGNATURES = {
     'odtk_snap_to_anchors': (ctypes.c_int, [ctypes.c_int, _vp, ctypes.c_int, _fp, ctypes.c_int, ctypes.c_int,
                                             ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float,
                                             _vp, _vp, _vp, _vp]),
+    'odtk_retina_loss_forward': (ctypes.c_int, [_vp, _vp, _vp, _vp] + [ctypes.c_int] * 8 + [ctypes.c_float] * 3 + [_vp, _vp]),
+    'odtk_retina_loss_backward': (ctypes.c_int, [_vp, _vp, _vp, _vp] + [ctypes.c_int] * 8 + [ctypes.c_float] * 3 +
+                                  [_vp, _vp, _vp, _vp, _vp]),
     'odtk_bias_act': (ctypes.c_int, [_vp, _vp, _vp, _sz, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp]),
     'odtk_profile_enable': (ctypes.c_int, [ctypes.c_int]),
     'odtk_debug_set_trace': (ctypes.c_int, [_vp]),
@@ -76,7 +79,7 @@ _SIGNATURES = {
 }
 
 KERNEL_NAMES = ('prefilter_scan_kernel', 'select_decode_kernel', 'nms_kernel', 'iou_pairs_kernel', 'bias_act_kernel',
-                'snap_to_anchors_kernel', 'gemm_bias_act')
+                'snap_to_anchors_kernel', 'gemm_bias_act', 'retina_loss_kernel', 'select_hist_kernel', 'select_filter_kernel')
 
 _lib = None
 
@@ -331,10 +334,12 @@ def detect(cls_heads, box_heads, anchors_list, strides, score_thresh, top_n, nms
     return out
 
 
-def snap_to_anchors(targets, anchors, num_classes, height, width, stride, iou_background, iou_foreground):
+def snap_to_anchors(targets, anchors, num_classes, height, width, stride, iou_background, iou_foreground,
+                    want_cls_target=True):
     """Fused target assignment of one pyramid level for the whole batch (reference box.py:134-189 per
     image).  targets: float32 CUDA [B, N, 5] (x, y, w, h, class; class < 0 = padding row).
-    -> cls_target [B, A, C, H, W], box_target [B, A, 4, H, W], depth [B, A, 1, H, W]."""
+    -> cls_target [B, A, C, H, W] (None with want_cls_target=False: the fused loss derives it from depth),
+    box_target [B, A, 4, H, W], depth [B, A, 1, H, W]."""
     _check_input(targets, 'targets')
     if targets.dim() != 3 or targets.shape[2] != 5:
         raise RuntimeError('targets must be [B, N, 5]')
@@ -343,15 +348,78 @@ def snap_to_anchors(targets, anchors, num_classes, height, width, stride, iou_ba
     b, n_max = targets.shape[0], targets.shape[1]
     dev = targets.device
     with torch.cuda.device(dev):
-        cls = torch.empty((b, a, num_classes, height, width), dtype=torch.float32, device=dev)
+        cls = torch.empty((b, a, num_classes, height, width), dtype=torch.float32, device=dev) if want_cls_target else None
         box_t = torch.empty((b, a, 4, height, width), dtype=torch.float32, device=dev)
         depth = torch.empty((b, a, 1, height, width), dtype=torch.float32, device=dev)
         stream = torch.cuda.current_stream(dev).cuda_stream
         _check(library().odtk_snap_to_anchors(b, targets.data_ptr(), n_max, arr, a, int(num_classes), int(height),
                                               int(width), int(stride), float(iou_background), float(iou_foreground),
-                                              cls.data_ptr(), box_t.data_ptr(), depth.data_ptr(), stream),
+                                              cls.data_ptr() if cls is not None else None, box_t.data_ptr(),
+                                              depth.data_ptr(), stream),
                'snap_to_anchors')
     return cls, box_t, depth
+
+
+def _loss_geometry(cls_head, box_head, depth, box_target):
+    """Shared validation of the fused loss entry points -> (B, A, C, H, W, nb, dtype enum, channels_last)."""
+    if not (cls_head.is_cuda and box_head.is_cuda and depth.is_cuda and box_target.is_cuda):
+        raise RuntimeError('retina_loss: tensors must be on the GPU')
+    if cls_head.dim() != 4 or box_head.dim() != 4 or depth.dim() != 5 or box_target.dim() != 5:
+        raise RuntimeError('retina_loss: cls/box must be [B, ch, H, W], depth [B, A, 1, H, W], box_target [B, A, nb, H, W]')
+    lay = _layout(cls_head, 'cls_head')
+    b, ch, h, w = cls_head.shape
+    if h * w > 1 and _layout(box_head, 'box_head') != lay:
+        raise RuntimeError('retina_loss: cls_head and box_head must share one memory format')
+    a, nb = box_target.shape[1], box_target.shape[2]
+    if cls_head.dtype not in _DTYPES or box_head.dtype != cls_head.dtype:
+        raise RuntimeError('retina_loss: heads must share one dtype out of float32 / bfloat16 / float16')
+    if ch % a or depth.shape != (b, a, 1, h, w) or box_target.shape != (b, a, nb, h, w) or box_head.shape != (b, a * nb, h, w):
+        raise RuntimeError('retina_loss: inconsistent shapes')
+    if depth.dtype != torch.float32 or box_target.dtype != torch.float32 or not depth.is_contiguous() or not box_target.is_contiguous():
+        raise RuntimeError('retina_loss: depth and box_target must be contiguous float32')
+    return b, a, ch // a, h, w, nb, _DTYPES[cls_head.dtype], lay
+
+
+def retina_loss_forward(cls_head, box_head, depth, box_target, alpha, gamma, beta):
+    """-> float64 CUDA tensor [3] = (sum of masked focal losses, sum of masked smooth-L1 losses, #foreground anchors)
+    of one level (reference model.py:193-209 + loss.py:13-31 in one pass; csrc/loss.hpp)."""
+    b, a, c, h, w, nb, dtype, lay = _loss_geometry(cls_head, box_head, depth, box_target)
+    dev = cls_head.device
+    with torch.cuda.device(dev):
+        sums = torch.empty(3, dtype=torch.float64, device=dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _check(library().odtk_retina_loss_forward(cls_head.data_ptr(), box_head.data_ptr(), depth.data_ptr(),
+                                                  box_target.data_ptr(), b, a, c, h, w, nb, dtype, lay, float(alpha),
+                                                  float(gamma), float(beta), sums.data_ptr(), stream), 'retina_loss_forward')
+    return sums
+
+
+def retina_loss_backward(cls_head, box_head, depth, box_target, alpha, gamma, beta, grad_cls_sum, grad_box_sum):
+    """Gradients of (g_cls * cls_sum + g_box * box_sum) w.r.t. the two heads, in the heads' dtype and layout.
+    grad_*: float32 CUDA scalars (or None = 0), read on the device."""
+    b, a, c, h, w, nb, dtype, lay = _loss_geometry(cls_head, box_head, depth, box_target)
+    dev = cls_head.device
+
+    def scalar(g):
+        if g is None:
+            return None
+        g = g.detach().to(device=dev, dtype=torch.float32).reshape(1)
+        return g
+
+    g_cls, g_box = scalar(grad_cls_sum), scalar(grad_box_sum)
+    with torch.cuda.device(dev):
+        dcls = torch.empty_like(cls_head)                   # preserves the (dense) memory format
+        dbox = torch.empty_like(box_head)
+        if dcls.stride() != cls_head.stride() or dbox.stride() != box_head.stride():
+            raise RuntimeError('retina_loss_backward: could not allocate gradients in the heads\' layout')
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _check(library().odtk_retina_loss_backward(cls_head.data_ptr(), box_head.data_ptr(), depth.data_ptr(),
+                                                   box_target.data_ptr(), b, a, c, h, w, nb, dtype, lay, float(alpha),
+                                                   float(gamma), float(beta),
+                                                   g_cls.data_ptr() if g_cls is not None else None,
+                                                   g_box.data_ptr() if g_box is not None else None,
+                                                   dcls.data_ptr(), dbox.data_ptr(), stream), 'retina_loss_backward')
+    return dcls, dbox
 
 
 def bias_act_(y, bias, residual=None, relu=True):

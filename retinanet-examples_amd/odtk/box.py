@@ -178,13 +178,13 @@ def snap_to_anchors(boxes, size, stride, anchors, num_classes, device, anchor_io
                                  box2delta)
 
 
-def snap_to_anchors_batched(targets, width, height, stride, anchors, num_classes, anchor_ious):
+def snap_to_anchors_batched(targets, width, height, stride, anchors, num_classes, anchor_ious, want_cls_target=True):
     """snap_to_anchors for every image of the batch in ONE fused HIP launch (GPU only).
     targets [B, N, 5] padded with class = -1 rows (reference data.py:154-161 format).
     Returns the stacked (cls_target [B,A,C,H,W], box_target [B,A,4,H,W], depth [B,A,1,H,W])."""
     _require_gpu(targets, 'snap_to_anchors_batched')
     return _C.snap_to_anchors(targets.float().contiguous(), anchors, num_classes, int(height), int(width),
-                              int(stride), anchor_ious[0], anchor_ious[1])
+                              int(stride), anchor_ious[0], anchor_ious[1], want_cls_target)
 
 
 def rotate_boxes(boxes, points=False):

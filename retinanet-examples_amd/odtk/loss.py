@@ -1,8 +1,13 @@
 """Training losses of RetinaNet on PyTorch-ROCm: the focal classification loss
 (https://arxiv.org/abs/1708.02002) and the smooth-L1 box loss.  Both are elementwise (no reduction);
 `Model._compute_loss` masks and sums them.  Values follow the reference's definitions
-(reference odtk/loss.py:13-31: alpha = 0.25, gamma = 2, beta = 0.11); the north star keeps these off
-the hand-written HIP path."""
+(reference odtk/loss.py:13-31: alpha = 0.25, gamma = 2, beta = 0.11).
+
+`fused_level_loss` is the MI355X form of one level's share of `Model._compute_loss`
+(reference model.py:193-209): focal loss, smooth-L1, both masks and the three sums in ONE hand-written HIP
+pass over the head tensors as the convolutions wrote them, and ONE pass in backward (csrc/loss.hpp) -- an
+`autograd.Function`, so it drops into the training graph; the torch modules below stay as the reference
+implementation it is tested against (tests/test_gpu_loss.py) and as the CPU path."""
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -42,3 +47,46 @@ class SmoothL1Loss(nn.Module):
 
     def forward(self, pred, target):
         return smooth_l1_loss(pred, target, self.beta)
+
+
+class _FusedLevelLoss(torch.autograd.Function):
+    """(cls_head, box_head) -> (cls_sum, box_sum, foreground) for one pyramid level of the batch."""
+
+    @staticmethod
+    def forward(ctx, cls_head, box_head, depth, box_target, alpha, gamma, beta):
+        from . import _C
+        sums = _C.retina_loss_forward(cls_head, box_head, depth, box_target, alpha, gamma, beta)
+        ctx.save_for_backward(cls_head, box_head, depth, box_target)
+        ctx.hyper = (alpha, gamma, beta)
+        out = sums.float()
+        foreground = out[2]
+        ctx.mark_non_differentiable(foreground)
+        return out[0], out[1], foreground
+
+    @staticmethod
+    def backward(ctx, grad_cls_sum, grad_box_sum, _grad_foreground):
+        from . import _C
+        cls_head, box_head, depth, box_target = ctx.saved_tensors
+        dcls, dbox = _C.retina_loss_backward(cls_head, box_head, depth, box_target, *ctx.hyper, grad_cls_sum, grad_box_sum)
+        return dcls, dbox, None, None, None, None, None
+
+
+def fused_level_loss(cls_head, box_head, depth, box_target, alpha=0.25, gamma=2.0, beta=0.11):
+    """One level's (sum of masked focal losses, sum of masked smooth-L1 losses, number of foreground anchors).
+
+    cls_head [B, A*C, H, W] logits and box_head [B, A*nb, H, W] as the convolutions wrote them (float32 /
+    bfloat16 / float16, NCHW or channels_last -- no .float(), no .contiguous()); depth [B, A, 1, H, W] and
+    box_target [B, A, nb, H, W] float32 from target assignment.  Equals, and differentiates like,
+
+        cls = FocalLoss(alpha, gamma)(cls_head.view(B, A, C, H, W).float(), onehot(depth - 1))
+        (cls * (depth >= 0)).sum(), (SmoothL1Loss(beta)(box_head.view_as(box_target).float(), box_target)
+                                     * (depth > 0)).sum(), (depth > 0).sum()"""
+    pair = [cls_head, box_head]
+    for i, t in enumerate(pair):
+        if not (t.is_contiguous() or t.is_contiguous(memory_format=torch.channels_last)):
+            pair[i] = t.contiguous()
+    if pair[0].is_contiguous() != pair[1].is_contiguous() and pair[0].shape[2] * pair[0].shape[3] > 1:
+        pair[1] = pair[1].contiguous() if pair[0].is_contiguous() else pair[1].contiguous(memory_format=torch.channels_last)
+    if pair[1].dtype != pair[0].dtype:
+        pair[1] = pair[1].to(pair[0].dtype)
+    return _FusedLevelLoss.apply(pair[0], pair[1], depth.contiguous(), box_target.contiguous(), alpha, gamma, beta)

@@ -27,7 +27,7 @@ import torch.nn as nn
 
 from . import backbones as backbones_mod
 from . import box as box_ops
-from .loss import FocalLoss, SmoothL1Loss
+from .loss import FocalLoss, SmoothL1Loss, fused_level_loss
 
 DEFAULT_RATIOS = [1.0, 2.0, 0.5]
 DEFAULT_SCALES = [4 * 2 ** (i / 3) for i in range(3)]
@@ -84,6 +84,7 @@ class Model(nn.Module):
         self.exporting = False
         self.fused_postprocess = True
         self.fused_graph = True                             # eval on a GPU runs the BN-folded engine (odtk/fused.py)
+        self.fused_loss = True                              # training on a GPU: HIP focal / smooth-L1 reduction (csrc/loss.hpp)
         self.__dict__['_engine_cache'] = {}                 # (not a submodule: keeps state_dict / checkpoints unchanged)
 
         self.num_anchors = len(ratios) * len(scales) * (len(self.angles) if rotated_bbox else 1)
@@ -231,13 +232,13 @@ class Model(nn.Module):
         return suppress(*[torch.cat(parts, 1) for parts in zip(*per_level)], self.nms, self.detections)
 
     # ------------------------------------------------------------------ training loss
-    def _extract_targets(self, targets, stride, size):
+    def _extract_targets(self, targets, stride, size, want_cls_target=True):
         """Per-image target assignment of one level, stacked over the batch (reference model.py:167-184)."""
         anchors = self.level_anchors(stride)
-        if targets.is_cuda and not self.rotated_bbox and targets.shape[1] <= 1024:
+        if targets.is_cuda and not self.rotated_bbox:
             # one fused HIP launch for the whole batch (csrc/targets.hpp) instead of ~25 torch ops per image
             return box_ops.snap_to_anchors_batched(targets, size[1], size[0], stride, anchors, self.classes,
-                                                   self.anchor_ious)
+                                                   self.anchor_ious, want_cls_target)
         assign = box_ops.snap_to_anchors_rotated if self.rotated_bbox else box_ops.snap_to_anchors
         if not self.rotated_bbox:
             anchors = anchors.to(targets.device)
@@ -250,9 +251,18 @@ class Model(nn.Module):
         """Focal + smooth-L1 losses summed over levels and normalised by the number of foreground
         anchors (reference model.py:186-210); `depth` is -1 ignore / 0 background / class+1."""
         cls_total, box_total, foreground = 0.0, 0.0, 0.0
+        fused = self.fused_loss and cls_heads[0].is_cuda
         for cls_head, box_head in zip(cls_heads, box_heads):
             stride = x.shape[-1] / cls_head.shape[-1]
-            cls_target, box_target, depth = self._extract_targets(targets, stride, cls_head.shape[-2:])
+            cls_target, box_target, depth = self._extract_targets(targets, stride, cls_head.shape[-2:], not fused)
+            if fused:
+                # focal + smooth-L1 + masks + sums of this level in one HIP pass (and one in backward); the class
+                # target is implied by depth, so the one-hot map above was not even built
+                cls_sum, box_sum, fg = fused_level_loss(cls_head, box_head, depth, box_target, self.cls_criterion.alpha,
+                                                        self.cls_criterion.gamma, self.box_criterion.beta)
+                foreground = foreground + fg.clamp(min=1)
+                cls_total, box_total = cls_total + cls_sum, box_total + box_sum
+                continue
             foreground = foreground + (depth > 0).sum().float().clamp(min=1)
             cls_loss = self.cls_criterion(cls_head.view_as(cls_target).float(), cls_target)
             cls_total = cls_total + (cls_loss * (depth >= 0).expand_as(cls_target).float()).sum()

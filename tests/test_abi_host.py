@@ -78,16 +78,26 @@ def test_detect_workspace_covers_decode_plus_candidates():
     assert lib.odtk_decode_levels(4, 2, lv, 9, 80, _C.F32, 0, 0.05, 1000, None, 0, None, 0, None) == _C.ERR_INVALID
 
 
-def test_python_surface_has_no_cpu_fallback():
+def test_hip_boundary_has_no_cpu_fallback():
+    """The operator boundary (odtk._C) and the batched HIP forms never run on the CPU: CPU tensors raise.  Only the
+    reference's own "no GPU" plumbing branch exists on the Python surface (box.decode / box.nms on CPU tensors,
+    pure torch, tests/test_config0_cpu.py) -- and it is chosen by the tensor's device, never as a fallback for a
+    missing library."""
     cls = torch.rand(1, 9 * 4, 3, 3)
     deltas = torch.zeros(1, 36, 3, 3)
     anchors = box.generate_anchors(8, RATIOS, SCALES)
-    with pytest.raises(RuntimeError, match='no CPU path'):
-        box.decode(cls, deltas, 8, 0.05, 10, anchors)
-    with pytest.raises(RuntimeError, match='no CPU path'):
-        box.nms(torch.rand(1, 5), torch.rand(1, 5, 4), torch.zeros(1, 5))
+    with pytest.raises(RuntimeError, match='must be on the GPU'):
+        box.detect([cls], [deltas], [8], {8: anchors})
+    with pytest.raises(RuntimeError, match='must be on the GPU'):
+        box.decode_levels([cls], [deltas], [8], 0.05, 10, {8: anchors})
+    with pytest.raises(RuntimeError, match='must be on the GPU'):
+        box.nms_rotated(torch.rand(1, 5), torch.rand(1, 5, 6), torch.zeros(1, 5))
     with pytest.raises(RuntimeError, match='must be a CUDA tensor'):
         _C.decode(cls, deltas, anchors.view(-1).tolist(), 8, 0.05, 10)
+    with pytest.raises(RuntimeError, match='must be a CUDA tensor'):
+        _C.nms(torch.rand(1, 5), torch.rand(1, 5, 4), torch.zeros(1, 5), 0.5, 3)
+    with pytest.raises(RuntimeError, match='must be on the GPU'):
+        _C.retina_loss_forward(cls, deltas, torch.zeros(1, 9, 1, 3, 3), torch.zeros(1, 9, 4, 3, 3), 0.25, 2.0, 0.11)
     with pytest.raises(NotImplementedError):
         _C.Engine()
 

@@ -1,15 +1,25 @@
-"""BASELINE.json's full configuration (bs=8, 800x1280, 5 levels, A=9, C=80: 122.9 M scores per
-batch) is far too big for the CPU oracle, so parity at that size is checked through size-independent
-properties and through torch's own GPU ops as an independent implementation:
+"""BASELINE.json's full configurations (800x1280, 5 levels, A=9 / 27, C=80; bs 8 = 122.9 M scores per batch,
+bs 16 = 245.7 M, rotated bs 8 = 368.6 M) on the GPU, checked two ways:
+
+(1) against the ORACLE at full size, image by image (`test_full_size_vs_oracle*`): the same head tensors go
+    to `oracle.box_oracle` (torch CPU restatement pinned to the reference's odtk/box.py; ~50 ms - 1 s per
+    image) / `oracle.c_oracle` (rotated) and to the HIP path.  Decode: flat indices, scores and classes bit
+    for bit, boxes within 1e-4 (1 ulp above 1024 px); NMS: kept positions, scores, boxes, classes bit for
+    bit on identical candidates, and the whole pipeline end to end.  This is where the > 4096-candidate
+    radix descent, the multi-workgroup selection passes, 2-tile spans and the 16 sub-lists see real densities.
+(2) through size-independent properties and torch's own GPU ops as an independent implementation
+    (`test_full_size_properties`):
   * per (image, level): emitted scores are exactly torch.topk's values (bit for bit), sorted,
     and their count is min(top_n, #{score >= thr});
   * every emitted index points at its score, is unique, and yields the emitted class;
   * boxes lie inside the level's clamp window;
   * detect == nms(decode_levels); NMS is idempotent; kept boxes of one class never overlap > thr.
 """
+import numpy as np
 import pytest
 import torch
 
+from oracle import box_oracle, c_oracle
 from odtk import _C, box, synthetic
 
 pytestmark = pytest.mark.gpu
@@ -19,14 +29,14 @@ SCALES = [4 * 2 ** (i / 3) for i in range(3)]
 STRIDES = [8, 16, 32, 64, 128]
 
 
-def full_heads(kind, dtype, logits, channels_last, batch=8, seed=4321):
+def full_heads(kind, dtype, logits, channels_last, batch=8, seed=4321, num_anchors=9, nb=4):
     g = torch.Generator(device='cuda').manual_seed(seed)
     cls, dl = [], []
     for (h, w) in synthetic.level_shapes(800, 1280, STRIDES):
-        c = torch.randn((batch, 720, h, w), generator=g, device='cuda') * synthetic.SIGMA[kind] + synthetic.LOGIT_PRIOR
+        c = torch.randn((batch, num_anchors * 80, h, w), generator=g, device='cuda') * synthetic.SIGMA[kind] + synthetic.LOGIT_PRIOR
         if not logits:
             c = c.sigmoid()
-        d = torch.randn((batch, 36, h, w), generator=g, device='cuda') * 0.2
+        d = torch.randn((batch, num_anchors * nb, h, w), generator=g, device='cuda') * 0.2
         c, d = c.to(dtype), d.to(dtype)
         if channels_last:
             c, d = c.contiguous(memory_format=torch.channels_last), d.contiguous(memory_format=torch.channels_last)
@@ -116,3 +126,88 @@ def test_full_size_saturated_and_empty():
     assert torch.all(out[3] == -1) and torch.all(out[0] == 0) and torch.all(out[1] == 0)
     det = box.detect(cls, dl, STRIDES, anchors)
     assert torch.all(det[0] == 0)
+
+
+# ------------------------------------------------------------------------------------------------
+# (1) the oracle at full size
+# ------------------------------------------------------------------------------------------------
+BOX_ATOL = 1e-4
+
+
+def _boxes_close(got, ref, what):
+    got, ref = got.double(), ref.double()
+    tol = torch.maximum(torch.full_like(ref, BOX_ATOL), torch.from_numpy(np.spacing(ref.abs().float().numpy())).double())
+    bad = (got - ref).abs() > tol
+    assert not bool(bad.any()), '%s: max |diff| %.3g' % (what, float((got - ref).abs()[bad].max()))
+
+
+@pytest.mark.parametrize('kind,dtype,logits,channels_last,batch', [
+    ('sparse', torch.float32, False, False, 8),      # config 2 parity sub-run: fp32 post-sigmoid scores, the reference boundary
+    ('sparse', torch.bfloat16, True, True, 8),       # config 2 as timed: bf16 channels_last logits, fused sigmoid (massive ties)
+    ('dense', torch.float32, False, False, 8),       # 5 % candidates: 570 k keys per image on P3
+    ('sparse', torch.bfloat16, True, True, 16),      # config 4's batch
+], ids=['cfg2-fp32-scores-bs8', 'cfg2-bf16-logits-bs8', 'dense-fp32-bs8', 'cfg4-bf16-logits-bs16'])
+def test_full_size_vs_oracle(kind, dtype, logits, channels_last, batch):
+    top_n, thr, nms_thr, ndet = 1000, 0.05, 0.5, 100
+    cls, dl = full_heads(kind, dtype, logits, channels_last, batch=batch, seed=97)
+    anchors = {s: box.generate_anchors(s, RATIOS, SCALES) for s in STRIDES}
+    dec = _C.decode_levels(cls, dl, [anchors[s] for s in STRIDES], STRIDES, thr, top_n, False, return_indices=True,
+                           logits=logits)
+    det = box.detect(cls, dl, STRIDES, anchors, thr, top_n, nms_thr, ndet, logits=logits)
+    hip_nms = _C.nms(dec[0], dec[1], dec[2], nms_thr, ndet, return_indices=True)
+    dec = [t.cpu() for t in dec]
+    det = [t.cpu() for t in det]
+    hip_nms = [t.cpu() for t in hip_nms]
+    n_dense_segments = 0
+    for b in range(batch):
+        # what the op sees, as the reference's boundary would receive it: fp32 NCHW post-sigmoid scores
+        # (torch's own sigmoid in the tensor's dtype, then .float() -- model.py:140, box.py:263)
+        scores = [(c[b:b + 1].sigmoid() if logits else c[b:b + 1]).float().contiguous().cpu() for c in cls]
+        deltas = [d[b:b + 1].float().contiguous().cpu() for d in dl]
+        ref_levels = [box_oracle.decode(s, d, st, thr, top_n, anchors[st], return_indices=True)
+                      for s, d, st in zip(scores, deltas, STRIDES)]
+        n_dense_segments += sum(int((s >= thr).sum()) > 4096 for s in scores)
+        ref = [torch.cat(t, 1) for t in zip(*ref_levels)]
+        assert torch.equal(dec[3][b].long(), ref[3][0]), 'image %d: flat indices' % b
+        assert torch.equal(dec[0][b], ref[0][0]), 'image %d: scores' % b
+        assert torch.equal(dec[2][b], ref[2][0]), 'image %d: classes' % b
+        _boxes_close(dec[1][b], ref[1][0], 'image %d: boxes' % b)
+        # NMS on identical candidates (the HIP decode's): everything bit for bit, kept positions included
+        ref_nms = box_oracle.nms(dec[0][b:b + 1], dec[1][b:b + 1], dec[2][b:b + 1], nms_thr, ndet, return_indices=True)
+        assert torch.equal(hip_nms[3][b].long(), ref_nms[3][0]), 'image %d: kept positions' % b
+        for k in range(3):
+            assert torch.equal(hip_nms[k][b], ref_nms[k][0]), 'image %d: nms output %d' % (b, k)
+        # the whole pipeline, oracle end to end
+        ref_e2e = box_oracle.nms(ref[0], ref[1], ref[2], nms_thr, ndet)
+        assert torch.equal(det[0][b], ref_e2e[0][0]) and torch.equal(det[2][b], ref_e2e[2][0]), 'image %d: end to end' % b
+        _boxes_close(det[1][b], ref_e2e[1][0], 'image %d: end-to-end boxes' % b)
+        assert int((det[0][b] > 0).sum()) == ndet
+    assert n_dense_segments >= batch          # P3 (at least) went through the > 4096-candidate selection path
+
+
+def test_full_size_rotated_vs_oracle():
+    """Config 5 at full size: A = 27, 6 box parameters, 46.07 M scores per image, bs 8.  The C restatement
+    (pinned to the reference's decode_rotate.cu lambda / nms_iou.cu device code) checks images 0 and 7 of
+    the batch -- a subset because one image costs the single-threaded C oracle seconds; the HIP launch is
+    the full bs-8 one."""
+    top_n, thr, nms_thr, ndet, batch = 1000, 0.05, 0.5, 100, 8
+    cls, dl = full_heads('sparse', torch.bfloat16, True, True, batch=batch, seed=131, num_anchors=27, nb=6)
+    angles = [-np.pi / 6, 0, np.pi / 6]
+    anchors = {s: box.generate_anchors_rotated(s, RATIOS, SCALES, angles) for s in STRIDES}
+    dec = _C.decode_levels(cls, dl, [anchors[s][0] for s in STRIDES], STRIDES, thr, top_n, True, return_indices=True,
+                           logits=True)
+    det = box.detect(cls, dl, STRIDES, anchors, thr, top_n, nms_thr, ndet, rotated=True, logits=True)
+    dec = [t.cpu().numpy() for t in dec]
+    det = [t.cpu().numpy() for t in det]
+    for b in (0, batch - 1):
+        per = [c_oracle.decode(c[b:b + 1].sigmoid().float().contiguous().cpu().numpy(),
+                               d[b:b + 1].float().contiguous().cpu().numpy(), st, thr, top_n, anchors[st][0].numpy(),
+                               rotated=True) for c, d, st in zip(cls, dl, STRIDES)]
+        ref = [np.concatenate(t, 1) for t in zip(*per)]
+        assert np.array_equal(dec[3][b].astype(np.int64), ref[3][0]), 'image %d: flat indices' % b
+        for k, name in ((0, 'scores'), (1, 'boxes'), (2, 'classes')):     # the C oracle rounds exp() like the kernel: bits
+            assert np.array_equal(dec[k][b].view(np.uint32), ref[k][0].view(np.uint32)), 'image %d: %s' % (b, name)
+        ref_nms = c_oracle.nms(ref[0], ref[1], ref[2], nms_thr, ndet, rotated=True)
+        for k, name in ((0, 'scores'), (1, 'boxes'), (2, 'classes')):
+            assert np.array_equal(det[k][b].view(np.uint32), ref_nms[k][0].view(np.uint32)), 'image %d: nms %s' % (b, name)
+        assert int((ref_nms[0] > 0).sum()) > 20

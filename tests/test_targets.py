@@ -135,20 +135,51 @@ def test_fused_kernel_random_batches_vs_oracle():
 
 @pytest.mark.gpu
 def test_training_loss_fused_equals_torch_targets():
-    """Model._compute_loss with the fused HIP target assignment == with the per-image torch path."""
+    """Model._compute_loss with the fused HIP target assignment == with the per-image torch path (rotated=False
+    models take the kernel for ANY number of target rows; the torch path is forced by patching the dispatcher)."""
     from odtk.model import Model
     from odtk import train as T
     torch.manual_seed(0)
     m = Model('ResNet18FPN', classes=6)
     m.initialize(None)
     m = m.cuda().train()
+    m.fused_loss = False                                   # this test is about the targets: torch losses on both sides
     data, target = T.SyntheticBatches(2, 256, 320, classes=6, max_boxes=6, seed=5, device='cuda').batch()
     with torch.no_grad():
         heads = m.heads(data)
         fused = m._compute_loss(data, *heads, target)
-        long_target = torch.cat([target, torch.full((2, 1100, 5), -1.0, device='cuda')], 1)   # > 1024 rows: torch path
-        plain = m._compute_loss(data, *heads, long_target)
+        real = box.snap_to_anchors_batched
+        try:
+            box.snap_to_anchors_batched = lambda t, w, h, s, a, c, i, want=True: tuple(
+                torch.stack(p) for p in zip(*[box.snap_to_anchors(r[r[:, -1] > -1], [w * s, h * s], s, a.to(t.device), c, t.device, i)
+                                              for r in t]))
+            plain = m._compute_loss(data, *heads, target)
+        finally:
+            box.snap_to_anchors_batched = real
     assert torch.allclose(fused[0], plain[0], rtol=1e-6) and torch.allclose(fused[1], plain[1], rtol=1e-5)
+
+
+@pytest.mark.gpu
+def test_fused_kernel_more_than_1024_rows():
+    """n_max > 1024: the rows go through LDS in rounds; first maximum over ALL rows wins, as torch.max."""
+    from odtk import _C
+    g = torch.Generator().manual_seed(3)
+    stride, wpx, hpx, n = 16, 320, 256, 2500
+    anchors = box.generate_anchors(stride, RATIOS, SCALES)
+    xy = torch.rand(n, 2, generator=g) * torch.tensor([wpx * 0.8, hpx * 0.8])
+    wh = torch.rand(n, 2, generator=g) * 80 + 8
+    boxes = torch.cat([xy, wh, torch.randint(0, 80, (n, 1), generator=g).float()], 1)
+    boxes[1500] = boxes[20]                                 # an exact duplicate in a later round: the FIRST must win
+    boxes[1500, 4] = (boxes[20, 4] + 1) % 80
+    targets = _pad([boxes, boxes[:1100]], n + 5)
+    out = _C.snap_to_anchors(targets.cuda(), anchors, 80, hpx // stride, wpx // stride, stride, 0.4, 0.5)
+    nocls = _C.snap_to_anchors(targets.cuda(), anchors, 80, hpx // stride, wpx // stride, stride, 0.4, 0.5, want_cls_target=False)
+    assert nocls[0] is None and torch.equal(nocls[1], out[1]) and torch.equal(nocls[2], out[2])
+    for i, b in enumerate([boxes, boxes[:1100]]):
+        ora = box_oracle.snap_to_anchors(b, [wpx, hpx], stride, anchors, 80, [0.4, 0.5])
+        assert np.array_equal(_bits(out[0][i].cpu().numpy()), _bits(ora[0].numpy()))
+        assert np.array_equal(_bits(out[2][i].cpu().numpy()), _bits(ora[2].numpy()))
+        assert np.allclose(out[1][i].cpu().numpy(), ora[1].numpy(), rtol=1e-6, atol=1e-6)
 
 
 # ---- rotated target assignment against the reference's OWN snap_to_anchors_rotated (odtk/box.py:192-252), run on the
