@@ -215,14 +215,18 @@ class FusedRetinaNet(nn.Module):
             main.wait_event(e)
         return [o[0] for o in out], [o[1] for o in out]
 
+    # The engine owns its dtypes (weights are stored in `self.dtype`, every op runs in it): an enclosing
+    # torch.autocast region -- which is how Model.forward picks the engine's dtype -- must not re-cast anything.
     def heads(self, x):
-        x = x.to(self.dtype).contiguous(memory_format=torch.channels_last)
-        return self._towers(self.features(x), True)
+        with torch.autocast(x.device.type, enabled=False):
+            x = x.to(self.dtype).contiguous(memory_format=torch.channels_last)
+            return self._towers(self.features(x), True)
 
     def heads_without_last_bias(self, x):
         """Head tensors as the last convolutions wrote them (bias NOT added) + the two bias vectors."""
-        x = x.to(self.dtype).contiguous(memory_format=torch.channels_last)
-        cls, box = self._towers(self.features(x), False)
+        with torch.autocast(x.device.type, enabled=False):
+            x = x.to(self.dtype).contiguous(memory_format=torch.channels_last)
+            cls, box = self._towers(self.features(x), False)
         return cls, box, self.cls_head[-1].bias, self.box_head[-1].bias
 
     @torch.no_grad()

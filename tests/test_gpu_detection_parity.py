@@ -10,14 +10,25 @@ substitute is agreement of the DETECTIONS with the reference-style pipeline on t
                  (c) the eager graph under bf16 autocast (`fused_graph = False`), whose frozen-BN kernels cost
                      ~14 % of logit amplitude on this stack
 
-A random-init network fills all 100 detection slots with marginal candidates whose scores are ~1e-3 apart, so
-which of them make the cut is decided by rounding noise.  A reference detection is therefore ELIGIBLE for
-matching only if its score clears the image's 100-th score by `margin` (the bound on |delta score| stated per
-path below); an eligible detection is MATCHED if the candidate path reports a box of the same class with
-IoU >= 0.9 (+1 pixel convention) whose score differs by <= margin.  Required: >= 99 % of the eligible
-detections matched, in both directions, and enough eligible ones for the statement to mean something."""
+A random-init network only offers marginal candidates: its 100 best scores per image lie within ~0.01 of each
+other, ~1e-3 apart, so WHICH of them make the cut is decided by rounding noise of any kind and says nothing
+about a detector.  The test network therefore gets what a trained detector has -- well separated objects:
+`plant_detections` re-fits the LAST classification convolution (only that layer; a weighted ridge regression on
+the fp32 features of this very batch) so that ~45 planted (level, cell, class) triples per image score between
+0.15 and 0.97 and everything else stays at the class prior.  Backbone, FPN, both towers and the box head -- the
+layers whose bf16 arithmetic is under test -- keep their random weights, and the fitted layer itself runs in
+bf16 in the candidate paths.
+
+A reference detection is ELIGIBLE for matching if its score clears the cut (the threshold, or the image's 100-th
+score when the list is full) by `margin` = the bound on |delta score| stated per path below; an eligible
+detection is MATCHED if the candidate path reports a box of the same class with IoU >= 0.9 (+1 pixel convention)
+whose score differs by <= margin.  Required: >= 99 % of the eligible detections matched, in both directions, and
+most detections eligible."""
+import math
+
 import pytest
 import torch
+import torch.nn.functional as F
 
 from oracle import box_oracle
 from odtk.model import Model
@@ -26,17 +37,52 @@ SIZE = (800, 1280)
 BATCH = 2
 
 
-def build_model(seed=0, sigma=0.573):
+def plant_detections(model, x, per_image=45, classes=10, anchor=4, pos_weight=300.0, ridge=1e-2, seed=0):
+    """Weighted ridge regression for the last cls conv on the fp32 features of `x`: planted cells -> a logit whose
+    sigmoid is U(0.15, 0.97), every other cell -> the class prior.  Only `classes` output channels of one anchor
+    shape are fitted, the rest of the layer is zeroed (their scores stay at the prior 0.01)."""
+    g = torch.Generator().manual_seed(seed)
+    dev = x.device
+    last = model.cls_head[-1]
+    prior = float(last.bias[0])
+    with torch.no_grad():
+        pyramid = [f for b in model.backbones.values() for f in b(x)]
+        feats = [model.cls_head[:-1](f) for f in pyramid]
+        dim = feats[0].shape[1] * 9
+        gram = torch.zeros(dim + 1, dim + 1, dtype=torch.float64, device=dev)
+        rhs = torch.zeros(dim + 1, classes, dtype=torch.float64, device=dev)
+        share = [0.5, 0.25, 0.15, 0.07, 0.03]
+        for lvl, f in enumerate(feats):
+            batch, _, h, w = f.shape
+            rows = F.unfold(f, 3, padding=1).permute(0, 2, 1).reshape(-1, dim)      # (c, kh, kw) order = conv weight layout
+            rows = torch.cat([rows, torch.ones(rows.shape[0], 1, device=dev)], 1)
+            want = torch.zeros(rows.shape[0], classes, device=dev)
+            weight = torch.ones(rows.shape[0], 1, device=dev)
+            n = max(1, int(round(per_image * share[lvl])))
+            for b in range(batch):
+                cells = (b * h * w + torch.randperm(h * w, generator=g)[:n]).to(dev)
+                score = torch.rand(n, generator=g) * 0.82 + 0.15
+                want[cells, torch.randint(0, classes, (n,), generator=g).to(dev)] = (torch.log(score / (1 - score)) - prior).to(dev)
+                weight[cells] = pos_weight
+            rows = rows * weight.sqrt()
+            gram += (rows.T @ rows).double()
+            rhs += (rows.T @ (want * weight.sqrt())).double()
+        eye = torch.eye(dim + 1, dtype=torch.float64, device=dev)
+        fit = torch.linalg.solve(gram + ridge * gram.diagonal().mean() * eye, rhs).float()
+        last.weight.zero_()
+        for c in range(classes):
+            ch = anchor * model.classes + c
+            last.weight[ch] = fit[:dim, c].view(last.weight.shape[1], 3, 3)
+            last.bias[ch] = prior + fit[dim, c]
+
+
+def build_model(seed=0, ridge=1e-2):
     torch.manual_seed(seed)
     model = Model('ResNet50FPN', classes=80)
     model.initialize(None)
     model = model.cuda().to(memory_format=torch.channels_last).eval()
     x = torch.randn(BATCH, 3, *SIZE, device='cuda').contiguous(memory_format=torch.channels_last)
-    with torch.no_grad():
-        cls_heads, _ = model.heads(x)                        # fp32 eager: the reference graph
-        bias = model.cls_head[-1].bias.view(1, -1, 1, 1)
-        measured = torch.cat([(c - bias).flatten() for c in cls_heads]).std()
-        model.cls_head[-1].weight.mul_(sigma / measured)     # SURVEY 8(d) sparse-realistic logits
+    plant_detections(model, x, ridge=ridge, seed=seed)       # fp32 eager features: the reference graph
     return model, x
 
 
@@ -114,7 +160,7 @@ MIN_ELIGIBLE = {'engine_fp32': 0.9, 'engine_bf16': 0.5, 'eager_autocast_bf16': 0
 def test_engines_agree_with_fp32_eager_plus_oracle():
     model, x = build_model()
     ref = reference_detections(model, x)
-    assert int((ref[0] > 0).sum()) == BATCH * model.detections
+    assert int((ref[0] >= 0.15).sum()) >= BATCH * 25         # the planted objects are there
     paths = candidate_paths(model, x)
     for name in ('engine_fp32', 'engine_bf16'):
         a = agreement(ref, paths[name], MARGIN[name])

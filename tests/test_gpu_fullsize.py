@@ -4,8 +4,9 @@ bs 16 = 245.7 M, rotated bs 8 = 368.6 M) on the GPU, checked two ways:
 (1) against the ORACLE at full size, image by image (`test_full_size_vs_oracle*`): the same head tensors go
     to `oracle.box_oracle` (torch CPU restatement pinned to the reference's odtk/box.py; ~50 ms - 1 s per
     image) / `oracle.c_oracle` (rotated) and to the HIP path.  Decode: flat indices, scores and classes bit
-    for bit, boxes within 1e-4 (1 ulp above 1024 px); NMS: kept positions, scores, boxes, classes bit for
-    bit on identical candidates, and the whole pipeline end to end.  This is where the > 4096-candidate
+    for bit, boxes within max(1e-4, 2 ulp) of the torch oracle (see `_boxes_close`) and bit for bit against the
+    C oracle; NMS: kept positions, scores, boxes, classes bit for bit on identical candidates, and the whole
+    pipeline end to end.  This is where the > 4096-candidate
     radix descent, the multi-workgroup selection passes, 2-tile spans and the 16 sub-lists see real densities.
 (2) through size-independent properties and torch's own GPU ops as an independent implementation
     (`test_full_size_properties`):
@@ -135,8 +136,14 @@ BOX_ATOL = 1e-4
 
 
 def _boxes_close(got, ref, what):
+    """The only operation of the path that is not bit-reproducible across implementations is exp(): torch's CPU
+    exp (what the reference computes with) is off the correctly rounded value by 1 ulp on 1.1 % of its inputs
+    (measured; it is a closed vector-library routine, not reproducible elsewhere), the kernel and the C oracle
+    round correctly.  One ulp of exp() moves `pw` by one ulp, and `pcx -+ 0.5 * pw (- 1)` rounds twice more, so a
+    corner can land 2 ulp of its own magnitude away: 1.2e-4 at 512..1024 px (seen once in ~40 000 boxes at full
+    size), 2.4e-4 beyond.  Tolerance = max(1e-4, 2 ulp)."""
     got, ref = got.double(), ref.double()
-    tol = torch.maximum(torch.full_like(ref, BOX_ATOL), torch.from_numpy(np.spacing(ref.abs().float().numpy())).double())
+    tol = torch.maximum(torch.full_like(ref, BOX_ATOL), 2 * torch.from_numpy(np.spacing(ref.abs().float().numpy())).double())
     bad = (got - ref).abs() > tol
     assert not bool(bad.any()), '%s: max |diff| %.3g' % (what, float((got - ref).abs()[bad].max()))
 
