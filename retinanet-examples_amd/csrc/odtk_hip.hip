@@ -83,15 +83,27 @@ uint32_t cand_cap_limit() {
   return v;
 }
 
+// ODTK_SELECT_MULTI=0 switches the multi-workgroup selection passes off (A/B measurements): select_decode then walks
+// the candidate lists alone, as in round 1.
+bool multi_pass_enabled() {
+  static const bool on = [] { const char *e = std::getenv("ODTK_SELECT_MULTI"); return !(e && e[0] == '0'); }();
+  return on;
+}
+
 struct DecodeLayout {
-  size_t counts_off, cand_off[ODTK_MAX_LEVELS], total;
+  size_t counts_off, sel_off, zero_bytes, cand_off[ODTK_MAX_LEVELS], surv_off, total;
   uint32_t cap[ODTK_MAX_LEVELS], n[ODTK_MAX_LEVELS];
 };
+static_assert(sizeof(odtk::DecodeArgs) <= 4096 && sizeof(odtk::ScanArgs) <= 4096, "kernel arguments travel by value");
 
 int decode_layout(int batch, int n_levels, const odtk_level_t *levels, int A, int C, DecodeLayout *out) {
   size_t off = 0;
   out->counts_off = off;
   off += align_up(sizeof(uint32_t) * static_cast<size_t>(batch) * n_levels * odtk::kSubLists);
+  // per-segment state of the multi-workgroup selection passes, right behind the counters: ONE memset clears both
+  out->sel_off = off;
+  off += align_up(sizeof(odtk::SelSeg) * static_cast<size_t>(batch) * n_levels);
+  out->zero_bytes = off;
   for (int l = 0; l < n_levels; ++l) {
     const unsigned long long n = 1ull * A * C * levels[l].height * levels[l].width;
     if (n == 0 || n > 0x7fff0000ull) return ODTK_ERR_INVALID;
@@ -112,6 +124,8 @@ int decode_layout(int batch, int n_levels, const odtk_level_t *levels, int A, in
     out->cand_off[l] = off;
     off += align_up(sizeof(uint64_t) * static_cast<size_t>(batch) * odtk::kSubLists * out->cap[l]);
   }
+  out->surv_off = off;
+  off += align_up(sizeof(uint64_t) * static_cast<size_t>(batch) * n_levels * odtk::kSurvCap);
   out->total = off;
   return ODTK_OK;
 }
@@ -135,6 +149,24 @@ int launch_decode(bool rotated, uint32_t tiles, int n_seg, size_t scan_lds, cons
     hipLaunchKernelGGL((odtk::prefilter_scan_kernel<T, kLogits>), dim3(tiles), dim3(odtk::kScanThreads), scan_lds, stream, sa);
   }
   ODTK_HIP_TRY(hipGetLastError());
+  // multi-workgroup narrowing of the segments that hold more candidates than one LDS sort (select_decode.hpp):
+  // histogram, histogram, filter.  Segments below that size leave at the first instruction.
+  const uint32_t pass_blocks = da.part_begin[da.n_levels];
+  if (pass_blocks && da.sel) {
+    {
+      KernelTimer t(ODTK_KERNEL_SELHIST, stream);
+      hipLaunchKernelGGL((odtk::select_pass_kernel<T, kLogits, 0>), dim3(pass_blocks), dim3(odtk::kSelThreads), 0, stream, da);
+    }
+    {
+      KernelTimer t(ODTK_KERNEL_SELHIST, stream);
+      hipLaunchKernelGGL((odtk::select_pass_kernel<T, kLogits, 1>), dim3(pass_blocks), dim3(odtk::kSelThreads), 0, stream, da);
+    }
+    {
+      KernelTimer t(ODTK_KERNEL_SELFILTER, stream);
+      hipLaunchKernelGGL((odtk::select_pass_kernel<T, kLogits, 2>), dim3(pass_blocks), dim3(odtk::kSelThreads), 0, stream, da);
+    }
+    ODTK_HIP_TRY(hipGetLastError());
+  }
   {
     KernelTimer t(ODTK_KERNEL_SELECT, stream);
     if (rotated)
@@ -220,7 +252,20 @@ int decode_levels_impl(int batch, int n_levels, const odtk_level_t *levels, int 
     da.lv[l].cls_bias = levels[l].cls_bias;
     da.lv[l].box_bias = levels[l].box_bias;
     std::memcpy(da.lv[l].anchors, levels[l].anchors, sizeof(float) * 4 * A);
+    // workgroups per segment of the selection passes: one per 2^17 scores of the level, none where a single sort
+    // always suffices
+    uint32_t sort_size = odtk::kSelThreads;
+    while (sort_size < static_cast<uint32_t>(top_n)) sort_size <<= 1;
+    uint32_t parts = lay.n[l] <= sort_size ? 0u : (lay.n[l] + (1u << 17) - 1) >> 17;
+    if (parts > static_cast<uint32_t>(odtk::kSelParts)) parts = odtk::kSelParts;
+    if (!multi_pass_enabled()) parts = 0;
+    da.parts[l] = parts;
+    da.part_begin[l] = l == 0 ? 0u : da.part_begin[l - 1] + da.parts[l - 1] * static_cast<uint32_t>(batch);
   }
+  da.part_begin[n_levels] = da.part_begin[n_levels - 1] + da.parts[n_levels - 1] * static_cast<uint32_t>(batch);
+  for (int l = n_levels + 1; l <= ODTK_MAX_LEVELS; ++l) da.part_begin[l] = da.part_begin[n_levels];
+  da.sel = reinterpret_cast<odtk::SelSeg *>(ws + lay.sel_off);
+  da.surv = reinterpret_cast<uint64_t *>(ws + lay.surv_off);
   sa.counts = counts;
   sa.cand = cand;
   sa.n_levels = n_levels;
@@ -243,7 +288,7 @@ int decode_levels_impl(int batch, int n_levels, const odtk_level_t *levels, int 
   da.trace = g_trace;
 
   const int n_seg = batch * n_levels;
-  ODTK_HIP_TRY(hipMemsetAsync(counts, 0, sizeof(uint32_t) * n_seg * odtk::kSubLists, stream));
+  ODTK_HIP_TRY(hipMemsetAsync(ws + lay.counts_off, 0, lay.zero_bytes - lay.counts_off, stream));   // counters + selection state
   const bool rotated = (flags & ODTK_FLAG_ROTATED) != 0, logits = (flags & ODTK_FLAG_LOGITS) != 0;
   if (dtype == ODTK_F32)
     return logits ? launch_decode<odtk::F32, true>(rotated, tiles, n_seg, scan_lds, sa, da, stream)

@@ -395,15 +395,24 @@ __global__ __launch_bounds__(kScanThreads, (sizeof(typename T::storage) == 2 ? 8
 #pragma unroll 1
       for (int k = 0; k < kStageCap / kScanThreads; ++k) {
         const uint32_t e = c0 + k * kScanThreads + tid;
+        bool hit = false;
+        uint32_t bits = 0;
         if (e < span_vec * kPer) {
           const float raw = load_raw<T>(span_ptr, e);
           const float t_e = bias ? storage_to_float<T>(s_thr[static_cast<uint32_t>((span_base + e) % L.channels)]) : raw_thr;
-          if (raw >= t_e) {
-            uint32_t bits;
-            if constexpr (std::is_same_v<T, F32>) bits = __float_as_uint(raw);
-            else bits = static_cast<const uint16_t *>(static_cast<const void *>(span_ptr))[e];
-            s_stage[atomicAdd(&s_cnt, 1u)] = (static_cast<uint64_t>(bits) << 32) | e;
-          }
+          hit = raw >= t_e;
+          if constexpr (std::is_same_v<T, F32>) bits = __float_as_uint(raw);
+          else bits = static_cast<const uint16_t *>(static_cast<const void *>(span_ptr))[e];
+        }
+        // one LDS atomic per wave, not per hit: in a saturated span EVERY element is a hit, and 2048 atomics on one
+        // LDS word per round serialise (this loop was 1.5 ms of the all-ones launch)
+        const uint64_t m = __ballot(hit);
+        if (m) {
+          const int leader = __ffsll(static_cast<unsigned long long>(m)) - 1;
+          uint32_t slot = 0;
+          if (lane == leader) slot = atomicAdd(&s_cnt, static_cast<uint32_t>(__popcll(m)));
+          slot = __shfl(slot, leader, kWave);
+          if (hit) s_stage[slot + __popcll(m & ((1ull << lane) - 1ull))] = (static_cast<uint64_t>(bits) << 32) | e;
         }
       }
       __syncthreads();

@@ -8,6 +8,11 @@
 // normative: two-sided clamp).
 //
 // Selection is exact for ANY input:
+//   K > sort size           : MULTI-WORKGROUP narrowing first (select_pass_kernel, three launches in front of this
+//                             kernel): two histogram passes over 11-bit digits of the 64-bit keys and one filter pass,
+//                             each walked by up to kSelParts workgroups per segment, leave the <= ~top_n keys at or
+//                             above the boundary bin in a small survivor list; this kernel then only sorts.  (One
+//                             workgroup walking 1e5..1e7 keys three times was the whole cost of this kernel.)
 //   K <= kSortCap           : all candidates are sorted (bitonic network in LDS).
 //   kSortCap < K <= cap     : MSD radix descent (11-bit digits, LDS histograms) on the 64-bit
 //                             keys of the candidate lists narrows down the bin of the top_n-th
@@ -44,8 +49,30 @@ struct DecodeLevel {
   float anchors[ODTK_MAX_ANCHORS * 4];
 };
 
+constexpr int kSelParts = 64;             // workgroups per segment of the multi-workgroup passes (largest levels)
+constexpr uint32_t kSelSlice = 4096;       // candidate keys per workgroup of a pass (list source)
+constexpr uint32_t kSurvCap = 16384;       // survivor keys per segment the filter pass may emit
+
+// Per-segment scratch of the multi-workgroup selection; zeroed by the host memset before every call.
+struct SelSeg {
+  uint32_t hist[2][1 << 11];               // digit histograms of pass 0 / pass 1, bins reversed (largest digit first)
+  unsigned long long kmax;                 // pass 0: largest key, and ...
+  unsigned long long kmin_inv;             // ... largest ~key (= ~smallest key): the bits above their first difference are common
+  unsigned long long prefix, pmask;        // pass 1 (part 0) publishes the state it derived from pass 0 for the filter pass
+  uint32_t hi_bit, remaining, taken, done;
+  unsigned long long T;                    // filter pass (part 0): every key >= T survives ...
+  uint32_t expected;                       // ... exactly this many of them
+  uint32_t filtered;                       // 1: the survivor list is complete and select_decode may use it
+  uint32_t surv_count;                     // append cursor of the filter pass
+  uint32_t pad_;
+};
+
 struct DecodeArgs {
   DecodeLevel lv[ODTK_MAX_LEVELS];
+  uint32_t part_begin[ODTK_MAX_LEVELS + 1];   // first workgroup of each level in a select_pass_kernel launch
+  uint32_t parts[ODTK_MAX_LEVELS];            // workgroups per segment of that level (0: level too small to need any)
+  SelSeg *sel;                                // [n_levels * batch]
+  uint64_t *surv;                             // [n_levels * batch][kSurvCap]
   const uint32_t *counts;
   const uint64_t *cand;
   float *out_scores;     // [batch, n_levels*top_n]
@@ -62,6 +89,10 @@ struct ListSource {   // the kSubLists compacted candidate sub-lists written by 
   const uint64_t *keys;              // sub-list s starts at keys + s * cap
   uint32_t cap;
   uint32_t start[kSubLists + 1];     // exclusive prefix of the (clamped) sub-list lengths: wave-uniform
+  __device__ ListSource(const uint64_t *k, uint32_t n_flat) : keys(k), cap(n_flat) {   // ONE flat list of n_flat keys
+#pragma unroll
+    for (int s = 0; s <= kSubLists; ++s) start[s] = s == 0 ? 0 : n_flat;
+  }
   __device__ ListSource(const uint64_t *k, const uint32_t *counts, uint32_t cap_) : keys(k), cap(cap_) {
     uint32_t acc = 0;
 #pragma unroll
@@ -77,19 +108,37 @@ struct ListSource {   // the kSubLists compacted candidate sub-lists written by 
   template <typename F>
   __device__ __forceinline__ void for_each(F &&f) const {
     const uint32_t total = start[kSubLists];
-    auto address = [&](uint32_t i) -> const uint64_t * {
-      uint32_t s = 0, base = 0;
-#pragma unroll
-      for (int q = 1; q < kSubLists; ++q)
-        if (i >= start[q]) { s = q; base = start[q]; }
-      return keys + static_cast<uint64_t>(s) * cap + (i - base);
-    };
+    auto address = [&](uint32_t i) -> const uint64_t * { return address_of(i); };
     // The lists live in L2 and ONE workgroup walks them: its only source of memory-level parallelism
     // is independent loads per lane.  16 in flight per lane (128 KiB per workgroup), then 4, then 1.
     uint32_t i = threadIdx.x;
     i = batched<16>(i, total, address, f);
     i = batched<4>(i, total, address, f);
     for (; i < total; i += kSelThreads) f(*address(i));
+  }
+  __device__ __forceinline__ const uint64_t *address_of(uint32_t i) const {
+    uint32_t sl = 0, base = 0;
+#pragma unroll
+    for (int q = 1; q < kSubLists; ++q)
+      if (i >= start[q]) { sl = q; base = start[q]; }
+    return keys + static_cast<uint64_t>(sl) * cap + (i - base);
+  }
+  // keys [lo, hi) of the flat order; every lane of the workgroup calls f(key, valid) the same number of times
+  // (wave-level ballots inside f stay legal)
+  template <typename F>
+  __device__ __forceinline__ void for_range(uint32_t lo, uint32_t hi, F &&f) const {
+    for (uint32_t i0 = lo; i0 < hi; i0 += 4 * kSelThreads) {
+      uint64_t k[4];
+      bool ok[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint32_t i = i0 + u * kSelThreads + threadIdx.x;
+        ok[u] = i < hi;
+        k[u] = ok[u] ? *address_of(i) : 0;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) f(k[u], ok[u]);
+    }
   }
   template <int kBatch, typename A, typename F>
   static __device__ __forceinline__ uint32_t batched(uint32_t i, uint32_t total, A &&address, F &&f) {
@@ -222,6 +271,30 @@ __device__ __forceinline__ void sort_keys_desc(uint64_t *s_keys, uint32_t n_vali
   else bitonic_sort_desc_regs<4>(s_keys);
 }
 
+// Given a histogram in s_hist (kRadixBins bins, REVERSED: bin 0 = largest digit) finds the bin in which the running
+// count (from the largest digit down) crosses `remaining`.  All threads return the same (bin, count above it, count
+// inside it).  s_misc: [0..15] wave totals, [16..18] result.  Ends with a barrier; s_hist may be reused afterwards.
+__device__ __forceinline__ void scan_boundary(const uint32_t *s_hist, uint32_t remaining, uint32_t *s_misc, uint32_t *rbin,
+                                              uint32_t *above, uint32_t *in_bin) {
+  // inclusive scan over kRadixBins bins, 2 per thread
+  const uint32_t h0 = s_hist[2 * threadIdx.x], h1 = s_hist[2 * threadIdx.x + 1];
+  const uint32_t inc = wave_inclusive_sum(h0 + h1);
+  const int w = threadIdx.x >> 6;
+  if (lane_id() == kWave - 1) s_misc[w] = inc;
+  __syncthreads();
+  uint32_t woff = 0;
+  for (int i = 0; i < w; ++i) woff += s_misc[i];
+  const uint32_t excl = woff + inc - (h0 + h1);
+  // the unique bin where the running count crosses `remaining`
+  if (excl < remaining && remaining <= excl + h0) { s_misc[16] = 2 * threadIdx.x; s_misc[17] = excl; s_misc[18] = h0; }
+  else if (excl + h0 < remaining && remaining <= excl + h0 + h1) { s_misc[16] = 2 * threadIdx.x + 1; s_misc[17] = excl + h0; s_misc[18] = h1; }
+  __syncthreads();
+  *rbin = s_misc[16];
+  *above = s_misc[17];
+  *in_bin = s_misc[18];
+  __syncthreads();
+}
+
 // MSD radix descent (11-bit digits, LDS histogram) on the bin that holds the `want`-th largest key.
 // Returns a threshold T and *n_out = #{key >= T} with  want <= *n_out <= max_take : the descent
 // stops as soon as everything above the boundary bin plus the bin itself fits `max_take`, so the
@@ -244,21 +317,8 @@ __device__ uint64_t radix_threshold(const Source &src, uint32_t want, uint32_t m
       if ((key & pmask) == prefix) atomicAdd(&s_hist[(nb - 1) - static_cast<uint32_t>((key >> shift) & (nb - 1))], 1u);
     });
     __syncthreads();
-    // inclusive scan over kRadixBins bins, 2 per thread
-    const uint32_t h0 = s_hist[2 * threadIdx.x], h1 = s_hist[2 * threadIdx.x + 1];
-    const uint32_t inc = wave_inclusive_sum(h0 + h1);
-    const int w = threadIdx.x >> 6;
-    if (lane_id() == kWave - 1) s_misc[w] = inc;
-    __syncthreads();
-    uint32_t woff = 0;
-    for (int i = 0; i < w; ++i) woff += s_misc[i];
-    const uint32_t excl = woff + inc - (h0 + h1);
-    // the unique bin where the running count crosses `remaining`
-    if (excl < remaining && remaining <= excl + h0) { s_misc[16] = 2 * threadIdx.x; s_misc[17] = excl; s_misc[18] = h0; }
-    else if (excl + h0 < remaining && remaining <= excl + h0 + h1) { s_misc[16] = 2 * threadIdx.x + 1; s_misc[17] = excl + h0; s_misc[18] = h1; }
-    __syncthreads();
-    const uint32_t rbin = s_misc[16], above = s_misc[17];
-    in_bin = s_misc[18];
+    uint32_t rbin, above;
+    scan_boundary(s_hist, remaining, s_misc, &rbin, &above, &in_bin);
     const uint64_t digit = (nb - 1) - rbin;
     prefix |= digit << shift;
     pmask |= static_cast<uint64_t>(nb - 1) << shift;
@@ -269,6 +329,234 @@ __device__ uint64_t radix_threshold(const Source &src, uint32_t want, uint32_t m
   }
   *n_out = taken_above + in_bin;
   return prefix;                                    // undecided low bits are 0 = start of the boundary bin
+}
+
+// ---- multi-workgroup narrowing (three launches in front of select_decode_kernel) --------------------------
+// pass 0: histogram of the top 11 bits of every key of the segment + the range [min key, max key]
+// pass 1: histogram of the next digit of the keys inside pass 0's boundary bin.  When pass 0 found every key in ONE
+//         bin (saturated scores: all keys share their 32 score bits and differ only in the index bits) the digit
+//         starts at the first bit in which min and max key differ instead of at bit 52, so that two passes always
+//         resolve 22 USEFUL bits.
+// pass 2: every key >= the boundary bin's lower bound goes to the segment's survivor list (a few more than top_n).
+// Up to kSelParts workgroups per segment walk disjoint slices of the candidate lists (or of the raw scores when a
+// sub-list overflowed); segments with <= sort-size candidates skip all three passes.
+struct SelState {
+  uint64_t prefix, pmask;
+  uint32_t hi_bit, remaining, taken, done, in_bin;
+};
+
+__device__ __forceinline__ uint32_t sort_size_for(uint32_t top_n) {
+  uint32_t sort_size = kSelThreads;
+  while (sort_size < top_n) sort_size <<= 1;
+  return sort_size;
+}
+
+// Folds one histogram pass into the state (block-wide, uniform result).  `total` = keys counted by the pass.
+__device__ __forceinline__ void advance_state(SelState &st, const uint32_t *g_hist, uint32_t total, uint64_t kmax, uint64_t kmin,
+                                              bool may_use_range, uint32_t max_take, uint32_t *s_hist, uint32_t *s_misc) {
+  const int bits = st.hi_bit >= static_cast<uint32_t>(kRadixBits) ? kRadixBits : static_cast<int>(st.hi_bit);
+  const int shift = static_cast<int>(st.hi_bit) - bits;
+  const uint32_t nb = 1u << bits;
+  for (uint32_t i = threadIdx.x; i < kRadixBins; i += kSelThreads) s_hist[i] = g_hist[i];
+  __syncthreads();
+  uint32_t rbin, above, in_bin;
+  scan_boundary(s_hist, st.remaining, s_misc, &rbin, &above, &in_bin);
+  st.in_bin = in_bin;
+  if (may_use_range && above == 0 && in_bin == total && st.taken + in_bin > max_take && kmax != kmin) {
+    // every key sits in one bin: nothing was narrowed.  All bits above the first difference of min and max are
+    // common to every key -- jump there.
+    const int hb = 63 - __clzll(static_cast<long long>(kmax ^ kmin));
+    const uint64_t low = hb >= 63 ? ~0ull : ((2ull << hb) - 1ull);
+    st.pmask = ~low;
+    st.prefix = kmax & ~low;
+    st.hi_bit = static_cast<uint32_t>(hb + 1);
+    return;
+  }
+  const uint64_t digit = (nb - 1) - rbin;
+  st.prefix |= digit << shift;
+  st.pmask |= static_cast<uint64_t>(nb - 1) << shift;
+  st.remaining -= above;
+  st.taken += above;
+  st.hi_bit = static_cast<uint32_t>(shift);
+  if (st.taken + in_bin <= max_take || shift == 0) st.done = 1;
+}
+
+// The raw head values of elements [lo, hi) (memory order) of one image, as keys: the overflow path of the passes.
+template <typename T, bool kLogits>
+struct RawSlice {
+  const void *image;
+  uint32_t n, channels, hw, channels_last;
+  float thresh;
+  const float *bias;
+  template <typename F>
+  __device__ __forceinline__ void for_range(uint32_t lo, uint32_t hi, F &&f) const {
+    for (uint32_t r0 = lo; r0 < hi; r0 += 4 * kSelThreads) {
+      float raw[4];
+      bool ok[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint32_t r = r0 + u * kSelThreads + threadIdx.x;
+        ok[u] = r < hi;
+        raw[u] = ok[u] ? load_raw<T>(image, r) : 0.0f;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint32_t r = r0 + u * kSelThreads + threadIdx.x;
+        float x = raw[u];
+        bool take = ok[u];
+        uint64_t key = 0;
+        if (take) {
+          if (kLogits && bias) x += bias[channels_last ? r % channels : (r / hw) % channels];
+          const float s = score_of<T, kLogits>(x);
+          take = s >= thresh;
+          if (take) {
+            uint32_t i = r;
+            if (channels_last) { const uint32_t pix = r / channels, ch = r - pix * channels; i = ch * hw + pix; }
+            key = make_key(s, i);
+          }
+        }
+        f(key, take);
+      }
+    }
+  }
+};
+
+template <typename T, bool kLogits, int PASS>
+__global__ __launch_bounds__(kSelThreads) void select_pass_kernel(const DecodeArgs a) {
+  __shared__ uint32_t s_hist[kRadixBins];
+  __shared__ uint32_t s_misc[32];
+  __shared__ unsigned long long s_range[2];
+
+  int l = 0;
+#pragma unroll
+  for (int i = 1; i < ODTK_MAX_LEVELS; ++i)
+    if (i < a.n_levels && blockIdx.x >= a.part_begin[i]) l = i;
+  const uint32_t P = a.parts[l];
+  const uint32_t j = blockIdx.x - a.part_begin[l];
+  const uint32_t b = j / P, part = j - b * P;
+  const int seg = l * a.batch + static_cast<int>(b);
+  const DecodeLevel &L = a.lv[l];
+  const uint32_t *sub_counts = a.counts + static_cast<size_t>(seg) * kSubLists;
+  uint32_t count = 0;
+  bool complete = true;
+#pragma unroll
+  for (int s = 0; s < kSubLists; ++s) {
+    const uint32_t c = sub_counts[s];
+    count += c;
+    complete = complete && c <= L.cap;
+  }
+  const uint32_t max_take = sort_size_for(a.top_n);
+  if (count <= max_take) return;                            // select_decode sorts these directly (block-uniform exit)
+  SelSeg &S = a.sel[seg];
+
+  SelState st{0, 0, 64, static_cast<uint32_t>(a.top_n), 0, 0, 0};
+  if (PASS == 1) {
+    advance_state(st, S.hist[0], count, S.kmax, ~S.kmin_inv, true, max_take, s_hist, s_misc);
+    if (part == 0 && threadIdx.x == 0) {
+      S.prefix = st.prefix; S.pmask = st.pmask; S.hi_bit = st.hi_bit; S.remaining = st.remaining; S.taken = st.taken;
+      S.done = st.done;
+      if (st.done) { S.T = st.prefix; S.expected = st.taken + st.in_bin; }
+    }
+    if (st.done) return;                                    // pass 0 already isolated the answer
+  }
+  uint64_t T64 = 0;
+  if (PASS == 2) {
+    uint32_t expected;
+    if (S.done) {
+      T64 = S.T;
+      expected = S.expected;
+    } else {
+      st.prefix = S.prefix; st.pmask = S.pmask; st.hi_bit = S.hi_bit; st.remaining = S.remaining; st.taken = S.taken;
+      advance_state(st, S.hist[1], 0, 0, 0, false, max_take, s_hist, s_misc);
+      T64 = st.prefix;
+      expected = st.taken + st.in_bin;
+    }
+    const bool fits = expected <= kSurvCap;
+    if (part == 0 && threadIdx.x == 0) { S.T = T64; S.expected = expected; S.filtered = fits ? 1u : 0u; }
+    if (!fits) return;                                      // (adversarial key sets only) select_decode walks the source itself
+  }
+
+  // ---- this workgroup's slice of the segment ----
+  const uint32_t hw = static_cast<uint32_t>(L.height) * L.width;
+  const uint32_t channels = static_cast<uint32_t>(a.num_anchors) * a.num_classes;
+  const ListSource lists(a.cand + L.cand_off + static_cast<uint64_t>(b) * kSubLists * L.cap, sub_counts, L.cap);
+  const uint32_t total = complete ? lists.start[kSubLists] : L.n;
+  uint32_t active = complete ? (total + kSelSlice - 1) / kSelSlice : P;
+  if (active > P) active = P;
+  if (part >= active) return;
+  const uint32_t chunk = ((total + active - 1) / active + kSelThreads - 1) / kSelThreads * kSelThreads;
+  const uint32_t lo = part * chunk;
+  const uint32_t hi = lo + chunk < total ? lo + chunk : total;
+  if (lo >= hi) return;
+
+  const int lane = lane_id();
+  if (PASS < 2) {
+    for (uint32_t i = threadIdx.x; i < kRadixBins; i += kSelThreads) s_hist[i] = 0;
+    if (threadIdx.x < 2) s_range[threadIdx.x] = 0;
+    __syncthreads();
+  }
+  const int bits = st.hi_bit >= static_cast<uint32_t>(kRadixBits) ? kRadixBits : static_cast<int>(st.hi_bit);
+  const int shift = static_cast<int>(st.hi_bit) - bits;
+  const uint32_t nb = 1u << bits;
+  uint64_t my_max = 0, my_min_inv = 0;
+  uint64_t *surv = a.surv + static_cast<uint64_t>(seg) * kSurvCap;
+
+  auto visit = [&](uint64_t key, bool valid) {
+    if (PASS < 2) {
+      if (PASS == 1) valid = valid && (key & st.pmask) == st.prefix;
+      const uint64_t m = __ballot(valid);
+      if (!m) return;                                       // wave-uniform
+      const uint32_t bin = (nb - 1) - static_cast<uint32_t>((key >> shift) & (nb - 1));
+      // a wave whose lanes all hit ONE bin (saturated inputs: every key) adds once -- 64 LDS atomics on one word
+      // would serialise
+      const int leader = __ffsll(static_cast<unsigned long long>(m)) - 1;
+      const uint32_t bin0 = __shfl(bin, leader, kWave);
+      const uint64_t same = __ballot(valid && bin == bin0);
+      if (same == m) { if (lane == leader) atomicAdd(&s_hist[bin0], static_cast<uint32_t>(__popcll(m))); }
+      else if (valid) atomicAdd(&s_hist[bin], 1u);
+      if (PASS == 0 && valid) {
+        my_max = key > my_max ? key : my_max;
+        my_min_inv = ~key > my_min_inv ? ~key : my_min_inv;
+      }
+    } else {
+      const bool take = valid && key >= T64;
+      const uint64_t m = __ballot(take);
+      if (!m) return;
+      const int leader = __ffsll(static_cast<unsigned long long>(m)) - 1;
+      uint32_t base = 0;
+      if (lane == leader) base = atomicAdd(&S.surv_count, static_cast<uint32_t>(__popcll(m)));
+      base = __shfl(base, leader, kWave);
+      if (take) {
+        const uint32_t pos = base + __popcll(m & ((1ull << lane) - 1ull));
+        if (pos < kSurvCap) surv[pos] = key;
+      }
+    }
+  };
+  if (complete) {
+    lists.for_range(lo, hi, visit);
+  } else {
+    const typename T::storage *cls_image = static_cast<const typename T::storage *>(L.cls) + static_cast<uint64_t>(b) * L.n;
+    const RawSlice<T, kLogits> raw{cls_image, L.n, channels, hw, L.channels_last, a.thresh, L.cls_bias};
+    raw.for_range(lo, hi, visit);
+  }
+  if (PASS < 2) {
+    if (PASS == 0) {
+#pragma unroll
+      for (int d = 32; d > 0; d >>= 1) {
+        const uint64_t o1 = shfl_xor_u64(my_max, d), o2 = shfl_xor_u64(my_min_inv, d);
+        my_max = o1 > my_max ? o1 : my_max;
+        my_min_inv = o2 > my_min_inv ? o2 : my_min_inv;
+      }
+      if (lane == 0) { atomicMax(&s_range[0], my_max); atomicMax(&s_range[1], my_min_inv); }
+    }
+    __syncthreads();
+    uint32_t *g_hist = S.hist[PASS == 0 ? 0 : 1];
+    for (uint32_t i = threadIdx.x; i < kRadixBins; i += kSelThreads) {
+      const uint32_t h = s_hist[i];
+      if (h) atomicAdd(&g_hist[i], h);
+    }
+    if (PASS == 0 && threadIdx.x == 0) { atomicMax(&S.kmax, s_range[0]); atomicMax(&S.kmin_inv, s_range[1]); }
+  }
 }
 
 // ---- the kernel ------------------------------------------------------------------------------
@@ -306,12 +594,28 @@ __global__ __launch_bounds__(kSelThreads) void select_decode_kernel(const Decode
   const ListSource lists(a.cand + L.cand_off + static_cast<uint64_t>(b) * kSubLists * L.cap, sub_counts, L.cap);
   uint32_t n_sort;   // number of valid keys placed in s_keys
 
-  if (count <= kSortCap && complete) {
+  // more candidates than one sort holds: the multi-workgroup passes (select_pass_kernel) have normally left the
+  // keys at or above the boundary bin -- top_n plus a few -- in the segment's survivor list
+  const SelSeg *S = a.sel ? a.sel + seg : nullptr;
+  const bool narrowed = S && count > sort_size_for(top_n) && S->filtered != 0;
+  if (narrowed) {
+    const uint32_t n_surv = S->expected;                               // <= kSurvCap, >= top_n
+    const ListSource surv(a.surv + static_cast<uint64_t>(seg) * kSurvCap, n_surv);
+    uint64_t T64 = 0;
+    n_sort = n_surv;
+    if (n_surv > kSortCap) T64 = radix_threshold(surv, top_n, kSortCap, s_hist, s_misc, &n_sort);   // tie-heavy inputs only
+    if (threadIdx.x == 0) s_misc[20] = 0;
+    __syncthreads();
+    surv.for_each([&](uint64_t key) {
+      if (key >= T64) { const uint32_t p = atomicAdd(&s_misc[20], 1u); if (p < kSortCap) s_keys[p] = key; }
+    });
+  } else if (count <= kSortCap && complete) {
     if (threadIdx.x == 0) s_misc[20] = 0;
     __syncthreads();
     lists.for_each([&](uint64_t key) { s_keys[atomicAdd(&s_misc[20], 1u)] = key; });   // order is irrelevant
     n_sort = count;
   } else {
+    // (reached only when the passes declined: > kSurvCap keys share 22 leading key bits with the top_n-th)
     const RawSource<T, kLogits> raw{cls_image, L.n, channels, hw, L.channels_last, a.thresh, L.cls_bias};
     uint64_t T64 = 0;
     n_sort = count;                // count <= top_n: everything is wanted (overflow path only)
@@ -331,8 +635,7 @@ __global__ __launch_bounds__(kSelThreads) void select_decode_kernel(const Decode
   // Second stage, in LDS.  Sorting is the expensive part (measured: 1024 keys 7 us, 4096 keys 24 us)
   // while a radix pass over keys that are already LDS-resident costs ~3 us, so narrow the buffer down
   // to the smallest sortable size that still holds top_n (1024 for the default 1000) first.
-  uint32_t sort_size = kSelThreads;
-  while (sort_size < top_n) sort_size <<= 1;
+  const uint32_t sort_size = sort_size_for(top_n);
   if (n_sort > sort_size) {
     uint32_t n_keep = n_sort;
     const LdsSource in_lds{s_keys, n_sort};

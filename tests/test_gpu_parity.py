@@ -264,3 +264,44 @@ def test_outputs_do_not_depend_on_preexisting_memory_or_workspace():
         for a, b in zip(runs[0], r):
             assert torch.equal(a, b)
     assert torch.isfinite(runs[0][1]).all()
+
+
+# ------------------------------------------------------------------------------------------------
+# (3) the multi-workgroup selection passes (select_pass_kernel): every route through them
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('case', ['spread', 'ties-bf16', 'all-equal', 'one-outlier-rest-equal', 'two-plateaus', 'overflow-raw'])
+def test_selection_passes_every_route(case):
+    """One level of 9 x 40 x 60 x 80 = 1.73 M scores per image (14 workgroups per segment), top_n = 1000:
+      spread                   two digits isolate the top 1000 (the normal route)
+      ties-bf16                bf16-quantised scores: hundreds of keys tie at the boundary, resolved by index
+      all-equal                every key in ONE bin: the range jump starts the second digit at the first differing bit
+      one-outlier-rest-equal   pass 0 splits {1 key} / {all the rest}: the second digit cannot separate 1.7 M equal
+                               scores, the filter pass declines (> kSurvCap survivors) and select_decode walks the lists
+      two-plateaus             boundary inside a plateau of 300 k equal scores below 5 k distinct larger ones
+      overflow-raw             ODTK_CAND_CAP-sized sub-lists overflow: the passes walk the raw scores"""
+    g = torch.Generator().manual_seed(len(case))
+    a, c, h, w = 9, 40, 60, 80
+    anchors = {16: box.generate_anchors(16, RATIOS, SCALES)}
+    dl = torch.randn(2, a * 4, h, w, generator=g) * 0.2
+    n = a * c * h * w
+    thr = 0.05
+    if case == 'spread':
+        cls = torch.rand(2, a * c, h, w, generator=g) * 0.9 + 0.06
+    elif case == 'ties-bf16':
+        cls = (torch.randn(2, a * c, h, w, generator=g) + synthetic.LOGIT_PRIOR + 2.0).sigmoid().bfloat16().float()
+    elif case == 'all-equal':
+        cls = torch.full((2, a * c, h, w), 0.625)
+    elif case == 'one-outlier-rest-equal':
+        cls = torch.full((2, a * c, h, w), 0.25)
+        cls.view(2, -1)[0, 12345] = 0.75
+        cls.view(2, -1)[1, n - 1] = 0.5
+    elif case == 'two-plateaus':
+        cls = torch.full((2, a * c, h, w), 0.01)
+        flat = cls.view(2, -1)
+        perm = torch.randperm(n, generator=g)
+        flat[:, perm[:300000]] = 0.375
+        flat[:, perm[300000:300700]] = torch.rand(2, 700, generator=g) * 0.5 + 0.4
+    else:
+        cls = torch.rand(2, a * c, h, w, generator=g) * 0.9 + 0.06          # every score a candidate: 1.7 M > any sub-list
+    out, ref = _check_decode_levels([cls], [dl], [16], anchors, thr, 1000)
+    assert int((ref[0] > 0).sum()) == 2000

@@ -104,6 +104,8 @@ def main():
            'threshold': args.threshold, 'batch': args.batch, 'candidates_per_image_per_level': cand,
            'detections': int((out[0] > 0).sum().item()), 'wall_us_per_call': round(wall * 1e6, 1),
            'kernels_us': {k: round(v[0] / v[1] * 1e3, 2) for k, v in prof.items() if v[1]},
+           'kernels_us_per_call': {k: round(v[0] / args.iters * 1e3, 2) for k, v in prof.items() if v[1]},
+           'select_us_per_call': round(sum(v[0] for k, v in prof.items() if k.startswith('select_')) / args.iters * 1e3, 2),
            'scores': n_scores, 'alg_bytes': esize * n_scores}
     t = prof['prefilter_scan_kernel']
     if t[1]:
