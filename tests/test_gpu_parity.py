@@ -269,13 +269,15 @@ def test_outputs_do_not_depend_on_preexisting_memory_or_workspace():
 # ------------------------------------------------------------------------------------------------
 # (3) the multi-workgroup selection passes (select_pass_kernel): every route through them
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize('case', ['spread', 'ties-bf16', 'all-equal', 'one-outlier-rest-equal', 'two-plateaus', 'overflow-raw'])
+@pytest.mark.parametrize('case', ['spread', 'ties-bf16', 'all-equal', 'all-equal-lists', 'one-outlier-rest-equal', 'two-plateaus', 'overflow-raw'])
 def test_selection_passes_every_route(case):
     """One level of 9 x 40 x 60 x 80 = 1.73 M scores per image (14 workgroups per segment), top_n = 1000:
       spread                   two digits isolate the top 1000 (the normal route)
       ties-bf16                bf16-quantised scores: hundreds of keys tie at the boundary, resolved by index
-      all-equal                every key in ONE bin: the range jump starts the second digit at the first differing bit
-      one-outlier-rest-equal   pass 0 splits {1 key} / {all the rest}: the second digit cannot separate 1.7 M equal
+      all-equal                every score equal (sub-lists overflow -> raw scores): every key in ONE bin, the range jump
+                               starts the second digit at the first differing bit (the "saturated input" route)
+      all-equal-lists          the same with 100 k equal candidates in complete lists
+      one-outlier-rest-equal   pass 0 splits {1 key} / {all the rest}: the second digit cannot separate 150 k equal
                                scores, the filter pass declines (> kSurvCap survivors) and select_decode walks the lists
       two-plateaus             boundary inside a plateau of 300 k equal scores below 5 k distinct larger ones
       overflow-raw             ODTK_CAND_CAP-sized sub-lists overflow: the passes walk the raw scores"""
@@ -286,13 +288,18 @@ def test_selection_passes_every_route(case):
     n = a * c * h * w
     thr = 0.05
     if case == 'spread':
-        cls = torch.rand(2, a * c, h, w, generator=g) * 0.9 + 0.06
+        cls = torch.where(torch.rand(2, a * c, h, w, generator=g) < 0.08, torch.rand(2, a * c, h, w, generator=g) * 0.9 + 0.06,
+                          torch.rand(2, a * c, h, w, generator=g) * 0.04)
     elif case == 'ties-bf16':
         cls = (torch.randn(2, a * c, h, w, generator=g) + synthetic.LOGIT_PRIOR + 2.0).sigmoid().bfloat16().float()
     elif case == 'all-equal':
         cls = torch.full((2, a * c, h, w), 0.625)
+    elif case == 'all-equal-lists':
+        cls = torch.full((2, a * c, h, w), 0.01)
+        cls.view(2, -1)[:, torch.randperm(n, generator=g)[:100000]] = 0.625
     elif case == 'one-outlier-rest-equal':
-        cls = torch.full((2, a * c, h, w), 0.25)
+        cls = torch.full((2, a * c, h, w), 0.01)
+        cls.view(2, -1)[:, torch.randperm(n, generator=g)[:150000]] = 0.25
         cls.view(2, -1)[0, 12345] = 0.75
         cls.view(2, -1)[1, n - 1] = 0.5
     elif case == 'two-plateaus':
