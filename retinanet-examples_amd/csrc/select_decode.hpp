@@ -448,6 +448,11 @@ __global__ __launch_bounds__(kSelThreads) void select_pass_kernel(const DecodeAr
   const uint32_t max_take = sort_size_for(a.top_n);
   if (count <= max_take) return;                            // select_decode sorts these directly (block-uniform exit)
   SelSeg &S = a.sel[seg];
+  // debug trace (odtk_debug_set_trace): 5 timestamps of part 0 per (pass, segment), behind the select_decode / nms slots
+  auto stamp = [&](int k) {
+    if (a.trace && part == 0 && threadIdx.x == 0) a.trace[1024 + (PASS * 64 + seg) * 8 + k] = wall_clock64();
+  };
+  stamp(0);
 
   SelState st{0, 0, 64, static_cast<uint32_t>(a.top_n), 0, 0, 0};
   if (PASS == 1) {
@@ -476,6 +481,7 @@ __global__ __launch_bounds__(kSelThreads) void select_pass_kernel(const DecodeAr
     if (!fits) return;                                      // (adversarial key sets only) select_decode walks the source itself
   }
 
+  stamp(1);
   // ---- this workgroup's slice of the segment ----
   const uint32_t hw = static_cast<uint32_t>(L.height) * L.width;
   const uint32_t channels = static_cast<uint32_t>(a.num_anchors) * a.num_classes;
@@ -532,6 +538,7 @@ __global__ __launch_bounds__(kSelThreads) void select_pass_kernel(const DecodeAr
       }
     }
   };
+  stamp(2);
   if (complete) {
     lists.for_range(lo, hi, visit);
   } else {
@@ -539,6 +546,7 @@ __global__ __launch_bounds__(kSelThreads) void select_pass_kernel(const DecodeAr
     const RawSlice<T, kLogits> raw{cls_image, L.n, channels, hw, L.channels_last, a.thresh, L.cls_bias};
     raw.for_range(lo, hi, visit);
   }
+  stamp(3);
   if (PASS < 2) {
     if (PASS == 0) {
 #pragma unroll
@@ -557,6 +565,7 @@ __global__ __launch_bounds__(kSelThreads) void select_pass_kernel(const DecodeAr
     }
     if (PASS == 0 && threadIdx.x == 0) { atomicMax(&S.kmax, s_range[0]); atomicMax(&S.kmin_inv, s_range[1]); }
   }
+  stamp(4);
 }
 
 // ---- the kernel ------------------------------------------------------------------------------

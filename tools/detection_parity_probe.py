@@ -11,7 +11,7 @@ for p in (ROOT, os.path.join(ROOT, 'retinanet-examples_amd'), os.path.join(ROOT,
 import torch  # noqa: E402
 import test_gpu_detection_parity as T  # noqa: E402
 
-for ridge in (1e-3, 1e-2, 1e-1):
+for ridge in (1e-2,):
     model, x = T.build_model(ridge=ridge)
     ref = T.reference_detections(model, x)
     paths = T.candidate_paths(model, x)
@@ -32,4 +32,4 @@ for ridge in (1e-3, 1e-2, 1e-1):
               'on logits > -3: amplitude ratio %.4f' % ((g[hot] + 4.595).mean() / (r[hot] + 4.595).mean()).item())
     for name, got in paths.items():
         for margin in (2e-4, 1e-3, 3e-3, 1e-2, 2e-2, 4e-2, 8e-2, 0.15, 0.3):
-            print(name, margin, json.dumps(T.agreement(ref, got, margin)))
+            print(name, margin, 'IoU>=0.9', json.dumps(T.agreement(ref, got, margin)), 'IoU>=0.5', json.dumps(T.agreement(ref, got, margin, min_iou=0.5)))
