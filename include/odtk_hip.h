@@ -46,7 +46,8 @@ extern "C" {
 #define ODTK_MAX_LEVELS    6       /* pyramid levels per call (P3..P7 = 5); keeps kernargs < 4 KiB */
 #define ODTK_MAX_ANCHORS   32      /* anchors per cell (9 axis-aligned, 27 rotated)       */
 #define ODTK_MAX_TOP_N     4096    /* per-level top_n                                     */
-#define ODTK_MAX_NMS_COUNT 7680    /* candidates per image into nms (5 x 1000 by default) */
+#define ODTK_MAX_NMS_COUNT 7680    /* candidates per image nms keeps LDS-resident (5 x 1000 by default);  */
+#define ODTK_MAX_NMS_COUNT_SCRATCH (1 << 22) /* beyond that, up to this, the key list lives in the workspace   */
 #define ODTK_MAX_NMS_DETECTIONS 2048 /* detections_per_im (100 by default)                */
 
 /* element types of the head tensors */
@@ -97,6 +98,8 @@ int odtk_decode_rotate(int batch_size, const void *const *inputs, void *const *o
  *   inputs[1]  boxes   float32 [batch, count, {4|6}]
  *   inputs[2]  classes float32 [batch, count]
  *   outputs[0..2]      float32 [batch, detections_per_im], [.., {4|6}], [..]
+ * count <= ODTK_MAX_NMS_COUNT: everything is LDS-resident, the workspace query returns a token size.  Larger
+ * counts (the reference has no cap, nms.cu:82-160): the query returns batch * count * 8 bytes for the key lists.
  */
 int odtk_nms(int batch_size, const void *const *inputs, void *const *outputs,
              size_t count, int detections_per_im, float nms_thresh,

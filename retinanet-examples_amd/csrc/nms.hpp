@@ -38,6 +38,7 @@ constexpr int kNmsRound = 1024;        // keys selected + sorted per round (one 
 constexpr int kNmsChunk = 64;          // candidates resolved per chunk: one wave-width
 
 struct NmsArgs {
+  uint64_t *key_scratch;   // [batch, count] keys in the workspace when count > ODTK_MAX_NMS_COUNT (else unused)
   const float *scores;     // [batch, count]
   const float *boxes;      // [batch, count, NB]
   const float *classes;    // [batch, count]
@@ -57,10 +58,10 @@ struct NmsLds {
   static constexpr size_t kLdsBudget = 160 * 1024;
   size_t keys, sel, box, cls, kbox, kcls, kscore, ksrc, hist, misc, clip, total;
   int ways;     // waves that take part in the pull phase
-  __host__ __device__ NmsLds(uint32_t count, int ndet, int nb) {
+  __host__ __device__ NmsLds(uint32_t count, int ndet, int nb, bool global_keys = false) {
     auto up = [](size_t v) { return (v + 15) & ~static_cast<size_t>(15); };
     size_t o = 0;
-    keys = o;   o += up(static_cast<size_t>(count) * 8);
+    keys = o;   o += global_keys ? 0 : up(static_cast<size_t>(count) * 8);
     sel = o;    o += up(kNmsRound * 8);
     box = o;    o += up(static_cast<size_t>(kNmsRound) * nb * 4);
     cls = o;    o += up(kNmsRound * 4);
@@ -145,11 +146,14 @@ struct LdsKeySource {   // keys of this image that rank below `upper` (exclusive
   }
 };
 
-template <int NB>
+// kGlobalKeys: more candidates than the LDS holds (count > ODTK_MAX_NMS_COUNT): the key list of an image lives in the
+// caller's workspace instead; rounds then walk it out of L2 -- slower, same result.
+template <int NB, bool kGlobalKeys = false>
 __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const NmsLds lay(a.count, a.ndet, NB);
-  uint64_t *s_keys = reinterpret_cast<uint64_t *>(smem + lay.keys);
+  const NmsLds lay(a.count, a.ndet, NB, kGlobalKeys);
+  uint64_t *s_keys = kGlobalKeys ? a.key_scratch + static_cast<size_t>(blockIdx.x) * a.count
+                                 : reinterpret_cast<uint64_t *>(smem + lay.keys);
   uint64_t *s_sel = reinterpret_cast<uint64_t *>(smem + lay.sel);
   float *s_box = reinterpret_cast<float *>(smem + lay.box);
   float *s_cls = reinterpret_cast<float *>(smem + lay.cls);
@@ -181,25 +185,33 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsArgs a) {
   // ---- compact positive-score candidates into 64-bit (score, ~position) keys ----
   if (tid == 0) { s_misc[32] = 0; s_misc[34] = 0; }
   __syncthreads();
-  constexpr int kScoreLoads = (ODTK_MAX_NMS_COUNT + kNmsThreads - 1) / kNmsThreads;   // 8
-  float my_scores[kScoreLoads];
-#pragma unroll
-  for (int u = 0; u < kScoreLoads; ++u) {                   // all score loads in flight at once
-    const uint32_t i = u * kNmsThreads + tid;
-    my_scores[u] = i < count ? in_s[i] : 0.0f;
-  }
-#pragma unroll
-  for (int u = 0; u < kScoreLoads; ++u) {
-    const uint32_t i = u * kNmsThreads + tid;
-    if (u * kNmsThreads >= count) break;                    // block-uniform
-    const float s = my_scores[u];
-    const bool pos = s > 0.0f;                              // box.py:328  score > 0 (NaN fails)
+  auto compact = [&](float sc, uint32_t i) {                // wave-uniform call sites
+    const bool pos = sc > 0.0f;                             // box.py:328  score > 0 (NaN fails)
     const uint64_t m = __ballot(pos);
     if (m) {                                                // wave-uniform
       uint32_t wbase = 0;
       if (lane == 0) wbase = atomicAdd(&s_misc[32], static_cast<uint32_t>(__popcll(m)));
       wbase = __shfl(wbase, 0, kWave);
-      if (pos) s_keys[wbase + __popcll(m & ((1ull << lane) - 1ull))] = make_key(s, i);
+      if (pos) s_keys[wbase + __popcll(m & ((1ull << lane) - 1ull))] = make_key(sc, i);
+    }
+  };
+  if constexpr (kGlobalKeys) {
+    for (uint32_t i0 = 0; i0 < count; i0 += kNmsThreads) {
+      const uint32_t i = i0 + tid;
+      compact(i < count ? in_s[i] : 0.0f, i);
+    }
+  } else {
+    constexpr int kScoreLoads = (ODTK_MAX_NMS_COUNT + kNmsThreads - 1) / kNmsThreads;   // 8
+    float my_scores[kScoreLoads];
+#pragma unroll
+    for (int u = 0; u < kScoreLoads; ++u) {                   // all score loads in flight at once
+      const uint32_t i = u * kNmsThreads + tid;
+      my_scores[u] = i < count ? in_s[i] : 0.0f;
+    }
+#pragma unroll
+    for (int u = 0; u < kScoreLoads; ++u) {
+      if (u * kNmsThreads >= count) break;                    // block-uniform
+      compact(my_scores[u], u * kNmsThreads + tid);
     }
   }
   __syncthreads();

@@ -155,15 +155,15 @@ int launch_decode(bool rotated, uint32_t tiles, int n_seg, size_t scan_lds, cons
   if (pass_blocks && da.sel) {
     {
       KernelTimer t(ODTK_KERNEL_SELHIST, stream);
-      hipLaunchKernelGGL((odtk::select_pass_kernel<T, kLogits, 0>), dim3(pass_blocks), dim3(odtk::kSelThreads), 0, stream, da);
+      hipLaunchKernelGGL((odtk::select_pass_kernel<T, kLogits, 0>), dim3(pass_blocks), dim3(odtk::kPassThreads), 0, stream, da);
     }
     {
       KernelTimer t(ODTK_KERNEL_SELHIST, stream);
-      hipLaunchKernelGGL((odtk::select_pass_kernel<T, kLogits, 1>), dim3(pass_blocks), dim3(odtk::kSelThreads), 0, stream, da);
+      hipLaunchKernelGGL((odtk::select_pass_kernel<T, kLogits, 1>), dim3(pass_blocks), dim3(odtk::kPassThreads), 0, stream, da);
     }
     {
       KernelTimer t(ODTK_KERNEL_SELFILTER, stream);
-      hipLaunchKernelGGL((odtk::select_pass_kernel<T, kLogits, 2>), dim3(pass_blocks), dim3(odtk::kSelThreads), 0, stream, da);
+      hipLaunchKernelGGL((odtk::select_pass_kernel<T, kLogits, 2>), dim3(pass_blocks), dim3(odtk::kPassThreads), 0, stream, da);
     }
     ODTK_HIP_TRY(hipGetLastError());
   }
@@ -300,16 +300,16 @@ int decode_levels_impl(int batch, int n_levels, const odtk_level_t *levels, int 
                 : launch_decode<odtk::F16, false>(rotated, tiles, n_seg, scan_lds, sa, da, stream);
 }
 
-template <int NB>
+template <int NB, bool kGlobalKeys>
 int nms_launch(const odtk::NmsArgs &na, int batch, size_t lds, hipStream_t stream) {
   // opt this kernel in to the full 160 KiB of LDS once (thread-safe static initialisation)
   static const hipError_t attr_err =
-      hipFuncSetAttribute(reinterpret_cast<const void *>(&odtk::nms_kernel<NB>),
+      hipFuncSetAttribute(reinterpret_cast<const void *>(&odtk::nms_kernel<NB, kGlobalKeys>),
                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (attr_err != hipSuccess) return hip_fail(attr_err, "hipFuncSetAttribute(nms_kernel)");
   {
     KernelTimer t(ODTK_KERNEL_NMS, stream);
-    hipLaunchKernelGGL(odtk::nms_kernel<NB>, dim3(batch), dim3(odtk::kNmsThreads), lds, stream, na);
+    hipLaunchKernelGGL((odtk::nms_kernel<NB, kGlobalKeys>), dim3(batch), dim3(odtk::kNmsThreads), lds, stream, na);
   }
   ODTK_HIP_TRY(hipGetLastError());
   return ODTK_OK;
@@ -317,12 +317,16 @@ int nms_launch(const odtk::NmsArgs &na, int batch, size_t lds, hipStream_t strea
 
 int nms_impl(int batch, const void *const *inputs, void *const *outputs, int n_outputs, size_t count,
              int ndet, float thresh, uint32_t flags, void *workspace, size_t workspace_size, hipStream_t stream) {
-  if (batch <= 0 || count == 0 || count > ODTK_MAX_NMS_COUNT || ndet <= 0 || ndet > ODTK_MAX_NMS_DETECTIONS)
+  if (batch <= 0 || count == 0 || count > ODTK_MAX_NMS_COUNT_SCRATCH || ndet <= 0 || ndet > ODTK_MAX_NMS_DETECTIONS)
     return ODTK_ERR_INVALID;
-  // the kernel needs no global scratch (everything is LDS-resident); a token size keeps the
-  // reference's two-phase calling convention working unchanged.
-  if (!workspace || !workspace_size) return static_cast<int>(kAlign);
-  if (workspace_size < kAlign) return ODTK_ERR_WORKSPACE;
+  // up to ODTK_MAX_NMS_COUNT candidates per image everything is LDS-resident and the kernel needs no global scratch
+  // (a token size keeps the reference's two-phase calling convention working unchanged); beyond that the key list
+  // of every image lives in the workspace
+  const bool global_keys = count > ODTK_MAX_NMS_COUNT;
+  const size_t need = global_keys ? align_up(sizeof(uint64_t) * static_cast<size_t>(batch) * count) : kAlign;
+  if (need > 0x7fffffffull) return ODTK_ERR_INVALID;
+  if (!workspace || !workspace_size) return static_cast<int>(need);
+  if (workspace_size < need) return ODTK_ERR_WORKSPACE;
   if (!inputs || !outputs || n_outputs < 3) return ODTK_ERR_INVALID;
   for (int i = 0; i < 3; ++i)
     if (!inputs[i] || !outputs[i]) return ODTK_ERR_INVALID;
@@ -341,9 +345,11 @@ int nms_impl(int batch, const void *const *inputs, void *const *outputs, int n_o
   na.thresh = thresh;
   na.flags = flags;
   na.trace = g_trace ? g_trace + 8 * 64 : nullptr;          // after the select_decode slots
-  const size_t lds = odtk::NmsLds(na.count, ndet, nb).total;   // same carve-up the kernel computes
+  na.key_scratch = global_keys ? static_cast<uint64_t *>(workspace) : nullptr;
+  const size_t lds = odtk::NmsLds(na.count, ndet, nb, global_keys).total;   // same carve-up the kernel computes
   if (lds > 160 * 1024) return ODTK_ERR_INVALID;
-  return nb == 6 ? nms_launch<6>(na, batch, lds, stream) : nms_launch<4>(na, batch, lds, stream);
+  if (global_keys) return nb == 6 ? nms_launch<6, true>(na, batch, lds, stream) : nms_launch<4, true>(na, batch, lds, stream);
+  return nb == 6 ? nms_launch<6, false>(na, batch, lds, stream) : nms_launch<4, false>(na, batch, lds, stream);
 }
 
 template <typename T, bool kRes, bool kRelu>
@@ -670,10 +676,13 @@ int odtk_detect(int batch_size, int n_levels, const odtk_level_t *levels, int nu
   const int dec = decode_levels_impl(batch_size, n_levels, levels, num_anchors, num_classes, dtype, flags,
                                      score_thresh, top_n, nullptr, 0, nullptr, 0, nullptr);
   if (dec < 0) return dec;
+  const int nms_ws = nms_impl(batch_size, nullptr, nullptr, 3, count, detections_per_im, nms_thresh, flags, nullptr, 0, nullptr);
+  if (nms_ws < 0) return nms_ws;
   const size_t off_s = align_up(static_cast<size_t>(dec));
   const size_t off_b = off_s + align_up(sizeof(float) * batch_size * count);
   const size_t off_c = off_b + align_up(sizeof(float) * batch_size * count * nb);
-  const size_t total = off_c + align_up(sizeof(float) * batch_size * count);
+  const size_t off_n = off_c + align_up(sizeof(float) * batch_size * count);
+  const size_t total = off_n + align_up(static_cast<size_t>(nms_ws));
   if (!workspace || !workspace_size) return total > 0x7fffffffull ? ODTK_ERR_INVALID : static_cast<int>(total);
   if (workspace_size < total) return ODTK_ERR_WORKSPACE;
   if (!outputs) return ODTK_ERR_INVALID;
@@ -682,9 +691,8 @@ int odtk_detect(int batch_size, int n_levels, const odtk_level_t *levels, int nu
   int rc = decode_levels_impl(batch_size, n_levels, levels, num_anchors, num_classes, dtype, flags, score_thresh,
                               top_n, cat, 3, workspace, static_cast<size_t>(dec), static_cast<hipStream_t>(stream));
   if (rc != ODTK_OK) return rc;
-  // nms needs no global scratch: hand it a token region inside the decode scratch (unused by it)
-  return nms_impl(batch_size, cat, outputs, 3, count, detections_per_im, nms_thresh, flags, ws, kAlign,
-                  static_cast<hipStream_t>(stream));
+  return nms_impl(batch_size, cat, outputs, 3, count, detections_per_im, nms_thresh, flags, ws + off_n,
+                  static_cast<size_t>(nms_ws), static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

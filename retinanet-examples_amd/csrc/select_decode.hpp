@@ -50,21 +50,24 @@ struct DecodeLevel {
 };
 
 constexpr int kSelParts = 64;             // workgroups per segment of the multi-workgroup passes (largest levels)
+constexpr int kPassThreads = 256;          // threads of a pass workgroup: 4 waves, so that the ~10^3 workgroups of a launch are
+                                           // all resident at once (1024-thread workgroups needed two rounds: +6 us per pass)
 constexpr uint32_t kSelSlice = 4096;       // candidate keys per workgroup of a pass (list source)
 constexpr uint32_t kSurvCap = 16384;       // survivor keys per segment the filter pass may emit
+constexpr uint32_t kRankCap = 1024;        // keys of the boundary bin select_decode can rank by brute force (one per thread)
 
 // Per-segment scratch of the multi-workgroup selection; zeroed by the host memset before every call.
 struct SelSeg {
-  uint32_t hist[2][1 << 11];               // digit histograms of pass 0 / pass 1, bins reversed (largest digit first)
+  uint32_t hist[2][1 << 11];               // histograms of pass 0 / pass 1, bins reversed (largest keys first)
   unsigned long long kmax;                 // pass 0: largest key, and ...
-  unsigned long long kmin_inv;             // ... largest ~key (= ~smallest key): the bits above their first difference are common
-  unsigned long long prefix, pmask;        // pass 1 (part 0) publishes the state it derived from pass 0 for the filter pass
-  uint32_t hi_bit, remaining, taken, done;
-  unsigned long long T;                    // filter pass (part 0): every key >= T survives ...
-  uint32_t expected;                       // ... exactly this many of them
-  uint32_t filtered;                       // 1: the survivor list is complete and select_decode may use it
-  uint32_t surv_count;                     // append cursor of the filter pass
-  uint32_t pad_;
+  unsigned long long kmin_inv;             // ... largest ~key (= ~smallest key)
+  unsigned long long lo, hi;               // pass 1 (part 0) publishes the state it derived from pass 0: boundary bin [lo, hi]
+  uint32_t remaining, taken, in_bin, done;
+  // filter pass (part 0): keys >= T survive, `expected` of them; those > bin_hi (exactly `taken` keys) are wanted
+  // outright, of the `in_bin` keys inside [T, bin_hi] the `need` largest are wanted
+  unsigned long long T, bin_hi;
+  uint32_t expected, need, n_above, n_bin;   // expected = n_above + n_bin
+  uint32_t filtered, surv_count;
 };
 
 struct DecodeArgs {
@@ -125,14 +128,14 @@ struct ListSource {   // the kSubLists compacted candidate sub-lists written by 
   }
   // keys [lo, hi) of the flat order; every lane of the workgroup calls f(key, valid) the same number of times
   // (wave-level ballots inside f stay legal)
-  template <typename F>
+  template <int kThreads, typename F>
   __device__ __forceinline__ void for_range(uint32_t lo, uint32_t hi, F &&f) const {
-    for (uint32_t i0 = lo; i0 < hi; i0 += 4 * kSelThreads) {
+    for (uint32_t i0 = lo; i0 < hi; i0 += 4 * kThreads) {
       uint64_t k[4];
       bool ok[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const uint32_t i = i0 + u * kSelThreads + threadIdx.x;
+        const uint32_t i = i0 + u * kThreads + threadIdx.x;
         ok[u] = i < hi;
         k[u] = ok[u] ? *address_of(i) : 0;
       }
@@ -332,17 +335,20 @@ __device__ uint64_t radix_threshold(const Source &src, uint32_t want, uint32_t m
 }
 
 // ---- multi-workgroup narrowing (three launches in front of select_decode_kernel) --------------------------
-// pass 0: histogram of the top 11 bits of every key of the segment + the range [min key, max key]
-// pass 1: histogram of the next digit of the keys inside pass 0's boundary bin.  When pass 0 found every key in ONE
-//         bin (saturated scores: all keys share their 32 score bits and differ only in the index bits) the digit
-//         starts at the first bit in which min and max key differ instead of at bit 52, so that two passes always
-//         resolve 22 USEFUL bits.
-// pass 2: every key >= the boundary bin's lower bound goes to the segment's survivor list (a few more than top_n).
-// Up to kSelParts workgroups per segment walk disjoint slices of the candidate lists (or of the raw scores when a
-// sub-list overflowed); segments with <= sort-size candidates skip all three passes.
+// A pass cuts the current key range [lo, hi] into 2048 equal bins (digit = (key - lo) >> sh) and histograms the keys
+// inside it; the bin in which the running count, from the top, crosses top_n becomes the next range.
+//   pass 0: range = [key(thresh, last index), key(1.0 | +inf, index 0)] -- every candidate lies in it; also records the
+//           smallest and the largest key.
+//   pass 1: the boundary bin of pass 0, clipped to [min key, max key] (saturated scores: all keys share their score
+//           bits and differ only in the index bits; the clip makes the 2048 bins land on the bits that differ).
+//           Skipped when pass 0 already left a boundary bin that select_decode can rank (<= kRankCap keys).
+//   pass 2: every key >= the boundary bin's lower end goes to the segment's survivor list: the `taken` keys above the
+//           bin, all wanted, and the bin's own `in_bin` keys of which select_decode keeps the `need` largest.
+// Up to kSelParts workgroups of 256 threads per segment walk disjoint slices of the candidate lists (or of the raw
+// scores when a sub-list overflowed); segments with <= sort-size candidates leave all three passes at once.
 struct SelState {
-  uint64_t prefix, pmask;
-  uint32_t hi_bit, remaining, taken, done, in_bin;
+  uint64_t lo, hi;                      // current range, both ends inclusive
+  uint32_t remaining, taken, in_bin, done;
 };
 
 __device__ __forceinline__ uint32_t sort_size_for(uint32_t top_n) {
@@ -351,34 +357,58 @@ __device__ __forceinline__ uint32_t sort_size_for(uint32_t top_n) {
   return sort_size;
 }
 
-// Folds one histogram pass into the state (block-wide, uniform result).  `total` = keys counted by the pass.
-__device__ __forceinline__ void advance_state(SelState &st, const uint32_t *g_hist, uint32_t total, uint64_t kmax, uint64_t kmin,
-                                              bool may_use_range, uint32_t max_take, uint32_t *s_hist, uint32_t *s_misc) {
-  const int bits = st.hi_bit >= static_cast<uint32_t>(kRadixBits) ? kRadixBits : static_cast<int>(st.hi_bit);
-  const int shift = static_cast<int>(st.hi_bit) - bits;
-  const uint32_t nb = 1u << bits;
-  for (uint32_t i = threadIdx.x; i < kRadixBins; i += kSelThreads) s_hist[i] = g_hist[i];
+__device__ __forceinline__ int range_shift(uint64_t lo, uint64_t hi) {   // (hi - lo) >> shift < 2048
+  const uint64_t w = hi - lo;
+  const int bl = w ? 64 - __clzll(static_cast<long long>(w)) : 0;
+  return bl > kRadixBits ? bl - kRadixBits : 0;
+}
+
+// scan_boundary for a 256-thread workgroup: 8 consecutive bins per thread.  s_misc: [0..3] wave totals, [16..18] result.
+__device__ __forceinline__ void scan_boundary_256(const uint32_t *s_hist, uint32_t remaining, uint32_t *s_misc, uint32_t *rbin,
+                                                  uint32_t *above, uint32_t *in_bin) {
+  constexpr int kPerThread = kRadixBins / kPassThreads;
+  uint32_t h[kPerThread], sum = 0;
+#pragma unroll
+  for (int k = 0; k < kPerThread; ++k) { h[k] = s_hist[threadIdx.x * kPerThread + k]; sum += h[k]; }
+  const uint32_t inc = wave_inclusive_sum(sum);
+  const int w = threadIdx.x >> 6;
+  if (lane_id() == kWave - 1) s_misc[w] = inc;
+  __syncthreads();
+  uint32_t run = inc - sum;
+  for (int i = 0; i < w; ++i) run += s_misc[i];
+#pragma unroll
+  for (int k = 0; k < kPerThread; ++k) {
+    if (run < remaining && remaining <= run + h[k]) { s_misc[16] = threadIdx.x * kPerThread + k; s_misc[17] = run; s_misc[18] = h[k]; }
+    run += h[k];
+  }
+  __syncthreads();
+  *rbin = s_misc[16];
+  *above = s_misc[17];
+  *in_bin = s_misc[18];
+  __syncthreads();
+}
+
+// Folds one histogram pass into the state (block-wide, uniform result).  [kmin, kmax]: all keys of the segment.
+__device__ __forceinline__ void advance_state(SelState &st, const uint32_t *g_hist, uint64_t kmin, uint64_t kmax, uint32_t *s_hist,
+                                              uint32_t *s_misc) {
+  const int sh = range_shift(st.lo, st.hi);
+  for (uint32_t i = threadIdx.x; i < kRadixBins; i += kPassThreads) s_hist[i] = g_hist[i];
   __syncthreads();
   uint32_t rbin, above, in_bin;
-  scan_boundary(s_hist, st.remaining, s_misc, &rbin, &above, &in_bin);
-  st.in_bin = in_bin;
-  if (may_use_range && above == 0 && in_bin == total && st.taken + in_bin > max_take && kmax != kmin) {
-    // every key sits in one bin: nothing was narrowed.  All bits above the first difference of min and max are
-    // common to every key -- jump there.
-    const int hb = 63 - __clzll(static_cast<long long>(kmax ^ kmin));
-    const uint64_t low = hb >= 63 ? ~0ull : ((2ull << hb) - 1ull);
-    st.pmask = ~low;
-    st.prefix = kmax & ~low;
-    st.hi_bit = static_cast<uint32_t>(hb + 1);
-    return;
-  }
-  const uint64_t digit = (nb - 1) - rbin;
-  st.prefix |= digit << shift;
-  st.pmask |= static_cast<uint64_t>(nb - 1) << shift;
+  scan_boundary_256(s_hist, st.remaining, s_misc, &rbin, &above, &in_bin);
+  const uint64_t digit = (kRadixBins - 1) - rbin;
+  uint64_t lo = st.lo + (digit << sh);
+  const uint64_t span = sh ? ((1ull << sh) - 1ull) : 0ull;
+  uint64_t hi = lo > ~0ull - span ? ~0ull : lo + span;
+  hi = hi < st.hi ? hi : st.hi;
+  lo = lo > kmin ? lo : kmin;                               // no key lies outside [kmin, kmax]
+  hi = hi < kmax ? hi : kmax;
+  st.lo = lo;
+  st.hi = hi;
   st.remaining -= above;
   st.taken += above;
-  st.hi_bit = static_cast<uint32_t>(shift);
-  if (st.taken + in_bin <= max_take || shift == 0) st.done = 1;
+  st.in_bin = in_bin;
+  if ((in_bin <= kRankCap && st.taken + in_bin <= static_cast<uint32_t>(kSortCap)) || lo >= hi) st.done = 1;
 }
 
 // The raw head values of elements [lo, hi) (memory order) of one image, as keys: the overflow path of the passes.
@@ -388,20 +418,20 @@ struct RawSlice {
   uint32_t n, channels, hw, channels_last;
   float thresh;
   const float *bias;
-  template <typename F>
+  template <int kThreads, typename F>
   __device__ __forceinline__ void for_range(uint32_t lo, uint32_t hi, F &&f) const {
-    for (uint32_t r0 = lo; r0 < hi; r0 += 4 * kSelThreads) {
-      float raw[4];
-      bool ok[4];
+    for (uint32_t r0 = lo; r0 < hi; r0 += 8 * kThreads) {
+      float raw[8];
+      bool ok[8];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const uint32_t r = r0 + u * kSelThreads + threadIdx.x;
+      for (int u = 0; u < 8; ++u) {
+        const uint32_t r = r0 + u * kThreads + threadIdx.x;
         ok[u] = r < hi;
         raw[u] = ok[u] ? load_raw<T>(image, r) : 0.0f;
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const uint32_t r = r0 + u * kSelThreads + threadIdx.x;
+      for (int u = 0; u < 8; ++u) {
+        const uint32_t r = r0 + u * kThreads + threadIdx.x;
         float x = raw[u];
         bool take = ok[u];
         uint64_t key = 0;
@@ -422,7 +452,7 @@ struct RawSlice {
 };
 
 template <typename T, bool kLogits, int PASS>
-__global__ __launch_bounds__(kSelThreads) void select_pass_kernel(const DecodeArgs a) {
+__global__ __launch_bounds__(kPassThreads) void select_pass_kernel(const DecodeArgs a) {
   __shared__ uint32_t s_hist[kRadixBins];
   __shared__ uint32_t s_misc[32];
   __shared__ unsigned long long s_range[2];
@@ -445,8 +475,7 @@ __global__ __launch_bounds__(kSelThreads) void select_pass_kernel(const DecodeAr
     count += c;
     complete = complete && c <= L.cap;
   }
-  const uint32_t max_take = sort_size_for(a.top_n);
-  if (count <= max_take) return;                            // select_decode sorts these directly (block-uniform exit)
+  if (count <= sort_size_for(a.top_n)) return;              // select_decode sorts these directly (block-uniform exit)
   SelSeg &S = a.sel[seg];
   // debug trace (odtk_debug_set_trace): 5 timestamps of part 0 per (pass, segment), behind the select_decode / nms slots
   auto stamp = [&](int k) {
@@ -454,34 +483,34 @@ __global__ __launch_bounds__(kSelThreads) void select_pass_kernel(const DecodeAr
   };
   stamp(0);
 
-  SelState st{0, 0, 64, static_cast<uint32_t>(a.top_n), 0, 0, 0};
+  // pass 0 range: every candidate has score >= thresh; sigmoid outputs never exceed 1
+  SelState st;
+  st.lo = make_key(a.thresh, 0xffffffffu);
+  st.hi = kLogits ? make_key(1.0f, 0u) : ~0ull;
+  st.remaining = static_cast<uint32_t>(a.top_n);
+  st.taken = st.in_bin = st.done = 0;
   if (PASS == 1) {
-    advance_state(st, S.hist[0], count, S.kmax, ~S.kmin_inv, true, max_take, s_hist, s_misc);
+    advance_state(st, S.hist[0], ~S.kmin_inv, S.kmax, s_hist, s_misc);
     if (part == 0 && threadIdx.x == 0) {
-      S.prefix = st.prefix; S.pmask = st.pmask; S.hi_bit = st.hi_bit; S.remaining = st.remaining; S.taken = st.taken;
-      S.done = st.done;
-      if (st.done) { S.T = st.prefix; S.expected = st.taken + st.in_bin; }
+      S.lo = st.lo; S.hi = st.hi; S.remaining = st.remaining; S.taken = st.taken; S.in_bin = st.in_bin; S.done = st.done;
     }
-    if (st.done) return;                                    // pass 0 already isolated the answer
+    if (st.done) return;                                    // pass 0 already isolated a rankable boundary bin
   }
   uint64_t T64 = 0;
   if (PASS == 2) {
-    uint32_t expected;
-    if (S.done) {
-      T64 = S.T;
-      expected = S.expected;
-    } else {
-      st.prefix = S.prefix; st.pmask = S.pmask; st.hi_bit = S.hi_bit; st.remaining = S.remaining; st.taken = S.taken;
-      advance_state(st, S.hist[1], 0, 0, 0, false, max_take, s_hist, s_misc);
-      T64 = st.prefix;
-      expected = st.taken + st.in_bin;
-    }
+    st.lo = S.lo; st.hi = S.hi; st.remaining = S.remaining; st.taken = S.taken; st.in_bin = S.in_bin; st.done = S.done;
+    if (!st.done) advance_state(st, S.hist[1], st.lo, st.hi, s_hist, s_misc);
+    T64 = st.lo;
+    const uint32_t expected = st.taken + st.in_bin;
     const bool fits = expected <= kSurvCap;
-    if (part == 0 && threadIdx.x == 0) { S.T = T64; S.expected = expected; S.filtered = fits ? 1u : 0u; }
+    if (part == 0 && threadIdx.x == 0) {
+      S.T = T64; S.bin_hi = st.hi; S.expected = expected; S.need = st.remaining; S.filtered = fits ? 1u : 0u;
+      S.n_above = st.taken; S.n_bin = st.in_bin;          // (own fields: the other workgroups of this pass still read S.taken / S.in_bin)
+    }
     if (!fits) return;                                      // (adversarial key sets only) select_decode walks the source itself
   }
-
   stamp(1);
+
   // ---- this workgroup's slice of the segment ----
   const uint32_t hw = static_cast<uint32_t>(L.height) * L.width;
   const uint32_t channels = static_cast<uint32_t>(a.num_anchors) * a.num_classes;
@@ -490,29 +519,30 @@ __global__ __launch_bounds__(kSelThreads) void select_pass_kernel(const DecodeAr
   uint32_t active = complete ? (total + kSelSlice - 1) / kSelSlice : P;
   if (active > P) active = P;
   if (part >= active) return;
-  const uint32_t chunk = ((total + active - 1) / active + kSelThreads - 1) / kSelThreads * kSelThreads;
+  const uint32_t chunk = ((total + active - 1) / active + kPassThreads - 1) / kPassThreads * kPassThreads;
   const uint32_t lo = part * chunk;
   const uint32_t hi = lo + chunk < total ? lo + chunk : total;
   if (lo >= hi) return;
 
   const int lane = lane_id();
   if (PASS < 2) {
-    for (uint32_t i = threadIdx.x; i < kRadixBins; i += kSelThreads) s_hist[i] = 0;
+    for (uint32_t i = threadIdx.x; i < kRadixBins; i += kPassThreads) s_hist[i] = 0;
     if (threadIdx.x < 2) s_range[threadIdx.x] = 0;
     __syncthreads();
   }
-  const int bits = st.hi_bit >= static_cast<uint32_t>(kRadixBits) ? kRadixBits : static_cast<int>(st.hi_bit);
-  const int shift = static_cast<int>(st.hi_bit) - bits;
-  const uint32_t nb = 1u << bits;
+  const int sh = range_shift(st.lo, st.hi);
+  const uint64_t r_lo = st.lo, r_hi = st.hi;
   uint64_t my_max = 0, my_min_inv = 0;
   uint64_t *surv = a.surv + static_cast<uint64_t>(seg) * kSurvCap;
 
   auto visit = [&](uint64_t key, bool valid) {
     if (PASS < 2) {
-      if (PASS == 1) valid = valid && (key & st.pmask) == st.prefix;
+      if (PASS == 1) valid = valid && key >= r_lo && key <= r_hi;
       const uint64_t m = __ballot(valid);
       if (!m) return;                                       // wave-uniform
-      const uint32_t bin = (nb - 1) - static_cast<uint32_t>((key >> shift) & (nb - 1));
+      uint32_t digit = static_cast<uint32_t>((key - r_lo) >> sh);
+      digit = digit > kRadixBins - 1 ? kRadixBins - 1 : digit;
+      const uint32_t bin = (kRadixBins - 1) - digit;
       // a wave whose lanes all hit ONE bin (saturated inputs: every key) adds once -- 64 LDS atomics on one word
       // would serialise
       const int leader = __ffsll(static_cast<unsigned long long>(m)) - 1;
@@ -540,11 +570,11 @@ __global__ __launch_bounds__(kSelThreads) void select_pass_kernel(const DecodeAr
   };
   stamp(2);
   if (complete) {
-    lists.for_range(lo, hi, visit);
+    lists.template for_range<kPassThreads>(lo, hi, visit);
   } else {
     const typename T::storage *cls_image = static_cast<const typename T::storage *>(L.cls) + static_cast<uint64_t>(b) * L.n;
     const RawSlice<T, kLogits> raw{cls_image, L.n, channels, hw, L.channels_last, a.thresh, L.cls_bias};
-    raw.for_range(lo, hi, visit);
+    raw.template for_range<kPassThreads>(lo, hi, visit);
   }
   stamp(3);
   if (PASS < 2) {
@@ -559,7 +589,7 @@ __global__ __launch_bounds__(kSelThreads) void select_pass_kernel(const DecodeAr
     }
     __syncthreads();
     uint32_t *g_hist = S.hist[PASS == 0 ? 0 : 1];
-    for (uint32_t i = threadIdx.x; i < kRadixBins; i += kSelThreads) {
+    for (uint32_t i = threadIdx.x; i < kRadixBins; i += kPassThreads) {
       const uint32_t h = s_hist[i];
       if (h) atomicAdd(&g_hist[i], h);
     }
@@ -610,14 +640,36 @@ __global__ __launch_bounds__(kSelThreads) void select_decode_kernel(const Decode
   if (narrowed) {
     const uint32_t n_surv = S->expected;                               // <= kSurvCap, >= top_n
     const ListSource surv(a.surv + static_cast<uint64_t>(seg) * kSurvCap, n_surv);
-    uint64_t T64 = 0;
-    n_sort = n_surv;
-    if (n_surv > kSortCap) T64 = radix_threshold(surv, top_n, kSortCap, s_hist, s_misc, &n_sort);   // tie-heavy inputs only
-    if (threadIdx.x == 0) s_misc[20] = 0;
-    __syncthreads();
-    surv.for_each([&](uint64_t key) {
-      if (key >= T64) { const uint32_t p = atomicAdd(&s_misc[20], 1u); if (p < kSortCap) s_keys[p] = key; }
-    });
+    const uint32_t n_hi = S->n_above, in_bin = S->n_bin, need = S->need;   // n_hi + in_bin == n_surv, n_hi + need == top_n
+    if (in_bin <= kRankCap && n_surv <= static_cast<uint32_t>(kSortCap) && top_n + in_bin <= static_cast<uint32_t>(kSortCap)) {
+      // the normal route: keys above the boundary bin go to the front of the sort buffer, the bin's own keys to its
+      // back; then every bin key counts the bin keys larger than itself (keys are unique: the counts are the ranks) and
+      // the `need` best land, already in order, behind the others -- exactly top_n keys, no further narrowing
+      const uint64_t bin_hi = S->bin_hi;
+      if (threadIdx.x == 0) { s_misc[20] = 0; s_misc[21] = 0; }
+      __syncthreads();
+      surv.for_each([&](uint64_t key) {
+        if (key > bin_hi) s_keys[atomicAdd(&s_misc[20], 1u)] = key;
+        else s_keys[kSortCap - 1 - atomicAdd(&s_misc[21], 1u)] = key;
+      });
+      __syncthreads();
+      if (threadIdx.x < in_bin) {
+        const uint64_t mine = s_keys[kSortCap - 1 - threadIdx.x];
+        uint32_t rank = 0;
+        for (uint32_t q = 0; q < in_bin; ++q) rank += s_keys[kSortCap - 1 - q] > mine ? 1u : 0u;   // same address in every lane: broadcast
+        if (rank < need) s_keys[n_hi + rank] = mine;
+      }
+      n_sort = n_hi + need;
+    } else {
+      uint64_t T64 = 0;
+      n_sort = n_surv;
+      if (n_surv > kSortCap) T64 = radix_threshold(surv, top_n, kSortCap, s_hist, s_misc, &n_sort);   // tie-heavy inputs only
+      if (threadIdx.x == 0) s_misc[20] = 0;
+      __syncthreads();
+      surv.for_each([&](uint64_t key) {
+        if (key >= T64) { const uint32_t p = atomicAdd(&s_misc[20], 1u); if (p < kSortCap) s_keys[p] = key; }
+      });
+    }
   } else if (count <= kSortCap && complete) {
     if (threadIdx.x == 0) s_misc[20] = 0;
     __syncthreads();

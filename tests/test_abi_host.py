@@ -55,7 +55,11 @@ def test_nms_workspace_query_and_limits():
     lib = _C.library()
     assert lib.odtk_nms(8, None, None, 5000, 100, 0.5, None, 0, None) > 0
     assert lib.odtk_nms_rotate(8, None, None, 5000, 100, 0.5, None, 0, None) > 0
-    assert lib.odtk_nms(8, None, None, _C.MAX_NMS_COUNT + 1, 100, 0.5, None, 0, None) == _C.ERR_INVALID
+    # beyond the LDS-resident size the key lists move to the workspace: the query says how much (the reference has no cap)
+    assert lib.odtk_nms(8, None, None, _C.MAX_NMS_COUNT, 100, 0.5, None, 0, None) == 256
+    big = lib.odtk_nms(8, None, None, _C.MAX_NMS_COUNT + 1, 100, 0.5, None, 0, None)
+    assert big >= 8 * (_C.MAX_NMS_COUNT + 1) * 8 and big % 256 == 0
+    assert lib.odtk_nms(8, None, None, _C.MAX_NMS_COUNT_SCRATCH + 1, 100, 0.5, None, 0, None) == _C.ERR_INVALID
     assert lib.odtk_nms(8, None, None, 0, 100, 0.5, None, 0, None) == _C.ERR_INVALID
     assert lib.odtk_iou(None, None, 4, 4, None) == _C.ERR_INVALID
 

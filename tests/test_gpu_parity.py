@@ -312,3 +312,47 @@ def test_selection_passes_every_route(case):
         cls = torch.rand(2, a * c, h, w, generator=g) * 0.9 + 0.06          # every score a candidate: 1.7 M > any sub-list
     out, ref = _check_decode_levels([cls], [dl], [16], anchors, thr, 1000)
     assert int((ref[0] > 0).sum()) == 2000
+
+
+# ------------------------------------------------------------------------------------------------
+# (4) no caps the reference does not have: top_n = 2000 x 5 levels (10 000 NMS inputs), NMS on 24 576 candidates
+# ------------------------------------------------------------------------------------------------
+def test_nms_beyond_the_lds_resident_count():
+    g = torch.Generator().manual_seed(29)
+    for count, ndet, n_cls, rotated in [(7681, 100, 3, False), (10000, 100, 80, False), (24576, 300, 2, False), (9000, 50, 2, True)]:
+        ctr = torch.rand(2, count, 2, generator=g) * 600
+        wh = torch.rand(2, count, 2, generator=g) * 120 + 1
+        boxes = torch.cat([ctr, ctr + wh], 2)
+        if rotated:
+            ang = (torch.rand(2, count, 1, generator=g) - 0.5) * 1.2
+            boxes = torch.cat([boxes, torch.sin(ang), torch.cos(ang)], 2)
+        scores = synthetic.make_unique_scores(torch.rand(2, count, generator=g), 0.0)
+        scores[1, ::3] = 0.0
+        classes = torch.randint(0, n_cls, (2, count), generator=g).float()
+        hip = _C.nms(scores.cuda(), boxes.cuda(), classes.cuda(), 0.5, ndet, rotated, return_indices=True)
+        if rotated:
+            from oracle import c_oracle
+            ora = c_oracle.nms(scores.numpy(), boxes.numpy(), classes.numpy(), 0.5, ndet, rotated=True)
+            assert np.array_equal(hip[3].cpu().numpy().astype(np.int64), ora[3]), count
+            for h, o in zip(hip[:3], ora[:3]):
+                assert_bits(h, o, 'rotated nms %d' % count)
+        else:
+            ora = box_oracle.nms(scores, boxes, classes, 0.5, ndet, return_indices=True)
+            assert torch.equal(hip[3].cpu().long(), ora[3]), count
+            for h, o in zip(hip[:3], ora[:3]):
+                assert_bits(h, o, 'nms %d/%d' % (count, ndet))
+
+
+def test_top_n_2000_times_five_levels():
+    """config['top_n'] = 2000 with 5 levels: 10 000 candidates per image into NMS (round 1 returned 'invalid argument')."""
+    cls, dl, strides = synthetic.pyramid(2, 9, 80, 256, 384, 'dense', 515)
+    anchors = {s: box.generate_anchors(s, RATIOS, SCALES) for s in strides}
+    out, ref = _check_decode_levels(cls, dl, strides, anchors, 0.05, 2000)
+    det = box.detect([c.cuda() for c in cls], [d.cuda() for d in dl], strides, anchors, 0.05, 2000, 0.5, 100)
+    via = _C.nms(out[0], out[1], out[2], 0.5, 100)
+    for a, b in zip(det, via):
+        assert torch.equal(a, b)
+    ora = box_oracle.nms(out[0].cpu(), out[1].cpu(), out[2].cpu(), 0.5, 100)
+    for h, o in zip(det, ora):
+        assert_bits(h, o, 'detect top_n=2000')
+    assert int((ref[0] > 0).sum()) > 5000
