@@ -174,6 +174,7 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsArgs a) {
   const int wave = tid >> 6;
   const int img = blockIdx.x;
   if (a.trace && tid == 0) a.trace[(gridDim.x + blockIdx.x) * 8 + 0] = wall_clock64();
+  const long long shader_clock0 = a.trace ? clock64() : 0;   // debug: shader cycles vs the 100 MHz wall clock = effective clock
   const uint32_t count = a.count;
   const int ndet = a.ndet;
   const float thr = a.thresh;
@@ -305,7 +306,11 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsArgs a) {
   }
 
   stamp(4);
-  if (a.trace && tid == 0) { a.trace[(gridDim.x + blockIdx.x) * 8 + 5] = consumed; a.trace[(gridDim.x + blockIdx.x) * 8 + 6] = K; }
+  if (a.trace && tid == 0) {
+    a.trace[(gridDim.x + blockIdx.x) * 8 + 5] = consumed;
+    a.trace[(gridDim.x + blockIdx.x) * 8 + 6] = K;
+    a.trace[(gridDim.x + blockIdx.x) * 8 + 7] = static_cast<unsigned long long>(clock64() - shader_clock0);
+  }
   // ---- outputs: kept boxes, then the zero-padded tail (box.py:322-324) ----
   for (int t = tid; t < ndet; t += kNmsThreads) {
     const size_t o = static_cast<size_t>(img) * ndet + t;

@@ -52,7 +52,7 @@ struct DecodeLevel {
 constexpr int kSelParts = 64;             // workgroups per segment of the multi-workgroup passes (largest levels)
 constexpr int kPassThreads = 256;          // threads of a pass workgroup: 4 waves, so that the ~10^3 workgroups of a launch are
                                            // all resident at once (1024-thread workgroups needed two rounds: +6 us per pass)
-constexpr uint32_t kSelSlice = 4096;       // candidate keys per workgroup of a pass (list source)
+constexpr uint32_t kSelSlice = 2048;       // candidate keys per workgroup of a pass (list source): 8 per lane, one round of loads
 constexpr uint32_t kSurvCap = 16384;       // survivor keys per segment the filter pass may emit
 constexpr uint32_t kRankCap = 1024;        // keys of the boundary bin select_decode can rank by brute force (one per thread)
 
@@ -130,17 +130,17 @@ struct ListSource {   // the kSubLists compacted candidate sub-lists written by 
   // (wave-level ballots inside f stay legal)
   template <int kThreads, typename F>
   __device__ __forceinline__ void for_range(uint32_t lo, uint32_t hi, F &&f) const {
-    for (uint32_t i0 = lo; i0 < hi; i0 += 4 * kThreads) {
-      uint64_t k[4];
-      bool ok[4];
+    // the lists come out of L2 at ~1.5 us per dependent round trip: a slice of kSelSlice keys is ONE round (8 loads per lane)
+    constexpr int kLoads = 8;
+    for (uint32_t i0 = lo; i0 < hi; i0 += kLoads * kThreads) {
+      uint64_t k[kLoads];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < kLoads; ++u) {
         const uint32_t i = i0 + u * kThreads + threadIdx.x;
-        ok[u] = i < hi;
-        k[u] = ok[u] ? *address_of(i) : 0;
+        k[u] = i < hi ? *address_of(i) : 0;                 // 0 is not a key (an index never has all bits set)
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) f(k[u], ok[u]);
+      for (int u = 0; u < kLoads; ++u) f(k[u], k[u] != 0);
     }
   }
   template <int kBatch, typename A, typename F>
@@ -453,7 +453,7 @@ struct RawSlice {
 
 template <typename T, bool kLogits, int PASS>
 __global__ __launch_bounds__(kPassThreads) void select_pass_kernel(const DecodeArgs a) {
-  __shared__ uint32_t s_hist[kRadixBins];
+  __shared__ __attribute__((aligned(8))) uint32_t s_hist[kRadixBins];
   __shared__ uint32_t s_misc[32];
   __shared__ unsigned long long s_range[2];
 
@@ -525,11 +525,15 @@ __global__ __launch_bounds__(kPassThreads) void select_pass_kernel(const DecodeA
   if (lo >= hi) return;
 
   const int lane = lane_id();
+  constexpr uint32_t kStageKeys = kRadixBins / 2;           // s_hist reinterpreted as 64-bit keys
+  uint64_t *s_stage = reinterpret_cast<uint64_t *>(s_hist);
   if (PASS < 2) {
     for (uint32_t i = threadIdx.x; i < kRadixBins; i += kPassThreads) s_hist[i] = 0;
     if (threadIdx.x < 2) s_range[threadIdx.x] = 0;
-    __syncthreads();
+  } else if (threadIdx.x == 0) {
+    s_misc[24] = 0;
   }
+  __syncthreads();
   const int sh = range_shift(st.lo, st.hi);
   const uint64_t r_lo = st.lo, r_hi = st.hi;
   uint64_t my_max = 0, my_min_inv = 0;
@@ -555,16 +559,19 @@ __global__ __launch_bounds__(kPassThreads) void select_pass_kernel(const DecodeA
         my_min_inv = ~key > my_min_inv ? ~key : my_min_inv;
       }
     } else {
+      // survivors are staged in LDS (the histogram's 8 KiB = 1024 keys, idle in this pass) and leave with ONE returning
+      // global atomic per workgroup; a returning atomic per wave and round cost 1-2 us each on the critical path
       const bool take = valid && key >= T64;
       const uint64_t m = __ballot(take);
       if (!m) return;
       const int leader = __ffsll(static_cast<unsigned long long>(m)) - 1;
       uint32_t base = 0;
-      if (lane == leader) base = atomicAdd(&S.surv_count, static_cast<uint32_t>(__popcll(m)));
+      if (lane == leader) base = atomicAdd(&s_misc[24], static_cast<uint32_t>(__popcll(m)));
       base = __shfl(base, leader, kWave);
       if (take) {
         const uint32_t pos = base + __popcll(m & ((1ull << lane) - 1ull));
-        if (pos < kSurvCap) surv[pos] = key;
+        if (pos < kStageKeys) s_stage[pos] = key;
+        else { const uint32_t g = atomicAdd(&S.surv_count, 1u); if (g < kSurvCap) surv[g] = key; }   // stage full (rare)
       }
     }
   };
@@ -594,6 +601,16 @@ __global__ __launch_bounds__(kPassThreads) void select_pass_kernel(const DecodeA
       if (h) atomicAdd(&g_hist[i], h);
     }
     if (PASS == 0 && threadIdx.x == 0) { atomicMax(&S.kmax, s_range[0]); atomicMax(&S.kmin_inv, s_range[1]); }
+  } else {
+    __syncthreads();
+    const uint32_t staged = s_misc[24] < kStageKeys ? s_misc[24] : kStageKeys;
+    if (staged) {
+      if (threadIdx.x == 0) s_misc[25] = atomicAdd(&S.surv_count, staged);
+      __syncthreads();
+      const uint32_t g0 = s_misc[25];
+      for (uint32_t i = threadIdx.x; i < staged; i += kPassThreads)
+        if (g0 + i < kSurvCap) surv[g0 + i] = s_stage[i];
+    }
   }
   stamp(4);
 }
@@ -648,10 +665,23 @@ __global__ __launch_bounds__(kSelThreads) void select_decode_kernel(const Decode
       const uint64_t bin_hi = S->bin_hi;
       if (threadIdx.x == 0) { s_misc[20] = 0; s_misc[21] = 0; }
       __syncthreads();
-      surv.for_each([&](uint64_t key) {
-        if (key > bin_hi) s_keys[atomicAdd(&s_misc[20], 1u)] = key;
-        else s_keys[kSortCap - 1 - atomicAdd(&s_misc[21], 1u)] = key;
-      });
+      for (uint32_t i0 = 0; i0 < n_surv; i0 += kSelThreads) {            // (block-uniform trip count: ballots are legal)
+        const uint32_t i = i0 + threadIdx.x;
+        const uint64_t key = i < n_surv ? surv.keys[i] : 0;
+        const bool above = key > bin_hi, inside = key != 0 && !above;
+        const uint64_t m_a = __ballot(above), m_i = __ballot(inside);
+        const int lane = lane_id();
+        uint32_t base_a = 0, base_i = 0;
+        if (lane == 0) {
+          if (m_a) base_a = atomicAdd(&s_misc[20], static_cast<uint32_t>(__popcll(m_a)));
+          if (m_i) base_i = atomicAdd(&s_misc[21], static_cast<uint32_t>(__popcll(m_i)));
+        }
+        base_a = __shfl(base_a, 0, kWave);
+        base_i = __shfl(base_i, 0, kWave);
+        const uint64_t lt = (1ull << lane) - 1ull;
+        if (above) s_keys[base_a + __popcll(m_a & lt)] = key;
+        if (inside) s_keys[kSortCap - 1 - (base_i + __popcll(m_i & lt))] = key;
+      }
       __syncthreads();
       if (threadIdx.x < in_bin) {
         const uint64_t mine = s_keys[kSortCap - 1 - threadIdx.x];
