@@ -13,8 +13,11 @@
 // __graft_entry__.build() as retinanet-examples_amd/odtk/_C_ext*.so (plain host C++, g++; links libodtk_hip.so);
 // `ODTK_BINDING=ext` makes odtk/_C.py hand decode / nms / iou to it instead of ctypes.
 #include <torch/extension.h>
-#include <c10/hip/HIPGuard.h>
-#include <c10/hip/HIPStream.h>
+// PyTorch-ROCm keeps the device type named "cuda": the guard and stream accessors that honour that are the
+// *MasqueradingAsCUDA forms (what hipify turns c10::cuda::CUDAGuard / getCurrentCUDAStream of the reference's
+// extensions.cpp:62,99 into); the plain c10::hip:: forms reject a "cuda" device.
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 
 #include <stdexcept>
 #include <string>
@@ -45,7 +48,7 @@ int checked(int rc, const char *what) {
 }
 
 void *current_stream(const torch::Tensor &t) {
-  return c10::hip::getCurrentHIPStream(t.device().index()).stream();
+  return c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(t.device().index()).stream();
 }
 
 // cub-style two-phase call (decode.cu:53-72): `call(workspace, size)` with (nullptr, 0) returns the bytes needed
@@ -66,7 +69,7 @@ std::vector<torch::Tensor> decode(torch::Tensor cls_head, torch::Tensor box_head
   const size_t num_anchors = anchors.size() / 4, num_classes = cls_head.size(1) / num_anchors;
   TORCH_CHECK(box_head.size(0) == batch && box_head.size(1) == static_cast<int64_t>(num_anchors) * nb &&
               box_head.size(2) == height && box_head.size(3) == width, "box_head does not match cls_head");
-  c10::hip::HIPGuard guard(cls_head.device());
+  c10::hip::HIPGuardMasqueradingAsCUDA guard(cls_head.device());
   auto opt = cls_head.options();
   auto scores = torch::empty({batch, top_n}, opt), boxes = torch::empty({batch, top_n, nb}, opt);
   auto classes = torch::empty({batch, top_n}, opt);
@@ -93,7 +96,7 @@ std::vector<torch::Tensor> nms(torch::Tensor scores, torch::Tensor boxes, torch:
   TORCH_CHECK(scores.dim() == 2 && boxes.dim() == 3 && boxes.size(2) == nb && boxes.size(0) == scores.size(0) &&
               boxes.size(1) == scores.size(1) && classes.sizes() == scores.sizes(), "nms: inconsistent shapes");
   const int64_t batch = scores.size(0), count = scores.size(1);
-  c10::hip::HIPGuard guard(scores.device());
+  c10::hip::HIPGuardMasqueradingAsCUDA guard(scores.device());
   auto opt = scores.options();
   auto out_scores = torch::empty({batch, detections_per_im}, opt), out_boxes = torch::empty({batch, detections_per_im, nb}, opt);
   auto out_classes = torch::empty({batch, detections_per_im}, opt);
@@ -115,7 +118,7 @@ std::vector<torch::Tensor> iou(torch::Tensor boxes, torch::Tensor anchors) {
   require_gpu_contiguous(boxes, "boxes");
   require_gpu_contiguous(anchors, "anchors");
   const int num_boxes = static_cast<int>(boxes.numel() / 8), num_anchors = static_cast<int>(anchors.numel() / 8);
-  c10::hip::HIPGuard guard(boxes.device());
+  c10::hip::HIPGuardMasqueradingAsCUDA guard(boxes.device());
   auto out = torch::empty({num_anchors, num_boxes}, boxes.options());          // layout of extensions.cpp:64-66
   const void *in[2] = {boxes.data_ptr(), anchors.data_ptr()};
   void *outs[1] = {out.data_ptr()};
@@ -153,7 +156,7 @@ std::vector<torch::Tensor> detect(std::vector<torch::Tensor> cls_heads, std::vec
                              nchw ? 0 : 1, anchors[i].data(), nullptr, nullptr};
   }
   const int num_classes = static_cast<int>(cls_heads[0].size(1)) / num_anchors;
-  c10::hip::HIPGuard guard(cls_heads[0].device());
+  c10::hip::HIPGuardMasqueradingAsCUDA guard(cls_heads[0].device());
   auto opt = cls_heads[0].options().dtype(torch::kFloat32);
   auto scores = torch::empty({batch, detections_per_im}, opt), boxes = torch::empty({batch, detections_per_im, nb}, opt);
   auto classes = torch::empty({batch, detections_per_im}, opt);
