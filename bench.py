@@ -144,6 +144,27 @@ def run_train(args, rank, local_rank, world, dev):
     torch.cuda.synchronize()
     elapsed, _ = parallel.timed_steps(step, args.steps, torch.cuda.synchronize, dev)
     both = T.reduce_losses(losses[-1][0], losses[-1][1], world)
+    # the hand-written training-side kernels, timed on a few extra steps outside the timed region (rank 0)
+    hip_kernels = None
+    if rank == 0:
+        from odtk import _C
+        _C.profile_enable(True, ('retina_loss_kernel', 'snap_to_anchors_kernel'))
+        _C.profile_collect()
+        for _ in range(5):
+            step()
+        torch.cuda.synchronize()
+        _C.profile_enable(False)
+        prof = _C.profile_collect()
+        hip_kernels = {k: {'us_per_step': round(v[0] / 5 * 1e3, 1), 'launches_per_step': v[1] // 5} for k, v in prof.items() if v[1]}
+        if 'retina_loss_kernel' in hip_kernels:
+            # forward reads every logit once, backward reads it again and writes its gradient: 3 x sizeof(dtype) per logit
+            esize = 4 if amp_dtype is None else 2
+            logits = per_gpu * sum(model.num_anchors * model.classes * h * w for h, w in
+                                   __import__('odtk.synthetic', fromlist=['x']).level_shapes(args.height, args.width))
+            alg = 3 * esize * logits
+            t = hip_kernels['retina_loss_kernel']['us_per_step'] * 1e-6
+            hip_kernels['retina_loss_kernel'].update({'alg_bytes_per_step': alg, 'achieved_GBps': round(alg / t / 1e9, 1),
+                                                      'frac_of_hbm_peak': round(alg / t / 1e9 / HBM_PEAK_GBS, 4)})
     exposed = None
     if world > 1:
         def quiet_step():
@@ -167,7 +188,7 @@ def run_train(args, rank, local_rank, world, dev):
                                       'fused HIP' if model.fused_loss else 'torch'),
                        'global_batch': per_gpu * world, 'parallelism': 'ddp x%d (RCCL all-reduce, 25 MB buckets, overlapped)' % world,
                        'gradient_bytes_per_step': grad_bytes},
-            'exposed_allreduce_ms': exposed,
+            'exposed_allreduce_ms': exposed, 'hip_kernels': hip_kernels,
             'loss': {'focal': round(float(both[0]), 5), 'box': round(float(both[1]), 5)},
         }
         print(json.dumps(line), flush=True)

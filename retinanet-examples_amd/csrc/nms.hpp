@@ -254,6 +254,12 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsArgs a) {
     // ---- chunks of 64 candidates: 16-way parallel pull, then one wave resolves the 64 in order ----
     for (uint32_t c0 = 0; c0 < n_round && kept < ndet; c0 += kNmsChunk) {
       const int kept_before = kept;
+      // debug: per-chunk timeline of image 0's first round (3 stamps per chunk: start, after the pull phase, after the resolve)
+      auto cstamp = [&](int k) {
+        if (a.trace && tid == 0 && blockIdx.x == 0 && consumed == n_round && c0 / kNmsChunk < 20)
+          a.trace[2048 - 8 * 64 + (c0 / kNmsChunk) * 4 + k] = k == 3 ? static_cast<unsigned long long>(kept) : wall_clock64();
+      };
+      cstamp(0);
       // (1) EVERY wave looks at the same 64 candidates (lane <-> candidate) but against its own
       //     slice of the kept list (ranks wave, wave + ways, ...): a candidate's <= ndet tests are
       //     spread over `ways` threads.  Wave w publishes its verdict word; the AND is the survivor set.
@@ -270,6 +276,7 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsArgs a) {
         if (lane == 0) s_alive[wave] = word;
       }
       __syncthreads();
+      cstamp(1);
 
       // (2) wave 0 resolves the 64 survivors sequentially: one step per KEPT box, registers + readlane
       if (wave == 0) {
@@ -302,6 +309,8 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsArgs a) {
       }
       __syncthreads();
       kept = static_cast<int>(s_misc[34]);
+      cstamp(2);
+      cstamp(3);
     }
   }
 

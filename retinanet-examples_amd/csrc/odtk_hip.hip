@@ -5,6 +5,7 @@
 // anchors travel BY VALUE in the kernarg segment: nothing is uploaded, so calls are
 // hipGraph-capturable), enqueue on the caller's stream, return.  No allocation, no host sync.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cmath>
 #include <cstdio>
@@ -67,6 +68,32 @@ struct KernelTimer {   // RAII: records start now and stop at scope exit, on `st
     g_prof.pending[id].push_back(ev);
   }
 };
+
+// One kernel launch, timed when its id is enabled.  The event pair is handed to the launch itself
+// (hipExtLaunchKernelGGL): start / stop then carry the timestamps of THIS dispatch's begin and end -- the same
+// clock pair rocprofv3's kernel trace reports -- instead of two separate marker packets around it, which add the
+// dispatch latency on both sides (measured: 57.9 vs 52.8 us for the same prefilter launches).
+template <typename K, typename... Args>
+void timed_launch(int id, K kernel, dim3 grid, dim3 block, size_t lds, hipStream_t stream, Args... args) {
+  if ((g_prof.on >> id) & 1u) {
+    EventPair ev;
+    bool ok = false;
+    {
+      std::lock_guard<std::mutex> lock(g_prof.mu);
+      if (g_prof.pending[id].size() < kMaxPendingEvents) {
+        if (!g_prof.spare.empty()) { ev = g_prof.spare.back(); g_prof.spare.pop_back(); ok = true; }
+        else ok = hipEventCreate(&ev.start) == hipSuccess && hipEventCreate(&ev.stop) == hipSuccess;
+      }
+    }
+    if (ok) {
+      hipExtLaunchKernelGGL(kernel, grid, block, static_cast<uint32_t>(lds), stream, ev.start, ev.stop, 0, args...);
+      std::lock_guard<std::mutex> lock(g_prof.mu);
+      g_prof.pending[id].push_back(ev);
+      return;
+    }
+  }
+  hipLaunchKernelGGL(kernel, grid, block, lds, stream, args...);
+}
 
 constexpr size_t kAlign = 256;
 inline size_t align_up(size_t v) { return (v + kAlign - 1) / kAlign * kAlign; }
@@ -144,36 +171,21 @@ float logit_lower_bound(float thresh) {
 template <typename T, bool kLogits>
 int launch_decode(bool rotated, uint32_t tiles, int n_seg, size_t scan_lds, const odtk::ScanArgs &sa,
                   const odtk::DecodeArgs &da, hipStream_t stream) {
-  {
-    KernelTimer t(ODTK_KERNEL_PREFILTER, stream);
-    hipLaunchKernelGGL((odtk::prefilter_scan_kernel<T, kLogits>), dim3(tiles), dim3(odtk::kScanThreads), scan_lds, stream, sa);
-  }
+  timed_launch(ODTK_KERNEL_PREFILTER, odtk::prefilter_scan_kernel<T, kLogits>, dim3(tiles), dim3(odtk::kScanThreads), scan_lds, stream, sa);
   ODTK_HIP_TRY(hipGetLastError());
   // multi-workgroup narrowing of the segments that hold more candidates than one LDS sort (select_decode.hpp):
   // histogram, histogram, filter.  Segments below that size leave at the first instruction.
   const uint32_t pass_blocks = da.part_begin[da.n_levels];
   if (pass_blocks && da.sel) {
-    {
-      KernelTimer t(ODTK_KERNEL_SELHIST, stream);
-      hipLaunchKernelGGL((odtk::select_pass_kernel<T, kLogits, 0>), dim3(pass_blocks), dim3(odtk::kPassThreads), 0, stream, da);
-    }
-    {
-      KernelTimer t(ODTK_KERNEL_SELHIST, stream);
-      hipLaunchKernelGGL((odtk::select_pass_kernel<T, kLogits, 1>), dim3(pass_blocks), dim3(odtk::kPassThreads), 0, stream, da);
-    }
-    {
-      KernelTimer t(ODTK_KERNEL_SELFILTER, stream);
-      hipLaunchKernelGGL((odtk::select_pass_kernel<T, kLogits, 2>), dim3(pass_blocks), dim3(odtk::kPassThreads), 0, stream, da);
-    }
+    timed_launch(ODTK_KERNEL_SELHIST, odtk::select_pass_kernel<T, kLogits, 0>, dim3(pass_blocks), dim3(odtk::kPassThreads), 0, stream, da);
+    timed_launch(ODTK_KERNEL_SELHIST, odtk::select_pass_kernel<T, kLogits, 1>, dim3(pass_blocks), dim3(odtk::kPassThreads), 0, stream, da);
+    timed_launch(ODTK_KERNEL_SELFILTER, odtk::select_pass_kernel<T, kLogits, 2>, dim3(pass_blocks), dim3(odtk::kPassThreads), 0, stream, da);
     ODTK_HIP_TRY(hipGetLastError());
   }
-  {
-    KernelTimer t(ODTK_KERNEL_SELECT, stream);
-    if (rotated)
-      hipLaunchKernelGGL((odtk::select_decode_kernel<6, T, kLogits>), dim3(n_seg), dim3(odtk::kSelThreads), 0, stream, da);
-    else
-      hipLaunchKernelGGL((odtk::select_decode_kernel<4, T, kLogits>), dim3(n_seg), dim3(odtk::kSelThreads), 0, stream, da);
-  }
+  if (rotated)
+    timed_launch(ODTK_KERNEL_SELECT, odtk::select_decode_kernel<6, T, kLogits>, dim3(n_seg), dim3(odtk::kSelThreads), 0, stream, da);
+  else
+    timed_launch(ODTK_KERNEL_SELECT, odtk::select_decode_kernel<4, T, kLogits>, dim3(n_seg), dim3(odtk::kSelThreads), 0, stream, da);
   ODTK_HIP_TRY(hipGetLastError());
   return ODTK_OK;
 }
@@ -307,10 +319,7 @@ int nms_launch(const odtk::NmsArgs &na, int batch, size_t lds, hipStream_t strea
       hipFuncSetAttribute(reinterpret_cast<const void *>(&odtk::nms_kernel<NB, kGlobalKeys>),
                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (attr_err != hipSuccess) return hip_fail(attr_err, "hipFuncSetAttribute(nms_kernel)");
-  {
-    KernelTimer t(ODTK_KERNEL_NMS, stream);
-    hipLaunchKernelGGL((odtk::nms_kernel<NB, kGlobalKeys>), dim3(batch), dim3(odtk::kNmsThreads), lds, stream, na);
-  }
+  timed_launch(ODTK_KERNEL_NMS, odtk::nms_kernel<NB, kGlobalKeys>, dim3(batch), dim3(odtk::kNmsThreads), lds, stream, na);
   ODTK_HIP_TRY(hipGetLastError());
   return ODTK_OK;
 }
@@ -420,11 +429,10 @@ int retina_loss_launch(bool backward, const void *cls, const void *box, const fl
   la.cls_blocks = static_cast<uint32_t>(cls_blocks);
   const dim3 grid(static_cast<unsigned>(cls_blocks + box_blocks)), block(odtk::kLossThreads);
   {
-    KernelTimer t(ODTK_KERNEL_LOSS, stream);
-#define ODTK_LOSS(T)                                                                                     \
-  do {                                                                                                   \
-    if (backward) hipLaunchKernelGGL((odtk::retina_loss_kernel<T, true>), grid, block, 0, stream, la);   \
-    else hipLaunchKernelGGL((odtk::retina_loss_kernel<T, false>), grid, block, 0, stream, la);           \
+#define ODTK_LOSS(T)                                                                                            \
+  do {                                                                                                          \
+    if (backward) timed_launch(ODTK_KERNEL_LOSS, odtk::retina_loss_kernel<T, true>, grid, block, 0, stream, la);   \
+    else timed_launch(ODTK_KERNEL_LOSS, odtk::retina_loss_kernel<T, false>, grid, block, 0, stream, la);           \
   } while (0)
     if (dtype == ODTK_F32) ODTK_LOSS(odtk::F32);
     else if (dtype == ODTK_BF16) ODTK_LOSS(odtk::BF16);

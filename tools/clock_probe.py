@@ -54,3 +54,24 @@ def clock_of(fn, warm=10, reps=5):
 
 print('in the inference step : nms wall us, effective GHz', clock_of(step))
 print('back to back, idle chip: nms wall us, effective GHz', clock_of(alone))
+
+
+# per-chunk timeline of image 0 (in the step)
+for _ in range(3):
+    step()
+trace = torch.zeros(8192, dtype=torch.int64, device='cuda')
+_C.library().odtk_debug_set_trace(trace.data_ptr())
+step(); torch.cuda.synchronize()
+_C.library().odtk_debug_set_trace(None)
+t = trace.cpu()
+rows = t[2048:2048 + 80].view(-1, 4)
+img0 = t.view(-1, 8)[64 + 8]
+print('nms image 0: compact %.2f | select %.2f | sort %.2f | chunks %.2f us; consumed %d of %d' % (
+    (img0[1] - img0[0]) / 100.0, (img0[2] - img0[1]) / 100.0, (img0[3] - img0[2]) / 100.0, (img0[4] - img0[3]) / 100.0, img0[5], img0[6]))
+prev = None
+for c, r in enumerate(rows):
+    if int(r[0]) == 0:
+        break
+    print('  chunk %2d: pull %.2f us | resolve %.2f us | kept after %d%s' % (c, (r[1] - r[0]) / 100.0, (r[2] - r[1]) / 100.0, int(r[3]),
+          '' if prev is None else ' | gap before %.2f' % ((r[0] - prev) / 100.0)))
+    prev = int(r[2])
