@@ -423,7 +423,10 @@ int retina_loss_launch(bool backward, const void *cls, const void *box, const fl
   const unsigned per = dtype == ODTK_F32 ? 4u : 8u;
   unsigned long long cls_blocks = (n / per + odtk::kLossThreads * 4ull - 1) / (odtk::kLossThreads * 4ull);   // ~4 vectors per lane
   if (cls_blocks < 1) cls_blocks = 1;
-  if (cls_blocks > 256 * 16) cls_blocks = 256 * 16;
+  // forward: every block ends in (up to) three double atomics on the SAME three words, ~11 ns each when they queue up
+  // (MI355X_MICROARCH.md "fanin") -- 4096 blocks cost 40 us of pure queueing per launch; backward has no such tail
+  const unsigned long long block_cap = backward ? 256 * 16 : 256 * 4;
+  if (cls_blocks > block_cap) cls_blocks = block_cap;
   unsigned long long box_blocks = (1ull * batch * A * height * width + odtk::kLossThreads - 1) / odtk::kLossThreads;
   if (box_blocks > 1024) box_blocks = 1024;
   la.cls_blocks = static_cast<uint32_t>(cls_blocks);

@@ -411,6 +411,44 @@ __device__ __forceinline__ void advance_state(SelState &st, const uint32_t *g_hi
   if ((in_bin <= kRankCap && st.taken + in_bin <= static_cast<uint32_t>(kSortCap)) || lo >= hi) st.done = 1;
 }
 
+// radix_threshold on a KNOWN key range [lo, hi] (both inclusive), 1024-thread workgroups: every pass cuts the range into
+// 2048 equal bins instead of taking the next 11 key bits, so the first pass already lands on the bits in which the keys
+// differ (fp32 scores of one image share their exponent bits: an 11-bit MSD digit separates almost nothing).  The source
+// must hold at least `want` keys inside the range.  Returns T with  want <= #{key in [T, hi]} = *n_out <= max_take  (or
+// the exact `want`-th key when ties in the digit cannot be split further).
+template <typename Source>
+__device__ uint64_t range_threshold(const Source &src, uint32_t want, uint32_t max_take, uint64_t lo, uint64_t hi, uint32_t *s_hist,
+                                    uint32_t *s_misc, uint32_t *n_out) {
+  uint32_t remaining = want, taken_above = 0, in_bin = 0;
+  for (;;) {
+    const int sh = range_shift(lo, hi);
+    for (uint32_t i = threadIdx.x; i < kRadixBins; i += kSelThreads) s_hist[i] = 0;
+    __syncthreads();
+    src.for_each([&](uint64_t key) {
+      if (key >= lo && key <= hi) {
+        uint32_t digit = static_cast<uint32_t>((key - lo) >> sh);
+        digit = digit > kRadixBins - 1 ? kRadixBins - 1 : digit;
+        atomicAdd(&s_hist[(kRadixBins - 1) - digit], 1u);
+      }
+    });
+    __syncthreads();
+    uint32_t rbin, above;
+    scan_boundary(s_hist, remaining, s_misc, &rbin, &above, &in_bin);
+    const uint64_t digit = (kRadixBins - 1) - rbin;
+    const uint64_t span = sh ? ((1ull << sh) - 1ull) : 0ull;
+    const uint64_t nlo = lo + (digit << sh);
+    uint64_t nhi = nlo > ~0ull - span ? ~0ull : nlo + span;
+    nhi = nhi < hi ? nhi : hi;
+    lo = nlo;
+    hi = nhi;
+    remaining -= above;
+    taken_above += above;
+    if (taken_above + in_bin <= max_take || sh == 0) break;
+  }
+  *n_out = taken_above + in_bin;
+  return lo;
+}
+
 // The raw head values of elements [lo, hi) (memory order) of one image, as keys: the overflow path of the passes.
 template <typename T, bool kLogits>
 struct RawSlice {
