@@ -221,7 +221,7 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsArgs a) {
     }
   }
   __syncthreads();
-  const uint32_t K = s_misc[32];
+  const uint32_t K = __builtin_amdgcn_readfirstlane(s_misc[32]);   // (LDS values are VGPRs to the compiler: pin loop-control scalars to SGPRs)
   auto stamp = [&](int k) { if (a.trace && tid == 0) a.trace[(gridDim.x + blockIdx.x) * 8 + k] = wall_clock64(); };
   stamp(1);
 
@@ -265,6 +265,7 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsArgs a) {
     src.for_each([&](uint64_t key) { if (key >= lower) s_sel[atomicAdd(&s_misc[33], 1u)] = key; });
     __syncthreads();
     if (consumed == 0) stamp(2);
+    n_round = __builtin_amdgcn_readfirstlane(n_round);
     sort_keys_desc(s_sel, n_round);                        // pads to 1024 with zeros (sort last)
     if (consumed == 0) stamp(3);
     upper = lower;
@@ -308,8 +309,13 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsArgs a) {
 
       // (2) wave 0 resolves the 64 survivors sequentially: one step per KEPT box, registers + readlane
       if (wave == 0) {
-        uint64_t mask = ~0ull;
-        for (int w = 0; w < ways; ++w) mask &= s_alive[w];
+        uint64_t word = ~0ull;
+        for (int w = 0; w < ways; ++w) word &= s_alive[w];
+        // The words come out of LDS, i.e. in VGPRs: to the compiler a divergent value, and a loop whose condition hangs
+        // on it is compiled as an exec-masked ("waterfall") loop -- ~70 dependent instructions per kept box.  Pin the mask
+        // to SGPRs once: ballots are uniform, so from here on the loop is scalar control flow around a few VALU ops.
+        uint64_t mask = (static_cast<uint64_t>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(word >> 32))) << 32) |
+                        static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(word)));
         bool alive = (mask >> lane) & 1ull;
         int k_cnt = kept_before, my_rank = -1;
         while (mask) {
@@ -341,7 +347,7 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsArgs a) {
         if (lane == 0) s_misc[34] = static_cast<uint32_t>(k_cnt);
       }
       __syncthreads();
-      kept = static_cast<int>(s_misc[34]);
+      kept = __builtin_amdgcn_readfirstlane(static_cast<int>(s_misc[34]));
       cstamp(2);
       cstamp(3);
     }

@@ -292,9 +292,11 @@ __device__ __forceinline__ void scan_boundary(const uint32_t *s_hist, uint32_t r
   if (excl < remaining && remaining <= excl + h0) { s_misc[16] = 2 * threadIdx.x; s_misc[17] = excl; s_misc[18] = h0; }
   else if (excl + h0 < remaining && remaining <= excl + h0 + h1) { s_misc[16] = 2 * threadIdx.x + 1; s_misc[17] = excl + h0; s_misc[18] = h1; }
   __syncthreads();
-  *rbin = s_misc[16];
-  *above = s_misc[17];
-  *in_bin = s_misc[18];
+  // (values read from LDS are VGPRs -- "divergent" to the compiler; callers steer loops with them, so pin them to SGPRs:
+  // the descent loops then compile to scalar control flow instead of exec-masked waterfall loops)
+  *rbin = __builtin_amdgcn_readfirstlane(s_misc[16]);
+  *above = __builtin_amdgcn_readfirstlane(s_misc[17]);
+  *in_bin = __builtin_amdgcn_readfirstlane(s_misc[18]);
   __syncthreads();
 }
 
@@ -382,9 +384,11 @@ __device__ __forceinline__ void scan_boundary_256(const uint32_t *s_hist, uint32
     run += h[k];
   }
   __syncthreads();
-  *rbin = s_misc[16];
-  *above = s_misc[17];
-  *in_bin = s_misc[18];
+  // (values read from LDS are VGPRs -- "divergent" to the compiler; callers steer loops with them, so pin them to SGPRs:
+  // the descent loops then compile to scalar control flow instead of exec-masked waterfall loops)
+  *rbin = __builtin_amdgcn_readfirstlane(s_misc[16]);
+  *above = __builtin_amdgcn_readfirstlane(s_misc[17]);
+  *in_bin = __builtin_amdgcn_readfirstlane(s_misc[18]);
   __syncthreads();
 }
 
