@@ -50,6 +50,20 @@ __device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v) {
   return v;
 }
 
+// Append slot for the lanes with `pred` in a list whose cursor is `counter` (LDS or global): ONE atomic per wave, issued by
+// the first participating lane, instead of one per element -- atomics on a single word serialise (1024 LDS atomics on
+// one cursor cost ~9 us).  Every lane of the wave must call it (ballot inside); the result is meaningful where pred holds.
+__device__ __forceinline__ uint32_t wave_append_slot(uint32_t *counter, bool pred) {
+  const uint64_t m = __ballot(pred);
+  if (!m) return 0;                                        // wave-uniform
+  const int lane = lane_id();
+  const int leader = __ffsll(static_cast<unsigned long long>(m)) - 1;
+  uint32_t base = 0;
+  if (lane == leader) base = atomicAdd(counter, static_cast<uint32_t>(__popcll(m)));
+  base = __shfl(base, leader, kWave);
+  return base + static_cast<uint32_t>(__popcll(m & ((1ull << lane) - 1ull)));
+}
+
 // torch.min / torch.max propagate NaN (box.py:107 `torch.max(m, torch.min(t, M))`)
 __device__ __forceinline__ float clamp_like_torch(float t, float hi) {
   float mn = (t != t) ? t : (t < hi ? t : hi);

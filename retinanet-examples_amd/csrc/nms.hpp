@@ -56,7 +56,7 @@ struct NmsArgs {
 // LDS carve-up shared by host (size) and device (pointers); every offset is 16-byte aligned.
 struct NmsLds {
   static constexpr size_t kLdsBudget = 160 * 1024;
-  size_t keys, sel, box, cls, kbox, kcls, kscore, ksrc, hist, misc, clip, total;
+  size_t keys, sel, box, cls, kbox, kcls, kscore, ksrc, hist, misc, sup, clip, total;
   int ways;     // waves that take part in the pull phase
   __host__ __device__ NmsLds(uint32_t count, int ndet, int nb, bool global_keys = false) {
     auto up = [](size_t v) { return (v + 15) & ~static_cast<size_t>(15); };
@@ -71,6 +71,7 @@ struct NmsLds {
     ksrc = o;   o += up(static_cast<size_t>(ndet) * 4);
     hist = o;   o += up(kRadixBins * 4);
     misc = o;   o += up(112 * 4);
+    sup = o;    o += up(kNmsChunk * 8);                     // suppression words of the current chunk
     // rotated IoU: one lane-private polygon region (4 KiB, rotated_iou.hpp) per wave that takes part
     // in the pull phase: as many of the 16 waves as the 160 KiB budget allows
     clip = o;
@@ -171,6 +172,7 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsArgs a) {
   // s_misc: [0..31] radix_select scratch, [32] key count, [33] gather cursor, [34] kept count,
   //         [40..71] verdict words of the pull phase (16 x 64 bits); [40..103] min / max keys per wave before the first round
   uint64_t *s_alive = reinterpret_cast<uint64_t *>(s_misc + 40);
+  uint64_t *s_sup = reinterpret_cast<uint64_t *>(smem + lay.sup);
   float2 *s_clip = reinterpret_cast<float2 *>(smem + lay.clip);     // rotated only
   const int ways = lay.ways;
 
@@ -262,7 +264,13 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsArgs a) {
       lower = range_threshold(src, 256, kNmsRound, k_lo, upper == ~0ull ? k_hi : upper - 1, s_hist, s_misc, &n_round);
     if (tid == 0) s_misc[33] = 0;
     __syncthreads();
-    src.for_each([&](uint64_t key) { if (key >= lower) s_sel[atomicAdd(&s_misc[33], 1u)] = key; });
+    for (uint32_t i0 = 0; i0 < K; i0 += kNmsThreads) {     // (block-uniform trip count: the append ballots)
+      const uint32_t i = i0 + tid;
+      const uint64_t key = i < K ? s_keys[i] : 0;
+      const bool take = key != 0 && key < upper && key >= lower;
+      const uint32_t slot = wave_append_slot(&s_misc[33], take);
+      if (take) s_sel[slot] = key;
+    }
     __syncthreads();
     if (consumed == 0) stamp(2);
     n_round = __builtin_amdgcn_readfirstlane(n_round);
@@ -289,54 +297,64 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsArgs a) {
           a.trace[2048 - 8 * 64 + (c0 / kNmsChunk) * 4 + k] = k == 3 ? static_cast<unsigned long long>(kept) : wall_clock64();
       };
       cstamp(0);
-      // (1) EVERY wave looks at the same 64 candidates (lane <-> candidate) but against its own
-      //     slice of the kept list (ranks wave, wave + ways, ...): a candidate's <= ndet tests are
-      //     spread over `ways` threads.  Wave w publishes its verdict word; the AND is the survivor set.
+      // (1) EVERY wave looks at the same 64 candidates (lane <-> candidate).
+      //   pull: against its own slice of the kept list (ranks wave, wave + ways, ...): a candidate's <= ndet tests are
+      //         spread over `ways` threads.  Wave w publishes its verdict word; the AND is the set still alive.
+      //   suppression rows: row i of the chunk = the lanes j > i of the same class that candidate i WOULD suppress if it is
+      //         kept.  Wave w computes rows w, w + ways, ...: all of the chunk's pairwise IoUs happen here, in parallel on
+      //         every wave, and not on the serial chain of (2) -- measured before: 0.28 us per kept box in (2), 28 of the
+      //         kernel's 50 us (one wave, ~10 dependent branches per box).
       const uint32_t r = c0 + lane;                           // rank inside the round (< 1024)
       float jb[NB];
 #pragma unroll
       for (int k = 0; k < NB; ++k) jb[k] = s_box[r * NB + k];
       const float jc = s_cls[r];
       float2 *clip = s_clip + static_cast<size_t>(wave) * kClipSlotsPerWave + lane;   // rotated: wave-private
+      const uint32_t n_chunk = n_round - c0 < kNmsChunk ? n_round - c0 : kNmsChunk;
       if (wave < ways) {
         bool alive = r < n_round;
         if (alive) alive = pull_against_kept<NB>(s_kcls, s_kbox, wave, kept_before, ways, jb, jc, true, thr, own_angle, clip);
         const uint64_t word = __ballot(alive);
         if (lane == 0) s_alive[wave] = word;
+        for (uint32_t i = wave; i < n_chunk; i += ways) {
+          const float ic = s_cls[c0 + i];                      // same address in every lane: LDS broadcast
+          const bool rival = static_cast<uint32_t>(lane) > i && r < n_round && jc == ic;
+          uint64_t row = 0;
+          if (__ballot(rival)) {                               // wave-uniform: most rows have no same-class follower
+            float ib[NB];
+#pragma unroll
+            for (int k = 0; k < NB; ++k) ib[k] = s_box[(c0 + i) * NB + k];
+            row = __ballot(rival && box_suppresses<NB>(ib, jb, thr, own_angle, clip));
+          }
+          if (lane == 0) s_sup[i] = row;
+        }
       }
       __syncthreads();
       cstamp(1);
 
-      // (2) wave 0 resolves the 64 survivors sequentially: one step per KEPT box, registers + readlane
+      // (2) wave 0 resolves the chunk in rank order with scalar bit operations only: lane i holds row i, the first alive
+      //     candidate is kept and clears its row's bits from the alive mask (v_readlane -> s_andn2).  No IoU, no LDS, one
+      //     branch per kept box.
       if (wave == 0) {
         uint64_t word = ~0ull;
         for (int w = 0; w < ways; ++w) word &= s_alive[w];
-        // The words come out of LDS, i.e. in VGPRs: to the compiler a divergent value, and a loop whose condition hangs
-        // on it is compiled as an exec-masked ("waterfall") loop -- ~70 dependent instructions per kept box.  Pin the mask
-        // to SGPRs once: ballots are uniform, so from here on the loop is scalar control flow around a few VALU ops.
+        const uint64_t my_row = static_cast<uint32_t>(lane) < n_chunk ? s_sup[lane] : 0;
+        const uint32_t row_lo = static_cast<uint32_t>(my_row), row_hi = static_cast<uint32_t>(my_row >> 32);
+        // (LDS values are VGPRs, "divergent" to the compiler: pin the loop state to SGPRs so the loop is scalar control flow)
         uint64_t mask = (static_cast<uint64_t>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(word >> 32))) << 32) |
                         static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(word)));
-        bool alive = (mask >> lane) & 1ull;
-        int k_cnt = kept_before, my_rank = -1;
-        while (mask) {
-          // mask is wave-uniform: keep l0 in an SGPR so the broadcasts are v_readlane, not LDS permutes
-          const int l0 = __builtin_amdgcn_readfirstlane(__ffsll(static_cast<unsigned long long>(mask)) - 1);
-          const float mc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(jc), l0));
-          if (lane == l0) { my_rank = k_cnt; alive = false; }   // kept: its entry is written after the loop
+        uint64_t kept_mask = 0;
+        int k_cnt = kept_before;
+        while (mask && k_cnt < ndet) {
+          const int l0 = __ffsll(static_cast<unsigned long long>(mask)) - 1;
+          const uint64_t row = (static_cast<uint64_t>(static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(row_hi), l0))) << 32) |
+                               static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(row_lo), l0));
+          kept_mask |= 1ull << l0;
+          mask &= ~(row | (1ull << l0));
           ++k_cnt;
-          if (k_cnt == ndet) break;
-          // the IoU sits on the serial chain (measured: 0.28 us per kept box, 28 of the kernel's 50 us): evaluate it only
-          // when a later live candidate of the SAME class exists -- with many classes most kept boxes have none
-          const bool rival = alive && lane > l0 && jc == mc;
-          if (__ballot(rival)) {                                // wave-uniform
-            float mb[NB];
-#pragma unroll
-            for (int k = 0; k < NB; ++k) mb[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(jb[k]), l0));
-            if (rival && box_suppresses<NB>(mb, jb, thr, own_angle, clip)) alive = false;
-          }
-          mask = __ballot(alive);
         }
-        if (my_rank >= 0) {                                     // all lanes kept in this chunk, in parallel
+        if ((kept_mask >> lane) & 1ull) {                       // all lanes kept in this chunk write their entry, in parallel
+          const int my_rank = kept_before + __popcll(kept_mask & ((1ull << lane) - 1ull));
           const uint64_t key = s_sel[r];
 #pragma unroll
           for (int k = 0; k < NB; ++k) s_kbox[my_rank * NB + k] = jb[k];

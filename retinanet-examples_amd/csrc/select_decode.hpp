@@ -738,14 +738,19 @@ __global__ __launch_bounds__(kSelThreads) void select_decode_kernel(const Decode
       if (n_surv > kSortCap) T64 = radix_threshold(surv, top_n, kSortCap, s_hist, s_misc, &n_sort);   // tie-heavy inputs only
       if (threadIdx.x == 0) s_misc[20] = 0;
       __syncthreads();
-      surv.for_each([&](uint64_t key) {
-        if (key >= T64) { const uint32_t p = atomicAdd(&s_misc[20], 1u); if (p < kSortCap) s_keys[p] = key; }
+      surv.template for_range<kSelThreads>(0, n_surv, [&](uint64_t key, bool valid) {
+        const bool take = valid && key >= T64;
+        const uint32_t slot = wave_append_slot(&s_misc[20], take);
+        if (take && slot < kSortCap) s_keys[slot] = key;
       });
     }
   } else if (count <= kSortCap && complete) {
     if (threadIdx.x == 0) s_misc[20] = 0;
     __syncthreads();
-    lists.for_each([&](uint64_t key) { s_keys[atomicAdd(&s_misc[20], 1u)] = key; });   // order is irrelevant
+    lists.template for_range<kSelThreads>(0, lists.start[kSubLists], [&](uint64_t key, bool valid) {   // order is irrelevant
+      const uint32_t slot = wave_append_slot(&s_misc[20], valid);     // one LDS atomic per wave: 4096 on one word cost ~30 us
+      if (valid) s_keys[slot] = key;
+    });
     n_sort = count;
   } else {
     // (reached only when the passes declined: > kSurvCap keys share 22 leading key bits with the top_n-th)
@@ -757,11 +762,17 @@ __global__ __launch_bounds__(kSelThreads) void select_decode_kernel(const Decode
                      : radix_threshold(raw, top_n, kSortCap, s_hist, s_misc, &n_sort);
     if (threadIdx.x == 0) s_misc[20] = 0;
     __syncthreads();
-    auto take = [&](uint64_t key) {
-      if (key >= T64) { const uint32_t p = atomicAdd(&s_misc[20], 1u); if (p < kSortCap) s_keys[p] = key; }
-    };
-    if (complete) lists.for_each(take);
-    else raw.for_each(take);
+    if (complete) {
+      lists.template for_range<kSelThreads>(0, lists.start[kSubLists], [&](uint64_t key, bool valid) {
+        const bool take = valid && key >= T64;
+        const uint32_t slot = wave_append_slot(&s_misc[20], take);
+        if (take && slot < kSortCap) s_keys[slot] = key;
+      });
+    } else {
+      raw.for_each([&](uint64_t key) {
+        if (key >= T64) { const uint32_t p = atomicAdd(&s_misc[20], 1u); if (p < kSortCap) s_keys[p] = key; }
+      });
+    }
   }
   stamp(1);
   __syncthreads();
@@ -783,8 +794,11 @@ __global__ __launch_bounds__(kSelThreads) void select_decode_kernel(const Decode
     if (threadIdx.x == 0) s_misc[20] = 0;
     __syncthreads();
 #pragma unroll
-    for (int u = 0; u < kSortCap / kSelThreads; ++u)
-      if (mine[u] != 0 && mine[u] >= T2) s_keys[atomicAdd(&s_misc[20], 1u)] = mine[u];
+    for (int u = 0; u < kSortCap / kSelThreads; ++u) {
+      const bool keep = mine[u] != 0 && mine[u] >= T2;
+      const uint32_t slot = wave_append_slot(&s_misc[20], keep);
+      if (keep) s_keys[slot] = mine[u];
+    }
     n_sort = n_keep;
     __syncthreads();
   }
