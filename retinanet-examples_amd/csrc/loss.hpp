@@ -46,12 +46,18 @@ struct LossArgs {
 };
 
 // loss.py:13-19 for one element; t is 0 or 1.  Returns the loss, *grad = d(loss)/dx.
+// The kernel was ALU-bound on ocml's expf / log1pf / IEEE division (~320 instructions per logit: 990 GB/s); this form
+// needs one hardware exp2, one log2 and one reciprocal per logit (each accurate to ~1 ulp, i.e. ~1e-7 relative on the
+// terms that carry the sums -- the parity bars are 1e-6 on the sums and 1e-5 on the gradients, tests/test_gpu_loss.py):
+//   e = exp(-|x|) in (0, 1];  sigmoid(x) = 1 / (1 + e) for x >= 0, e / (1 + e) for x < 0;  log1p(e) = log(1 + e), 1 + e in (1, 2]
 template <bool kGrad>
 __device__ __forceinline__ float focal_element(float x, bool positive, float alpha, float gamma, float *grad) {
   const float t = positive ? 1.0f : 0.0f;
-  const float p = 1.0f / (1.0f + expf(-x));                                   // pred_logits.sigmoid()
+  const float e = __expf(-fabsf(x));
+  const float r = __builtin_amdgcn_rcpf(1.0f + e);
+  const float p = x >= 0.0f ? r : e * r;                                        // pred_logits.sigmoid()
   // F.binary_cross_entropy_with_logits: (1 - t) * x + max(-x, 0) + log1p(exp(-|x|))
-  const float ce = (1.0f - t) * x + fmaxf(-x, 0.0f) + log1pf(expf(-fabsf(x)));
+  const float ce = (1.0f - t) * x + fmaxf(-x, 0.0f) + __logf(1.0f + e);
   const float a_t = t * alpha + (1.0f - t) * (1.0f - alpha);
   const float pt = positive ? p : 1.0f - p;
   const float q = 1.0f - pt;                                                    // (1. - pt)
