@@ -144,9 +144,32 @@ __global__ __launch_bounds__(kLossThreads) void retina_loss_kernel(const LossArg
         img = ia / A;
         an = ia - img * A;
       }
+      // depth of every element of the vector, fetched BEFORE the arithmetic (independent loads, one wait) -- an element's
+      // depth read inside the loop put an L2 round trip on every element's critical path.
+      //   channels_last, vector inside one anchor's class run (C % kPer == 0: always): ONE depth value
+      //   NCHW, vector inside one (image, anchor, class) plane row (hw % kPer == 0: P3..P6): kPer consecutive values
+      //   otherwise (tiny levels): element by element with carries
+      float dep[kPer];
+      uint32_t cls_of[kPer];
+      const uint32_t cell = (img * A + an) * hw + pix;
+      if (a.channels_last && c + kPer <= C) {
+        const float d = a.depth[cell];
+#pragma unroll
+        for (int e = 0; e < kPer; ++e) { dep[e] = d; cls_of[e] = c + e; }
+      } else if (!a.channels_last && pix + kPer <= hw) {
+#pragma unroll
+        for (int e = 0; e < kPer; ++e) { dep[e] = a.depth[cell + e]; cls_of[e] = c; }
+      } else {
+        uint32_t i2 = img, a2 = an, c2 = c, p2 = pix;
+#pragma unroll
+        for (int e = 0; e < kPer; ++e) {
+          dep[e] = a.depth[(static_cast<uint64_t>(i2) * A + a2) * hw + p2];
+          cls_of[e] = c2;
+          if (a.channels_last) { if (++c2 == C) { c2 = 0; if (++a2 == A) { a2 = 0; if (++p2 == hw) { p2 = 0; ++i2; } } } }
+          else { if (++p2 == hw) { p2 = 0; if (++c2 == C) { c2 = 0; if (++a2 == A) { a2 = 0; ++i2; } } } }
+        }
+      }
       float out[kPer];
-      float dep = 0.0f;
-      bool reload = true;                                     // depth is per (image, anchor, pixel): re-read only when that moves
 #pragma unroll
       for (int e = 0; e < kPer; ++e) {
         float x;
@@ -156,21 +179,13 @@ __global__ __launch_bounds__(kLossThreads) void retina_loss_kernel(const LossArg
           const uint32_t h = (raw[e >> 1] >> (16 * (e & 1))) & 0xffffu;
           x = std::is_same_v<T, BF16> ? bf16_bits_to_float(h) : f16_bits_to_float(h);
         }
-        if (reload) dep = a.depth[(static_cast<uint64_t>(img) * A + an) * hw + pix];
+        // evaluated for every element (no branch around the arithmetic: lanes diverge on `dep`), masked afterwards
+        const bool positive = dep[e] > 0.0f && static_cast<uint32_t>(dep[e] - 1.0f) == cls_of[e];
         float grad = 0.0f;
-        if (dep >= 0.0f) {                                                      // model.py:199 cls_mask
-          const bool positive = dep > 0.0f && static_cast<uint32_t>(dep - 1.0f) == c;
-          const float l = focal_element<kBackward>(x, positive, a.alpha, a.gamma, &grad);
-          if constexpr (!kBackward) sum_cls += l;
-        }
-        out[e] = g * grad;
-        // next element in memory order
-        if (a.channels_last) {
-          reload = false;
-          if (++c == C) { c = 0; reload = true; if (++an == A) { an = 0; if (++pix == hw) { pix = 0; ++img; } } }
-        } else {
-          if (++pix == hw) { pix = 0; if (++c == C) { c = 0; if (++an == A) { an = 0; ++img; } } }
-        }
+        const float l = focal_element<kBackward>(x, positive, a.alpha, a.gamma, &grad);
+        const bool counted = dep[e] >= 0.0f;                                    // model.py:199 cls_mask
+        if constexpr (!kBackward) sum_cls += counted ? l : 0.0f;
+        out[e] = counted ? g * grad : 0.0f;
       }
       if constexpr (kBackward) {
         vuint4 w;
