@@ -111,8 +111,8 @@ def calibrate_cls_head(model, heads, x, fraction, threshold):
 def run_train(args, rank, local_rank, world, dev):
     """BASELINE config 3: ResNet50FPN fp32 training (FocalLoss + SmoothL1), 2 images per GPU, DDP over RCCL.
     A step = forward + loss + backward (+ bucketed gradient all-reduce overlapped with it) + SGD update.
-    `exposed_allreduce_ms` = step time with DDP's all-reduce minus step time under `no_sync()` (same compute,
-    no communication): the part of the all-reduce that backward does not hide."""
+    `exposed_allreduce_ms` = step time with DDP's all-reduce minus the time of the same step on the bare module (same
+    compute, no communication): the part of the all-reduce that backward does not hide."""
     from odtk import parallel, train as T
     from odtk.model import Model
     torch.manual_seed(0)
@@ -144,32 +144,37 @@ def run_train(args, rank, local_rank, world, dev):
     torch.cuda.synchronize()
     elapsed, _ = parallel.timed_steps(step, args.steps, torch.cuda.synchronize, dev)
     both = T.reduce_losses(losses[-1][0], losses[-1][1], world)
-    # the hand-written training-side kernels, timed on a few extra steps outside the timed region (rank 0)
+    # the hand-written training-side kernels, timed on a few extra steps outside the timed region.  EVERY rank runs the
+    # steps (each one all-reduces gradients under DDP); only rank 0 records
+    from odtk import _C
     hip_kernels = None
     if rank == 0:
-        from odtk import _C
         _C.profile_enable(True, ('retina_loss_kernel', 'snap_to_anchors_kernel'))
         _C.profile_collect()
-        for _ in range(5):
-            step()
-        torch.cuda.synchronize()
+    for _ in range(5):
+        step()
+    torch.cuda.synchronize()
+    if rank == 0:
         _C.profile_enable(False)
         prof = _C.profile_collect()
         hip_kernels = {k: {'us_per_step': round(v[0] / 5 * 1e3, 1), 'launches_per_step': v[1] // 5} for k, v in prof.items() if v[1]}
         if 'retina_loss_kernel' in hip_kernels:
             # forward reads every logit once, backward reads it again and writes its gradient: 3 x sizeof(dtype) per logit
+            from odtk import synthetic
             esize = 4 if amp_dtype is None else 2
-            logits = per_gpu * sum(model.num_anchors * model.classes * h * w for h, w in
-                                   __import__('odtk.synthetic', fromlist=['x']).level_shapes(args.height, args.width))
+            logits = per_gpu * sum(model.num_anchors * model.classes * h * w for h, w in synthetic.level_shapes(args.height, args.width))
             alg = 3 * esize * logits
             t = hip_kernels['retina_loss_kernel']['us_per_step'] * 1e-6
             hip_kernels['retina_loss_kernel'].update({'alg_bytes_per_step': alg, 'achieved_GBps': round(alg / t / 1e9, 1),
                                                       'frac_of_hbm_peak': round(alg / t / 1e9 / HBM_PEAK_GBS, 4)})
     exposed = None
     if world > 1:
+        # the same step on the bare module: identical compute, no gradient all-reduce (replicas drift apart from here on,
+        # which no longer matters: nothing is timed with DDP after this)
         def quiet_step():
-            with net.no_sync():
-                return step()
+            d, t = batches[it[0] % len(batches)]
+            it[0] += 1
+            return T.train_step(model, optimizer, scheduler, scaler, d, t, amp_dtype)[0]
         for _ in range(2):
             quiet_step()
         quiet, _ = parallel.timed_steps(quiet_step, max(args.steps // 2, 5), torch.cuda.synchronize, dev)

@@ -267,10 +267,12 @@ int odtk_retina_loss_backward(const void *cls, const void *box, const float *dep
 
 /* ------------------------------------------------------------------------------------------
  * Measurement hooks (used by bench.py; off by default, zero cost when off).
- * While enabled, every kernel launch of this library is bracketed by a hipEvent pair recorded on
- * the launch stream (asynchronous -- still no host synchronisation).  odtk_profile_collect waits
- * for the recorded events, accumulates per-kernel elapsed milliseconds and launch counts, and
- * clears the pool.  Kernel ids: */
+ * While enabled, a kernel launch of this library carries a hipEvent pair (asynchronous -- still no
+ * host synchronisation): the post-processing, target and loss kernels hand the pair to the launch
+ * itself (hipExtLaunchKernelGGL), so the two events hold the dispatch's own begin / end timestamps --
+ * the figures rocprofv3's kernel trace reports; the epilogue / GEMM entry points record the pair around
+ * the call.  odtk_profile_collect waits for the recorded events, accumulates per-kernel elapsed
+ * milliseconds and launch counts, and clears the pool.  Kernel ids: */
 #define ODTK_KERNEL_PREFILTER 0   /* prefilter_scan_kernel                         */
 #define ODTK_KERNEL_SELECT    1   /* select_decode_kernel                          */
 #define ODTK_KERNEL_NMS       2   /* nms_kernel                                    */
