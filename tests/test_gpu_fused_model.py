@@ -72,3 +72,38 @@ def test_fused_graph_matches_eager_fp32(backbone):
         cos = F.cosine_similarity(r.flatten().float(), g.flatten().float(), dim=0).item()
         assert cos > 0.999, cos
     assert det[0].shape == (2, 100) and det[1].shape == (2, 100, 4)
+
+
+@pytest.mark.gpu
+def test_engine_on_a_128px_image_whose_p7_level_is_1x1():
+    """a [B, C, 1, 1] head is NCHW- and NHWC-contiguous at once; the bias fold needs the channels_last reading.
+    Also the default route: Model.forward in eval mode IS the engine, under autocast and without."""
+    torch.manual_seed(0)
+    model = Model('ResNet18FPN', classes=8)
+    model.initialize(None)
+    model = model.cuda().to(memory_format=torch.channels_last).eval()
+    x = torch.randn(2, 3, 128, 128, device='cuda')
+    with torch.no_grad():
+        cls_heads, _ = model.heads(x)
+        assert cls_heads[-1].shape[-2:] == (1, 1)
+        model.cls_head[-1].weight.mul_(60.0)                  # detections exist
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            out16 = model(x)                                    # bf16 engine, head bias folded into the kernels
+        assert torch.bfloat16 in model._engine_cache
+        out32 = model(x)                                        # fp32 engine (cache re-keyed by dtype)
+        assert torch.float32 in model._engine_cache and torch.bfloat16 not in model._engine_cache
+        model.fused_graph = False
+        eager = model(x)
+    for o in (out16, out32, eager):
+        assert o[0].shape == (2, 100) and o[1].shape == (2, 100, 4)
+    assert int((out32[0] > 0).sum()) > 10
+    # fp32 engine vs fp32 eager graph: same detector up to conv rounding
+    n = int(min((out32[0] > 0).sum(), (eager[0] > 0).sum()))
+    assert (out32[0].flatten().sort(descending=True).values[:n // 2] - eager[0].flatten().sort(descending=True).values[:n // 2]).abs().max() < 1e-3
+    # the engine follows the weights: an in-place update re-folds it
+    model.fused_graph = True
+    with torch.no_grad():
+        before = model(x)[0].clone()
+        model.cls_head[-1].bias.add_(0.5)
+        after = model(x)[0]
+    assert not torch.equal(before, after)
