@@ -45,7 +45,7 @@ extern "C" {
 
 #define ODTK_MAX_LEVELS    6       /* pyramid levels per call (P3..P7 = 5); keeps kernargs < 4 KiB */
 #define ODTK_MAX_ANCHORS   32      /* anchors per cell (9 axis-aligned, 27 rotated)       */
-#define ODTK_MAX_TOP_N     4096    /* per-level top_n                                     */
+#define ODTK_MAX_TOP_N     16384   /* per-level top_n (<= 4096: 32 KiB LDS sort; beyond: a 128 KiB variant) */
 #define ODTK_MAX_NMS_COUNT 7680    /* candidates per image nms keeps LDS-resident (5 x 1000 by default);  */
 #define ODTK_MAX_NMS_COUNT_SCRATCH (1 << 22) /* beyond that, up to this, the key list lives in the workspace   */
 #define ODTK_MAX_NMS_DETECTIONS 2048 /* detections_per_im (100 by default)                */

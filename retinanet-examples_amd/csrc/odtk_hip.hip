@@ -123,7 +123,11 @@ struct DecodeLayout {
 };
 static_assert(sizeof(odtk::DecodeArgs) <= 4096 && sizeof(odtk::ScanArgs) <= 4096, "kernel arguments travel by value");
 
-int decode_layout(int batch, int n_levels, const odtk_level_t *levels, int A, int C, DecodeLayout *out) {
+// top_n <= 4096: the standard select_decode (32 KiB static sort buffer); beyond: the variant with 128 KiB of dynamic LDS
+uint32_t sort_cap_for(int top_n) { return top_n <= odtk::kSortCap ? odtk::kSortCap : odtk::kSortCapBig; }
+uint32_t surv_cap_for(int top_n) { return top_n <= odtk::kSortCap ? odtk::kSurvCap : 4 * odtk::kSurvCap; }
+
+int decode_layout(int batch, int n_levels, const odtk_level_t *levels, int A, int C, int top_n, DecodeLayout *out) {
   size_t off = 0;
   out->counts_off = off;
   off += align_up(sizeof(uint32_t) * static_cast<size_t>(batch) * n_levels * odtk::kSubLists);
@@ -152,7 +156,7 @@ int decode_layout(int batch, int n_levels, const odtk_level_t *levels, int A, in
     off += align_up(sizeof(uint64_t) * static_cast<size_t>(batch) * odtk::kSubLists * out->cap[l]);
   }
   out->surv_off = off;
-  off += align_up(sizeof(uint64_t) * static_cast<size_t>(batch) * n_levels * odtk::kSurvCap);
+  off += align_up(sizeof(uint64_t) * static_cast<size_t>(batch) * n_levels * surv_cap_for(top_n));
   out->total = off;
   return ODTK_OK;
 }
@@ -182,10 +186,23 @@ int launch_decode(bool rotated, uint32_t tiles, int n_seg, size_t scan_lds, cons
     timed_launch(ODTK_KERNEL_SELFILTER, odtk::select_pass_kernel<T, kLogits, 2>, dim3(pass_blocks), dim3(odtk::kPassThreads), 0, stream, da);
     ODTK_HIP_TRY(hipGetLastError());
   }
-  if (rotated)
+  if (da.sort_cap > static_cast<uint32_t>(odtk::kSortCap)) {
+    // top_n > 4096 (the reference has no cap): the sort buffer moves to 128 KiB of dynamic LDS
+    constexpr size_t big_lds = sizeof(uint64_t) * odtk::kSortCapBig;
+    static const hipError_t attr6 = hipFuncSetAttribute(reinterpret_cast<const void *>(&odtk::select_decode_kernel<6, T, kLogits, odtk::kSortCapBig>),
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
+    static const hipError_t attr4 = hipFuncSetAttribute(reinterpret_cast<const void *>(&odtk::select_decode_kernel<4, T, kLogits, odtk::kSortCapBig>),
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
+    if (attr6 != hipSuccess || attr4 != hipSuccess) return hip_fail(attr6 != hipSuccess ? attr6 : attr4, "hipFuncSetAttribute(select_decode_kernel)");
+    if (rotated)
+      timed_launch(ODTK_KERNEL_SELECT, odtk::select_decode_kernel<6, T, kLogits, odtk::kSortCapBig>, dim3(n_seg), dim3(odtk::kSelThreads), big_lds, stream, da);
+    else
+      timed_launch(ODTK_KERNEL_SELECT, odtk::select_decode_kernel<4, T, kLogits, odtk::kSortCapBig>, dim3(n_seg), dim3(odtk::kSelThreads), big_lds, stream, da);
+  } else if (rotated) {
     timed_launch(ODTK_KERNEL_SELECT, odtk::select_decode_kernel<6, T, kLogits>, dim3(n_seg), dim3(odtk::kSelThreads), 0, stream, da);
-  else
+  } else {
     timed_launch(ODTK_KERNEL_SELECT, odtk::select_decode_kernel<4, T, kLogits>, dim3(n_seg), dim3(odtk::kSelThreads), 0, stream, da);
+  }
   ODTK_HIP_TRY(hipGetLastError());
   return ODTK_OK;
 }
@@ -210,7 +227,7 @@ int decode_levels_impl(int batch, int n_levels, const odtk_level_t *levels, int 
   }
 
   DecodeLayout lay;
-  int rc = decode_layout(batch, n_levels, levels, A, C, &lay);
+  int rc = decode_layout(batch, n_levels, levels, A, C, top_n, &lay);
   if (rc != ODTK_OK) return rc;
   if (!workspace || !workspace_size) {
     if (lay.total > 0x7fffffffull) return ODTK_ERR_INVALID;   // the int return cannot carry it
@@ -278,6 +295,8 @@ int decode_levels_impl(int batch, int n_levels, const odtk_level_t *levels, int 
   for (int l = n_levels + 1; l <= ODTK_MAX_LEVELS; ++l) da.part_begin[l] = da.part_begin[n_levels];
   da.sel = reinterpret_cast<odtk::SelSeg *>(ws + lay.sel_off);
   da.surv = reinterpret_cast<uint64_t *>(ws + lay.surv_off);
+  da.sort_cap = sort_cap_for(top_n);
+  da.surv_cap = surv_cap_for(top_n);
   sa.counts = counts;
   sa.cand = cand;
   sa.n_levels = n_levels;

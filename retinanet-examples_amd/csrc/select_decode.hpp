@@ -31,7 +31,8 @@
 namespace odtk {
 
 constexpr int kSelThreads = 1024;
-constexpr int kSortCap = ODTK_MAX_TOP_N;        // keys sortable in LDS (32 KiB)
+constexpr int kSortCap = 4096;                  // keys sortable in LDS by the standard kernel (32 KiB)
+constexpr int kSortCapBig = ODTK_MAX_TOP_N;     // ... by the top_n > 4096 variant (128 KiB of dynamic LDS)
 constexpr int kRadixBits = 11;
 constexpr int kRadixBins = 1 << kRadixBits;
 
@@ -53,7 +54,7 @@ constexpr int kSelParts = 64;             // workgroups per segment of the multi
 constexpr int kPassThreads = 256;          // threads of a pass workgroup: 4 waves, so that the ~10^3 workgroups of a launch are
                                            // all resident at once (1024-thread workgroups needed two rounds: +6 us per pass)
 constexpr uint32_t kSelSlice = 2048;       // candidate keys per workgroup of a pass (list source): 8 per lane, one round of loads
-constexpr uint32_t kSurvCap = 16384;       // survivor keys per segment the filter pass may emit
+constexpr uint32_t kSurvCap = 16384;       // survivor keys per segment the filter pass may emit (4 x that for top_n > 4096)
 constexpr uint32_t kRankCap = 1024;        // keys of the boundary bin select_decode can rank by brute force (one per thread)
 
 // Per-segment scratch of the multi-workgroup selection; zeroed by the host memset before every call.
@@ -75,7 +76,8 @@ struct DecodeArgs {
   uint32_t part_begin[ODTK_MAX_LEVELS + 1];   // first workgroup of each level in a select_pass_kernel launch
   uint32_t parts[ODTK_MAX_LEVELS];            // workgroups per segment of that level (0: level too small to need any)
   SelSeg *sel;                                // [n_levels * batch]
-  uint64_t *surv;                             // [n_levels * batch][kSurvCap]
+  uint64_t *surv;                             // [n_levels * batch][surv_cap]
+  uint32_t sort_cap, surv_cap;                // LDS sort capacity of the select_decode variant in use; survivor keys per segment
   const uint32_t *counts;
   const uint64_t *cand;
   float *out_scores;     // [batch, n_levels*top_n]
@@ -263,7 +265,8 @@ __device__ void bitonic_sort_desc_regs(uint64_t *s_keys) {
 }
 
 // Sorts s_keys[0..n_valid) descending; entries up to the padded size are zeroed (sort last).
-// The buffer must hold max(1024, pow2(n_valid)) <= kSortCap keys.
+// The buffer must hold max(1024, pow2(n_valid)) <= kSortCapBig keys.
+template <int kMaxKeys = 4096>
 __device__ __forceinline__ void sort_keys_desc(uint64_t *s_keys, uint32_t n_valid) {
   uint32_t n_pad = kSelThreads;
   while (n_pad < n_valid) n_pad <<= 1;
@@ -271,7 +274,11 @@ __device__ __forceinline__ void sort_keys_desc(uint64_t *s_keys, uint32_t n_vali
   __syncthreads();
   if (n_pad == kSelThreads) bitonic_sort_desc_regs<1>(s_keys);
   else if (n_pad == 2 * kSelThreads) bitonic_sort_desc_regs<2>(s_keys);
-  else bitonic_sort_desc_regs<4>(s_keys);
+  else if (n_pad == 4 * kSelThreads || kMaxKeys <= 4 * kSelThreads) bitonic_sort_desc_regs<4>(s_keys);
+  else if constexpr (kMaxKeys > 4 * kSelThreads) {           // only the top_n > 4096 variant carries the big networks
+    if (n_pad == 8 * kSelThreads) bitonic_sort_desc_regs<8>(s_keys);
+    else bitonic_sort_desc_regs<16>(s_keys);
+  }
 }
 
 // Given a histogram in s_hist (kRadixBins bins, REVERSED: bin 0 = largest digit) finds the bin in which the running
@@ -393,8 +400,8 @@ __device__ __forceinline__ void scan_boundary_256(const uint32_t *s_hist, uint32
 }
 
 // Folds one histogram pass into the state (block-wide, uniform result).  [kmin, kmax]: all keys of the segment.
-__device__ __forceinline__ void advance_state(SelState &st, const uint32_t *g_hist, uint64_t kmin, uint64_t kmax, uint32_t *s_hist,
-                                              uint32_t *s_misc) {
+__device__ __forceinline__ void advance_state(SelState &st, const uint32_t *g_hist, uint64_t kmin, uint64_t kmax, uint32_t sort_cap,
+                                              uint32_t *s_hist, uint32_t *s_misc) {
   const int sh = range_shift(st.lo, st.hi);
   for (uint32_t i = threadIdx.x; i < kRadixBins; i += kPassThreads) s_hist[i] = g_hist[i];
   __syncthreads();
@@ -412,7 +419,7 @@ __device__ __forceinline__ void advance_state(SelState &st, const uint32_t *g_hi
   st.remaining -= above;
   st.taken += above;
   st.in_bin = in_bin;
-  if ((in_bin <= kRankCap && st.taken + in_bin <= static_cast<uint32_t>(kSortCap)) || lo >= hi) st.done = 1;
+  if ((in_bin <= kRankCap && st.taken + in_bin <= sort_cap) || lo >= hi) st.done = 1;
 }
 
 // radix_threshold on a KNOWN key range [lo, hi] (both inclusive), 1024-thread workgroups: every pass cuts the range into
@@ -532,7 +539,7 @@ __global__ __launch_bounds__(kPassThreads) void select_pass_kernel(const DecodeA
   st.remaining = static_cast<uint32_t>(a.top_n);
   st.taken = st.in_bin = st.done = 0;
   if (PASS == 1) {
-    advance_state(st, S.hist[0], ~S.kmin_inv, S.kmax, s_hist, s_misc);
+    advance_state(st, S.hist[0], ~S.kmin_inv, S.kmax, a.sort_cap, s_hist, s_misc);
     if (part == 0 && threadIdx.x == 0) {
       S.lo = st.lo; S.hi = st.hi; S.remaining = st.remaining; S.taken = st.taken; S.in_bin = st.in_bin; S.done = st.done;
     }
@@ -541,10 +548,10 @@ __global__ __launch_bounds__(kPassThreads) void select_pass_kernel(const DecodeA
   uint64_t T64 = 0;
   if (PASS == 2) {
     st.lo = S.lo; st.hi = S.hi; st.remaining = S.remaining; st.taken = S.taken; st.in_bin = S.in_bin; st.done = S.done;
-    if (!st.done) advance_state(st, S.hist[1], st.lo, st.hi, s_hist, s_misc);
+    if (!st.done) advance_state(st, S.hist[1], st.lo, st.hi, a.sort_cap, s_hist, s_misc);
     T64 = st.lo;
     const uint32_t expected = st.taken + st.in_bin;
-    const bool fits = expected <= kSurvCap;
+    const bool fits = expected <= a.surv_cap;
     if (part == 0 && threadIdx.x == 0) {
       S.T = T64; S.bin_hi = st.hi; S.expected = expected; S.need = st.remaining; S.filtered = fits ? 1u : 0u;
       S.n_above = st.taken; S.n_bin = st.in_bin;          // (own fields: the other workgroups of this pass still read S.taken / S.in_bin)
@@ -579,7 +586,7 @@ __global__ __launch_bounds__(kPassThreads) void select_pass_kernel(const DecodeA
   const int sh = range_shift(st.lo, st.hi);
   const uint64_t r_lo = st.lo, r_hi = st.hi;
   uint64_t my_max = 0, my_min_inv = 0;
-  uint64_t *surv = a.surv + static_cast<uint64_t>(seg) * kSurvCap;
+  uint64_t *surv = a.surv + static_cast<uint64_t>(seg) * a.surv_cap;
 
   auto visit = [&](uint64_t key, bool valid) {
     if (PASS < 2) {
@@ -613,7 +620,7 @@ __global__ __launch_bounds__(kPassThreads) void select_pass_kernel(const DecodeA
       if (take) {
         const uint32_t pos = base + __popcll(m & ((1ull << lane) - 1ull));
         if (pos < kStageKeys) s_stage[pos] = key;
-        else { const uint32_t g = atomicAdd(&S.surv_count, 1u); if (g < kSurvCap) surv[g] = key; }   // stage full (rare)
+        else { const uint32_t g = atomicAdd(&S.surv_count, 1u); if (g < a.surv_cap) surv[g] = key; }   // stage full (rare)
       }
     }
   };
@@ -651,7 +658,7 @@ __global__ __launch_bounds__(kPassThreads) void select_pass_kernel(const DecodeA
       __syncthreads();
       const uint32_t g0 = s_misc[25];
       for (uint32_t i = threadIdx.x; i < staged; i += kPassThreads)
-        if (g0 + i < kSurvCap) surv[g0 + i] = s_stage[i];
+        if (g0 + i < a.surv_cap) surv[g0 + i] = s_stage[i];
     }
   }
   stamp(4);
@@ -660,9 +667,13 @@ __global__ __launch_bounds__(kPassThreads) void select_pass_kernel(const DecodeA
 // ---- the kernel ------------------------------------------------------------------------------
 // NB: box parameters (4 axis-aligned, 6 rotated); T: element type of BOTH head tensors;
 // kLogits: cls holds logits (sigmoid fused, see prefilter.hpp score_of).
-template <int NB, typename T, bool kLogits>
+// CAP: keys the LDS sort buffer holds -- kSortCap (static LDS) for top_n <= 4096, kSortCapBig (dynamic LDS, the launch
+// passes CAP * 8 bytes) beyond.
+template <int NB, typename T, bool kLogits, int CAP = kSortCap>
 __global__ __launch_bounds__(kSelThreads) void select_decode_kernel(const DecodeArgs a) {
-  __shared__ uint64_t s_keys[kSortCap];
+  __shared__ uint64_t s_keys_static[CAP <= kSortCap ? CAP : 1];
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_keys_dynamic[];
+  uint64_t *s_keys = CAP <= kSortCap ? s_keys_static : reinterpret_cast<uint64_t *>(s_keys_dynamic);
   __shared__ uint32_t s_hist[kRadixBins];
   __shared__ uint32_t s_misc[32];
 
@@ -698,9 +709,9 @@ __global__ __launch_bounds__(kSelThreads) void select_decode_kernel(const Decode
   const bool narrowed = S && count > sort_size_for(top_n) && S->filtered != 0;
   if (narrowed) {
     const uint32_t n_surv = S->expected;                               // <= kSurvCap, >= top_n
-    const ListSource surv(a.surv + static_cast<uint64_t>(seg) * kSurvCap, n_surv);
+    const ListSource surv(a.surv + static_cast<uint64_t>(seg) * a.surv_cap, n_surv);
     const uint32_t n_hi = S->n_above, in_bin = S->n_bin, need = S->need;   // n_hi + in_bin == n_surv, n_hi + need == top_n
-    if (in_bin <= kRankCap && n_surv <= static_cast<uint32_t>(kSortCap) && top_n + in_bin <= static_cast<uint32_t>(kSortCap)) {
+    if (in_bin <= kRankCap && n_surv <= static_cast<uint32_t>(CAP) && top_n + in_bin <= static_cast<uint32_t>(CAP)) {
       // the normal route: keys above the boundary bin go to the front of the sort buffer, the bin's own keys to its
       // back; then every bin key counts the bin keys larger than itself (keys are unique: the counts are the ranks) and
       // the `need` best land, already in order, behind the others -- exactly top_n keys, no further narrowing
@@ -722,29 +733,29 @@ __global__ __launch_bounds__(kSelThreads) void select_decode_kernel(const Decode
         base_i = __shfl(base_i, 0, kWave);
         const uint64_t lt = (1ull << lane) - 1ull;
         if (above) s_keys[base_a + __popcll(m_a & lt)] = key;
-        if (inside) s_keys[kSortCap - 1 - (base_i + __popcll(m_i & lt))] = key;
+        if (inside) s_keys[CAP - 1 - (base_i + __popcll(m_i & lt))] = key;
       }
       __syncthreads();
       if (threadIdx.x < in_bin) {
-        const uint64_t mine = s_keys[kSortCap - 1 - threadIdx.x];
+        const uint64_t mine = s_keys[CAP - 1 - threadIdx.x];
         uint32_t rank = 0;
-        for (uint32_t q = 0; q < in_bin; ++q) rank += s_keys[kSortCap - 1 - q] > mine ? 1u : 0u;   // same address in every lane: broadcast
+        for (uint32_t q = 0; q < in_bin; ++q) rank += s_keys[CAP - 1 - q] > mine ? 1u : 0u;   // same address in every lane: broadcast
         if (rank < need) s_keys[n_hi + rank] = mine;
       }
       n_sort = n_hi + need;
     } else {
       uint64_t T64 = 0;
       n_sort = n_surv;
-      if (n_surv > kSortCap) T64 = radix_threshold(surv, top_n, kSortCap, s_hist, s_misc, &n_sort);   // tie-heavy inputs only
+      if (n_surv > CAP) T64 = radix_threshold(surv, top_n, CAP, s_hist, s_misc, &n_sort);   // tie-heavy inputs only
       if (threadIdx.x == 0) s_misc[20] = 0;
       __syncthreads();
       surv.template for_range<kSelThreads>(0, n_surv, [&](uint64_t key, bool valid) {
         const bool take = valid && key >= T64;
         const uint32_t slot = wave_append_slot(&s_misc[20], take);
-        if (take && slot < kSortCap) s_keys[slot] = key;
+        if (take && slot < CAP) s_keys[slot] = key;
       });
     }
-  } else if (count <= kSortCap && complete) {
+  } else if (count <= CAP && complete) {
     if (threadIdx.x == 0) s_misc[20] = 0;
     __syncthreads();
     lists.template for_range<kSelThreads>(0, lists.start[kSubLists], [&](uint64_t key, bool valid) {   // order is irrelevant
@@ -758,19 +769,19 @@ __global__ __launch_bounds__(kSelThreads) void select_decode_kernel(const Decode
     uint64_t T64 = 0;
     n_sort = count;                // count <= top_n: everything is wanted (overflow path only)
     if (count > top_n)
-      T64 = complete ? radix_threshold(lists, top_n, kSortCap, s_hist, s_misc, &n_sort)
-                     : radix_threshold(raw, top_n, kSortCap, s_hist, s_misc, &n_sort);
+      T64 = complete ? radix_threshold(lists, top_n, CAP, s_hist, s_misc, &n_sort)
+                     : radix_threshold(raw, top_n, CAP, s_hist, s_misc, &n_sort);
     if (threadIdx.x == 0) s_misc[20] = 0;
     __syncthreads();
     if (complete) {
       lists.template for_range<kSelThreads>(0, lists.start[kSubLists], [&](uint64_t key, bool valid) {
         const bool take = valid && key >= T64;
         const uint32_t slot = wave_append_slot(&s_misc[20], take);
-        if (take && slot < kSortCap) s_keys[slot] = key;
+        if (take && slot < CAP) s_keys[slot] = key;
       });
     } else {
       raw.for_each([&](uint64_t key) {
-        if (key >= T64) { const uint32_t p = atomicAdd(&s_misc[20], 1u); if (p < kSortCap) s_keys[p] = key; }
+        if (key >= T64) { const uint32_t p = atomicAdd(&s_misc[20], 1u); if (p < CAP) s_keys[p] = key; }
       });
     }
   }
@@ -785,16 +796,16 @@ __global__ __launch_bounds__(kSelThreads) void select_decode_kernel(const Decode
     const LdsSource in_lds{s_keys, n_sort};
     const uint64_t T2 = radix_threshold(in_lds, top_n, sort_size, s_hist, s_misc, &n_keep);
     // in-place compaction: every lane reads its keys (<= 4), barrier, survivors go to the front
-    uint64_t mine[kSortCap / kSelThreads];
+    uint64_t mine[CAP / kSelThreads];
 #pragma unroll
-    for (int u = 0; u < kSortCap / kSelThreads; ++u) {
+    for (int u = 0; u < CAP / kSelThreads; ++u) {
       const uint32_t i = u * kSelThreads + threadIdx.x;
       mine[u] = i < n_sort ? s_keys[i] : 0;
     }
     if (threadIdx.x == 0) s_misc[20] = 0;
     __syncthreads();
 #pragma unroll
-    for (int u = 0; u < kSortCap / kSelThreads; ++u) {
+    for (int u = 0; u < CAP / kSelThreads; ++u) {
       const bool keep = mine[u] != 0 && mine[u] >= T2;
       const uint32_t slot = wave_append_slot(&s_misc[20], keep);
       if (keep) s_keys[slot] = mine[u];
@@ -804,7 +815,7 @@ __global__ __launch_bounds__(kSelThreads) void select_decode_kernel(const Decode
   }
   stamp(2);
   if (a.trace && threadIdx.x == 0) { a.trace[blockIdx.x * 8 + 5] = count; a.trace[blockIdx.x * 8 + 6] = n_sort; a.trace[blockIdx.x * 8 + 7] = complete; }
-  sort_keys_desc(s_keys, n_sort);   // the first k_out are the answer
+  sort_keys_desc<CAP>(s_keys, n_sort);   // the first k_out are the answer
   stamp(3);
 
   // ---- decode + write this segment's slice of the concatenated outputs ----

@@ -27,7 +27,7 @@ _LIB_PATH = os.environ.get('ODTK_HIP_LIBRARY') or os.path.join(os.path.dirname(o
 OK, ERR_INVALID, ERR_WORKSPACE, ERR_HIP, ERR_UNSUPPORTED = 0, -1, -2, -3, -4
 F32, BF16, F16 = 0, 1, 2
 FLAG_ROTATED, FLAG_LOGITS, FLAG_ROTATED_NMS_FIXED_ANGLE = 1, 2, 4
-MAX_LEVELS, MAX_ANCHORS, MAX_TOP_N, MAX_NMS_COUNT, MAX_NMS_COUNT_SCRATCH = 6, 32, 4096, 7680, 1 << 22
+MAX_LEVELS, MAX_ANCHORS, MAX_TOP_N, MAX_NMS_COUNT, MAX_NMS_COUNT_SCRATCH = 6, 32, 16384, 7680, 1 << 22
 
 _vp = ctypes.c_void_p
 _vpp = ctypes.POINTER(ctypes.c_void_p)

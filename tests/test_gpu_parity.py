@@ -356,3 +356,25 @@ def test_top_n_2000_times_five_levels():
     for h, o in zip(det, ora):
         assert_bits(h, o, 'detect top_n=2000')
     assert int((ref[0] > 0).sum()) > 5000
+
+
+@pytest.mark.parametrize('top_n', [4097, 5000, 16384])
+def test_top_n_beyond_4096(top_n):
+    """top_n > 4096 per level (round 1 / 2a: 'invalid argument'; the reference has no cap): the select_decode variant with a
+    128 KiB dynamic-LDS sort buffer, through the selection passes (138 k candidates), the direct route (fewer candidates
+    than top_n) and ties; NMS then takes 2 x top_n candidates per image out of the workspace."""
+    g = torch.Generator().manual_seed(top_n)
+    a, c, h, w = 9, 40, 60, 80
+    anchors = {16: box.generate_anchors(16, RATIOS, SCALES), 32: box.generate_anchors(32, RATIOS, SCALES)}
+    big = torch.where(torch.rand(2, a * c, h, w, generator=g) < 0.08, torch.rand(2, a * c, h, w, generator=g) * 0.9 + 0.06,
+                      torch.rand(2, a * c, h, w, generator=g) * 0.04)
+    big[1] = big[1].bfloat16().float()                                         # image 1: heavy ties
+    small = torch.where(torch.rand(2, a * c, 30, 40, generator=g) < 0.005, torch.rand(2, a * c, 30, 40, generator=g) * 0.9 + 0.06,
+                        torch.zeros(2, a * c, 30, 40))                         # ~2 k candidates: fewer than top_n
+    dl = [torch.randn(2, a * 4, h, w, generator=g) * 0.2, torch.randn(2, a * 4, 30, 40, generator=g) * 0.2]
+    out, ref = _check_decode_levels([big, small], dl, [16, 32], anchors, 0.05, top_n)
+    assert int((ref[0][:, :top_n] > 0).sum()) == 2 * top_n
+    det = box.detect([big.cuda(), small.cuda()], [d.cuda() for d in dl], [16, 32], anchors, 0.05, top_n, 0.5, 300)
+    ora = box_oracle.nms(out[0].cpu(), out[1].cpu(), out[2].cpu(), 0.5, 300)
+    for h_, o in zip(det, ora):
+        assert_bits(h_, o, 'detect top_n=%d' % top_n)
