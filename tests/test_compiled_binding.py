@@ -12,7 +12,16 @@ import numpy as np
 import pytest
 import torch
 
-from odtk import _C, _C_ext, box
+from odtk import _C, box
+
+try:
+    from odtk import _C_ext
+except ImportError:                      # not built yet (a fresh checkout): build it the way __graft_entry__.build() does
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'retinanet-examples_amd', 'csrc'))
+    import build_ext
+    build_ext.build()
+    from odtk import _C_ext
 
 GOLDEN = os.path.join(os.path.dirname(__file__), 'golden')
 RATIOS = [1.0, 2.0, 0.5]

@@ -8,7 +8,6 @@ import torch
 torch.backends.cudnn.benchmark = True
 from odtk import _C, box
 from odtk.model import Model
-from odtk.fused import FusedRetinaNet
 sys.path.insert(0, ROOT)
 import bench
 
@@ -17,10 +16,9 @@ ROT = '--rotated' in sys.argv
 m = Model('ResNet50FPN', rotated_bbox=ROT); m.initialize(None)
 m = m.cuda().to(memory_format=torch.channels_last).eval()
 x = torch.randn(8, 3, 800, 1280, generator=torch.Generator().manual_seed(0)).cuda().contiguous(memory_format=torch.channels_last)
-bench.calibrate_cls_head(m, x, 0.573, torch.bfloat16)
-eng = FusedRetinaNet(m).cuda()
+bench.calibrate_cls_head(m, lambda t: m.inference_engine(torch.bfloat16).heads(t), x, bench.SPEC_FRACTION, m.threshold)
 with torch.no_grad():
-    cls, dl = eng.heads(x)
+    cls, dl = m.inference_engine(torch.bfloat16).heads(x)
 strides = [8, 16, 32, 64, 128]
 for s in strides: m.level_anchors(s)
 run = lambda: box.detect(cls, dl, strides, m.anchors, 0.05, 1000, 0.5, 100, ROT, logits=True)
