@@ -265,6 +265,32 @@ int odtk_retina_loss_backward(const void *cls, const void *box, const float *dep
                               const float *grad_cls_sum, const float *grad_box_sum, void *dcls, void *dbox,
                               void *stream);
 
+/*
+ * odtk_retina_loss_levels_forward / _backward -- the same reduction for ALL pyramid levels of the batch in ONE launch
+ * per direction (a training step: two launches instead of ten).  Per level: the tensors of odtk_retina_loss_*; every
+ * level shares batch, num_anchors, num_classes, box_params, dtype.
+ *   forward:  sums = DEVICE double[n_levels][3] (cls_sum, box_sum, foreground count per level), overwritten.
+ *   backward: grad_cls_sums / grad_box_sums = DEVICE float32 [n_levels] (NULL = zeros); levels[l].dcls / .dbox receive
+ *             the gradients (forward ignores them).
+ */
+typedef struct odtk_loss_level {
+  const void *cls;            /* [batch, A*C, H, W] logits                                   */
+  const void *box;            /* [batch, A*box_params, H, W]                                 */
+  const float *depth;         /* float32 [batch, A, 1, H, W]                                 */
+  const float *box_target;    /* float32 [batch, A, box_params, H, W]                        */
+  void *dcls, *dbox;          /* backward outputs, dtype / layout of cls / box               */
+  int32_t height, width;
+  int32_t channels_last;      /* layout of cls and box: 0 NCHW, 1 NHWC                       */
+  int32_t pad_;
+} odtk_loss_level_t;
+
+int odtk_retina_loss_levels_forward(int n_levels, const odtk_loss_level_t *levels, int batch_size, int num_anchors,
+                                    int num_classes, int box_params, int dtype, float alpha, float gamma, float beta,
+                                    double *sums, void *stream);
+int odtk_retina_loss_levels_backward(int n_levels, const odtk_loss_level_t *levels, int batch_size, int num_anchors,
+                                     int num_classes, int box_params, int dtype, float alpha, float gamma, float beta,
+                                     const float *grad_cls_sums, const float *grad_box_sums, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * Measurement hooks (used by bench.py; off by default, zero cost when off).
  * While enabled, a kernel launch of this library carries a hipEvent pair (asynchronous -- still no

@@ -24,6 +24,7 @@
 
 #include "common.hpp"
 #include "prefilter.hpp"   // element types F32 / BF16 / F16, vuint4, load_raw, round_to_*
+#include "../../include/odtk_hip.h"
 
 namespace odtk {
 
@@ -104,17 +105,17 @@ __device__ __forceinline__ double block_sum(double v, double *s_red) {
   return r;                                                                    // valid on thread 0
 }
 
-// kBackward = false: accumulate the three sums.  kBackward = true: write the gradients.
+// One workgroup's share of one level: workgroup `block` of the `n_blocks` that level's launch (or its slice of a
+// multi-level launch) consists of.  kBackward = false: accumulate the three sums.  kBackward = true: write the gradients.
 template <typename T, bool kBackward>
-__global__ __launch_bounds__(kLossThreads) void retina_loss_kernel(const LossArgs a) {
+__device__ __forceinline__ void retina_loss_block(const LossArgs &a, uint32_t block, uint32_t n_blocks, double *s_red) {
   constexpr int kPer = T::kPerLoad;
-  __shared__ double s_red[kLossThreads / kWave];
   const uint32_t A = a.num_anchors, C = a.num_classes, hw = a.hw, NB = a.nb;
   const uint32_t channels = A * C;
   float sum_cls = 0.0f, sum_box = 0.0f, n_fg = 0.0f;
   double acc_cls = 0.0, acc_box = 0.0, acc_fg = 0.0;
 
-  if (blockIdx.x < a.cls_blocks) {
+  if (block < a.cls_blocks) {
     // ---- the logits, in memory order, 16 bytes per lane per trip ----
     const float g = kBackward ? (a.g_cls ? *a.g_cls : 0.0f) : 0.0f;
     // (the host guarantees batch * channels * hw < 2^32: index arithmetic stays in 32 bits -- a 64-bit division
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(kLossThreads) void retina_loss_kernel(const LossArg
     const vuint4 *src = static_cast<const vuint4 *>(a.cls);
     const uint32_t stride = a.cls_blocks * kLossThreads;
     int trips = 0;
-    for (uint32_t v = blockIdx.x * kLossThreads + threadIdx.x; v < n_vec; v += stride) {
+    for (uint32_t v = block * kLossThreads + threadIdx.x; v < n_vec; v += stride) {
       const vuint4 raw = __builtin_nontemporal_load(src + v);
       const uint32_t r0 = v * kPer;
       // decompose the first element once; the others follow by increment with carry
@@ -214,7 +215,7 @@ __global__ __launch_bounds__(kLossThreads) void retina_loss_kernel(const LossArg
       }
     }
     // scalar tail (n % kPer elements), first block only
-    if (blockIdx.x == 0 && threadIdx.x < n - n_vec * kPer) {
+    if (block == 0 && threadIdx.x < n - n_vec * kPer) {
       const uint32_t r = n_vec * kPer + threadIdx.x;
       uint32_t img, an, c, pix;
       if (a.channels_last) {
@@ -241,8 +242,8 @@ __global__ __launch_bounds__(kLossThreads) void retina_loss_kernel(const LossArg
     // ---- the box deltas: one lane per (image, anchor, pixel), NB parameters each; only foreground anchors count ----
     const float g = kBackward ? (a.g_box ? *a.g_box : 0.0f) : 0.0f;
     const uint64_t cells = static_cast<uint64_t>(a.batch) * A * hw;
-    const uint64_t stride = static_cast<uint64_t>(gridDim.x - a.cls_blocks) * kLossThreads;
-    for (uint64_t cell = static_cast<uint64_t>(blockIdx.x - a.cls_blocks) * kLossThreads + threadIdx.x; cell < cells; cell += stride) {
+    const uint64_t stride = static_cast<uint64_t>(n_blocks - a.cls_blocks) * kLossThreads;
+    for (uint64_t cell = static_cast<uint64_t>(block - a.cls_blocks) * kLossThreads + threadIdx.x; cell < cells; cell += stride) {
       const uint64_t ia = cell / hw;                          // img * A + an
       const uint32_t pix = static_cast<uint32_t>(cell - ia * hw);
       const uint32_t img = static_cast<uint32_t>(ia / A), an = static_cast<uint32_t>(ia - static_cast<uint64_t>(img) * A);
@@ -274,6 +275,30 @@ __global__ __launch_bounds__(kLossThreads) void retina_loss_kernel(const LossArg
       if (f_ != 0.0) atomicAdd(a.acc + 2, f_);
     }
   }
+}
+
+template <typename T, bool kBackward>
+__global__ __launch_bounds__(kLossThreads) void retina_loss_kernel(const LossArgs a) {
+  __shared__ double s_red[kLossThreads / kWave];
+  retina_loss_block<T, kBackward>(a, blockIdx.x, gridDim.x, s_red);
+}
+
+// All pyramid levels of the batch in ONE launch per direction (ten launches per training step become two): the
+// workgroups of level l are [block_begin[l], block_begin[l + 1]).
+struct LossLevelsArgs {
+  LossArgs lv[ODTK_MAX_LEVELS];
+  uint32_t block_begin[ODTK_MAX_LEVELS + 1];
+  int n_levels;
+};
+
+template <typename T, bool kBackward>
+__global__ __launch_bounds__(kLossThreads) void retina_loss_levels_kernel(const LossLevelsArgs a) {
+  __shared__ double s_red[kLossThreads / kWave];
+  int l = 0;
+#pragma unroll
+  for (int i = 1; i < ODTK_MAX_LEVELS; ++i)
+    if (i < a.n_levels && blockIdx.x >= a.block_begin[i]) l = i;
+  retina_loss_block<T, kBackward>(a.lv[l], blockIdx.x - a.block_begin[l], a.block_begin[l + 1] - a.block_begin[l], s_red);
 }
 
 }  // namespace odtk

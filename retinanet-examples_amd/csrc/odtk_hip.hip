@@ -421,18 +421,18 @@ int bias_act_dispatch(void *y, const float *bias, const void *res, uint64_t n, u
   return bias_act_typed<odtk::F16>(y, bias, res, n, c, relu, s);
 }
 
-int retina_loss_launch(bool backward, const void *cls, const void *box, const float *depth, const float *box_target,
-                       int batch, int A, int C, int height, int width, int nb, int dtype, int channels_last, float alpha,
-                       float gamma, float beta, double *sums, const float *g_cls, const float *g_box, void *dcls,
-                       void *dbox, hipStream_t stream) {
-  if (!cls || !box || !depth || !box_target || batch <= 0 || A <= 0 || C <= 0 || height <= 0 || width <= 0 || nb <= 0)
-    return ODTK_ERR_INVALID;
-  if (dtype != ODTK_F32 && dtype != ODTK_BF16 && dtype != ODTK_F16) return ODTK_ERR_UNSUPPORTED;
-  if (channels_last != 0 && channels_last != 1) return ODTK_ERR_INVALID;
-  if ((reinterpret_cast<uintptr_t>(cls) | reinterpret_cast<uintptr_t>(box)) & 15u) return ODTK_ERR_INVALID;   // 16-B vector loads
+// fills the kernel arguments of one level; returns the number of workgroups it wants (0 on error, *rc set)
+unsigned retina_loss_fill(odtk::LossArgs &la, bool backward, const void *cls, const void *box, const float *depth,
+                          const float *box_target, int batch, int A, int C, int height, int width, int nb, int dtype,
+                          int channels_last, float alpha, float gamma, float beta, double *sums, const float *g_cls,
+                          const float *g_box, void *dcls, void *dbox, int *rc) {
+  *rc = ODTK_ERR_INVALID;
+  if (!cls || !box || !depth || !box_target || batch <= 0 || A <= 0 || C <= 0 || height <= 0 || width <= 0 || nb <= 0) return 0;
+  if (channels_last != 0 && channels_last != 1) return 0;
+  if ((reinterpret_cast<uintptr_t>(cls) | reinterpret_cast<uintptr_t>(box)) & 15u) return 0;   // 16-B vector loads
+  if (backward && (!dcls || !dbox || ((reinterpret_cast<uintptr_t>(dcls) | reinterpret_cast<uintptr_t>(dbox)) & 15u))) return 0;
   const unsigned long long n = 1ull * batch * A * C * height * width;
-  if (n >= (1ull << 32)) return ODTK_ERR_INVALID;
-  odtk::LossArgs la;
+  if (n >= (1ull << 32)) return 0;
   std::memset(&la, 0, sizeof la);
   la.cls = cls; la.box = box; la.depth = depth; la.box_target = box_target;
   la.acc = sums; la.g_cls = g_cls; la.g_box = g_box; la.dcls = dcls; la.dbox = dbox;
@@ -449,7 +449,21 @@ int retina_loss_launch(bool backward, const void *cls, const void *box, const fl
   unsigned long long box_blocks = (1ull * batch * A * height * width + odtk::kLossThreads - 1) / odtk::kLossThreads;
   if (box_blocks > 1024) box_blocks = 1024;
   la.cls_blocks = static_cast<uint32_t>(cls_blocks);
-  const dim3 grid(static_cast<unsigned>(cls_blocks + box_blocks)), block(odtk::kLossThreads);
+  *rc = ODTK_OK;
+  return static_cast<unsigned>(cls_blocks + box_blocks);
+}
+
+int retina_loss_launch(bool backward, const void *cls, const void *box, const float *depth, const float *box_target,
+                       int batch, int A, int C, int height, int width, int nb, int dtype, int channels_last, float alpha,
+                       float gamma, float beta, double *sums, const float *g_cls, const float *g_box, void *dcls,
+                       void *dbox, hipStream_t stream) {
+  if (dtype != ODTK_F32 && dtype != ODTK_BF16 && dtype != ODTK_F16) return ODTK_ERR_UNSUPPORTED;
+  odtk::LossArgs la;
+  int rc;
+  const unsigned blocks = retina_loss_fill(la, backward, cls, box, depth, box_target, batch, A, C, height, width, nb, dtype,
+                                           channels_last, alpha, gamma, beta, sums, g_cls, g_box, dcls, dbox, &rc);
+  if (rc != ODTK_OK) return rc;
+  const dim3 grid(blocks), block(odtk::kLossThreads);
   {
 #define ODTK_LOSS(T)                                                                                            \
   do {                                                                                                          \
@@ -461,6 +475,40 @@ int retina_loss_launch(bool backward, const void *cls, const void *box, const fl
     else ODTK_LOSS(odtk::F16);
 #undef ODTK_LOSS
   }
+  ODTK_HIP_TRY(hipGetLastError());
+  return ODTK_OK;
+}
+
+int retina_loss_levels_launch(bool backward, int n_levels, const odtk_loss_level_t *levels, int batch, int A, int C, int nb,
+                              int dtype, float alpha, float gamma, float beta, double *sums, const float *g_cls,
+                              const float *g_box, hipStream_t stream) {
+  if (n_levels <= 0 || n_levels > ODTK_MAX_LEVELS || !levels) return ODTK_ERR_INVALID;
+  if (dtype != ODTK_F32 && dtype != ODTK_BF16 && dtype != ODTK_F16) return ODTK_ERR_UNSUPPORTED;
+  odtk::LossLevelsArgs la;
+  std::memset(&la, 0, sizeof la);
+  la.n_levels = n_levels;
+  unsigned total = 0;
+  for (int l = 0; l < n_levels; ++l) {
+    int rc;
+    const unsigned blocks = retina_loss_fill(la.lv[l], backward, levels[l].cls, levels[l].box, levels[l].depth, levels[l].box_target,
+                                             batch, A, C, levels[l].height, levels[l].width, nb, dtype, levels[l].channels_last,
+                                             alpha, gamma, beta, sums ? sums + 3 * l : nullptr, g_cls ? g_cls + l : nullptr,
+                                             g_box ? g_box + l : nullptr, levels[l].dcls, levels[l].dbox, &rc);
+    if (rc != ODTK_OK) return rc;
+    la.block_begin[l] = total;
+    total += blocks;
+  }
+  for (int l = n_levels; l <= ODTK_MAX_LEVELS; ++l) la.block_begin[l] = total;
+  const dim3 grid(total), block(odtk::kLossThreads);
+#define ODTK_LOSS(T)                                                                                                   \
+  do {                                                                                                                 \
+    if (backward) timed_launch(ODTK_KERNEL_LOSS, odtk::retina_loss_levels_kernel<T, true>, grid, block, 0, stream, la);  \
+    else timed_launch(ODTK_KERNEL_LOSS, odtk::retina_loss_levels_kernel<T, false>, grid, block, 0, stream, la);          \
+  } while (0)
+  if (dtype == ODTK_F32) ODTK_LOSS(odtk::F32);
+  else if (dtype == ODTK_BF16) ODTK_LOSS(odtk::BF16);
+  else ODTK_LOSS(odtk::F16);
+#undef ODTK_LOSS
   ODTK_HIP_TRY(hipGetLastError());
   return ODTK_OK;
 }
@@ -633,6 +681,22 @@ int odtk_retina_loss_backward(const void *cls, const void *box, const float *dep
   return retina_loss_launch(true, cls, box, depth, box_target, batch_size, num_anchors, num_classes, height, width,
                             box_params, dtype, channels_last, alpha, gamma, beta, nullptr, grad_cls_sum, grad_box_sum, dcls,
                             dbox, static_cast<hipStream_t>(stream));
+}
+
+int odtk_retina_loss_levels_forward(int n_levels, const odtk_loss_level_t *levels, int batch_size, int num_anchors,
+                                    int num_classes, int box_params, int dtype, float alpha, float gamma, float beta,
+                                    double *sums, void *stream) {
+  if (!sums || n_levels <= 0 || n_levels > ODTK_MAX_LEVELS) return ODTK_ERR_INVALID;
+  ODTK_HIP_TRY(hipMemsetAsync(sums, 0, 3 * sizeof(double) * n_levels, static_cast<hipStream_t>(stream)));
+  return retina_loss_levels_launch(false, n_levels, levels, batch_size, num_anchors, num_classes, box_params, dtype, alpha,
+                                   gamma, beta, sums, nullptr, nullptr, static_cast<hipStream_t>(stream));
+}
+
+int odtk_retina_loss_levels_backward(int n_levels, const odtk_loss_level_t *levels, int batch_size, int num_anchors,
+                                     int num_classes, int box_params, int dtype, float alpha, float gamma, float beta,
+                                     const float *grad_cls_sums, const float *grad_box_sums, void *stream) {
+  return retina_loss_levels_launch(true, n_levels, levels, batch_size, num_anchors, num_classes, box_params, dtype, alpha,
+                                   gamma, beta, nullptr, grad_cls_sums, grad_box_sums, static_cast<hipStream_t>(stream));
 }
 
 int odtk_bias_act_maxpool(const void *y, const float *bias, void *out, int batch_size, int height, int width,

@@ -35,6 +35,13 @@ _fp = ctypes.POINTER(ctypes.c_float)
 _sz = ctypes.c_size_t
 
 
+class LossLevel(ctypes.Structure):
+    """odtk_loss_level_t"""
+    _fields_ = [('cls', ctypes.c_void_p), ('box', ctypes.c_void_p), ('depth', ctypes.c_void_p), ('box_target', ctypes.c_void_p),
+                ('dcls', ctypes.c_void_p), ('dbox', ctypes.c_void_p), ('height', ctypes.c_int32), ('width', ctypes.c_int32),
+                ('channels_last', ctypes.c_int32), ('pad_', ctypes.c_int32)]
+
+
 class Level(ctypes.Structure):
     """odtk_level_t"""
     _fields_ = [('cls', _vp), ('box', _vp), ('height', ctypes.c_int32), ('width', ctypes.c_int32),
@@ -66,6 +73,10 @@ _SIGNATURES = {
     'odtk_retina_loss_forward': (ctypes.c_int, [_vp, _vp, _vp, _vp] + [ctypes.c_int] * 8 + [ctypes.c_float] * 3 + [_vp, _vp]),
     'odtk_retina_loss_backward': (ctypes.c_int, [_vp, _vp, _vp, _vp] + [ctypes.c_int] * 8 + [ctypes.c_float] * 3 +
                                   [_vp, _vp, _vp, _vp, _vp]),
+    'odtk_retina_loss_levels_forward': (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(LossLevel)] + [ctypes.c_int] * 5 +
+                                        [ctypes.c_float] * 3 + [_vp, _vp]),
+    'odtk_retina_loss_levels_backward': (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(LossLevel)] + [ctypes.c_int] * 5 +
+                                         [ctypes.c_float] * 3 + [_vp, _vp, _vp]),
     'odtk_bias_act': (ctypes.c_int, [_vp, _vp, _vp, _sz, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp]),
     'odtk_profile_enable': (ctypes.c_int, [ctypes.c_int]),
     'odtk_debug_set_trace': (ctypes.c_int, [_vp]),
@@ -378,6 +389,62 @@ def _loss_geometry(cls_head, box_head, depth, box_target):
     if depth.dtype != torch.float32 or box_target.dtype != torch.float32 or not depth.is_contiguous() or not box_target.is_contiguous():
         raise RuntimeError('retina_loss: depth and box_target must be contiguous float32')
     return b, a, ch // a, h, w, nb, _DTYPES[cls_head.dtype], lay
+
+
+def _loss_levels(cls_heads, box_heads, depths, box_targets, grads=None):
+    n = len(cls_heads)
+    if not (n == len(box_heads) == len(depths) == len(box_targets)) or n == 0 or n > MAX_LEVELS:
+        raise RuntimeError('retina_loss_levels: need 1..%d levels with matching lists' % MAX_LEVELS)
+    arr = (LossLevel * n)()
+    geo = None
+    for i in range(n):
+        b, a, c, h, w, nb, dtype, lay = _loss_geometry(cls_heads[i], box_heads[i], depths[i], box_targets[i])
+        if geo is None:
+            geo = (b, a, c, nb, dtype)
+        elif geo != (b, a, c, nb, dtype):
+            raise RuntimeError('retina_loss_levels: every level must share batch, anchors, classes, box parameters and dtype')
+        arr[i].cls, arr[i].box = cls_heads[i].data_ptr(), box_heads[i].data_ptr()
+        arr[i].depth, arr[i].box_target = depths[i].data_ptr(), box_targets[i].data_ptr()
+        arr[i].height, arr[i].width, arr[i].channels_last = h, w, lay
+        if grads is not None:
+            arr[i].dcls, arr[i].dbox = grads[0][i].data_ptr(), grads[1][i].data_ptr()
+    return arr, n, geo
+
+
+def retina_loss_levels_forward(cls_heads, box_heads, depths, box_targets, alpha, gamma, beta):
+    """All pyramid levels in ONE launch -> float64 CUDA tensor [L, 3] = per level (cls_sum, box_sum, #foreground)."""
+    arr, n, (b, a, c, nb, dtype) = _loss_levels(cls_heads, box_heads, depths, box_targets)
+    dev = cls_heads[0].device
+    with torch.cuda.device(dev):
+        sums = torch.empty((n, 3), dtype=torch.float64, device=dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _check(library().odtk_retina_loss_levels_forward(n, arr, b, a, c, nb, dtype, float(alpha), float(gamma), float(beta),
+                                                         sums.data_ptr(), stream), 'retina_loss_levels_forward')
+    return sums
+
+
+def retina_loss_levels_backward(cls_heads, box_heads, depths, box_targets, alpha, gamma, beta, grad_cls_sums, grad_box_sums):
+    """Gradients of sum_l (g_cls[l] * cls_sum[l] + g_box[l] * box_sum[l]) w.r.t. every head, ONE launch.
+    grad_*: float32 CUDA vectors [L] (or None = zeros), read on the device."""
+    dev = cls_heads[0].device
+    with torch.cuda.device(dev):
+        dcls = [torch.empty_like(t) for t in cls_heads]
+        dbox = [torch.empty_like(t) for t in box_heads]
+        for g, t in zip(dcls + dbox, list(cls_heads) + list(box_heads)):
+            if g.stride() != t.stride():
+                raise RuntimeError('retina_loss_levels_backward: could not allocate gradients in the heads\' layout')
+        arr, n, (b, a, c, nb, dtype) = _loss_levels(cls_heads, box_heads, depths, box_targets, (dcls, dbox))
+
+        def vec(g):
+            return None if g is None else g.detach().to(device=dev, dtype=torch.float32).reshape(n).contiguous()
+
+        g_cls, g_box = vec(grad_cls_sums), vec(grad_box_sums)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _check(library().odtk_retina_loss_levels_backward(n, arr, b, a, c, nb, dtype, float(alpha), float(gamma), float(beta),
+                                                          g_cls.data_ptr() if g_cls is not None else None,
+                                                          g_box.data_ptr() if g_box is not None else None, stream),
+               'retina_loss_levels_backward')
+    return dcls, dbox
 
 
 def retina_loss_forward(cls_head, box_head, depth, box_target, alpha, gamma, beta):

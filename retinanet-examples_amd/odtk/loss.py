@@ -71,6 +71,53 @@ class _FusedLevelLoss(torch.autograd.Function):
         return dcls, dbox, None, None, None, None, None
 
 
+def _as_written_pair(cls_head, box_head):
+    """Head tensors go to the kernels as the convolutions wrote them; anything exotic is normalised once."""
+    pair = [cls_head, box_head]
+    for i, t in enumerate(pair):
+        if not (t.is_contiguous() or t.is_contiguous(memory_format=torch.channels_last)):
+            pair[i] = t.contiguous()
+    if pair[0].is_contiguous() != pair[1].is_contiguous() and pair[0].shape[2] * pair[0].shape[3] > 1:
+        pair[1] = pair[1].contiguous() if pair[0].is_contiguous() else pair[1].contiguous(memory_format=torch.channels_last)
+    if pair[1].dtype != pair[0].dtype:
+        pair[1] = pair[1].to(pair[0].dtype)
+    return pair
+
+
+class _FusedPyramidLoss(torch.autograd.Function):
+    """(cls_heads..., box_heads...) of ALL levels -> (cls_sums [L], box_sums [L], foreground [L]); one launch each way."""
+
+    @staticmethod
+    def forward(ctx, n, alpha, gamma, beta, *tensors):
+        from . import _C
+        cls_heads, box_heads = tensors[:n], tensors[n:2 * n]
+        depths, box_targets = tensors[2 * n:3 * n], tensors[3 * n:4 * n]
+        sums = _C.retina_loss_levels_forward(cls_heads, box_heads, depths, box_targets, alpha, gamma, beta).float()
+        ctx.save_for_backward(*tensors)
+        ctx.meta = (n, alpha, gamma, beta)
+        cls_sums, box_sums, foreground = sums[:, 0].contiguous(), sums[:, 1].contiguous(), sums[:, 2].contiguous()
+        ctx.mark_non_differentiable(foreground)
+        return cls_sums, box_sums, foreground
+
+    @staticmethod
+    def backward(ctx, grad_cls_sums, grad_box_sums, _grad_foreground):
+        from . import _C
+        n, alpha, gamma, beta = ctx.meta
+        t = ctx.saved_tensors
+        dcls, dbox = _C.retina_loss_levels_backward(t[:n], t[n:2 * n], t[2 * n:3 * n], t[3 * n:4 * n], alpha, gamma, beta,
+                                                    grad_cls_sums, grad_box_sums)
+        return (None, None, None, None) + tuple(dcls) + tuple(dbox) + (None,) * (2 * n)
+
+
+def fused_pyramid_loss(cls_heads, box_heads, depths, box_targets, alpha=0.25, gamma=2.0, beta=0.11):
+    """`fused_level_loss` for every pyramid level at once: per-level (cls_sums [L], box_sums [L], foreground [L]) from ONE
+    HIP launch forward and ONE backward (a training step: two launches where the per-level form needs ten)."""
+    pairs = [_as_written_pair(c, b) for c, b in zip(cls_heads, box_heads)]
+    n = len(pairs)
+    return _FusedPyramidLoss.apply(n, alpha, gamma, beta, *[p[0] for p in pairs], *[p[1] for p in pairs],
+                                   *[d.contiguous() for d in depths], *[t.contiguous() for t in box_targets])
+
+
 def fused_level_loss(cls_head, box_head, depth, box_target, alpha=0.25, gamma=2.0, beta=0.11):
     """One level's (sum of masked focal losses, sum of masked smooth-L1 losses, number of foreground anchors).
 
@@ -81,12 +128,5 @@ def fused_level_loss(cls_head, box_head, depth, box_target, alpha=0.25, gamma=2.
         cls = FocalLoss(alpha, gamma)(cls_head.view(B, A, C, H, W).float(), onehot(depth - 1))
         (cls * (depth >= 0)).sum(), (SmoothL1Loss(beta)(box_head.view_as(box_target).float(), box_target)
                                      * (depth > 0)).sum(), (depth > 0).sum()"""
-    pair = [cls_head, box_head]
-    for i, t in enumerate(pair):
-        if not (t.is_contiguous() or t.is_contiguous(memory_format=torch.channels_last)):
-            pair[i] = t.contiguous()
-    if pair[0].is_contiguous() != pair[1].is_contiguous() and pair[0].shape[2] * pair[0].shape[3] > 1:
-        pair[1] = pair[1].contiguous() if pair[0].is_contiguous() else pair[1].contiguous(memory_format=torch.channels_last)
-    if pair[1].dtype != pair[0].dtype:
-        pair[1] = pair[1].to(pair[0].dtype)
+    pair = _as_written_pair(cls_head, box_head)
     return _FusedLevelLoss.apply(pair[0], pair[1], depth.contiguous(), box_target.contiguous(), alpha, gamma, beta)

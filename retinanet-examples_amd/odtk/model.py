@@ -27,7 +27,7 @@ import torch.nn as nn
 
 from . import backbones as backbones_mod
 from . import box as box_ops
-from .loss import FocalLoss, SmoothL1Loss, fused_level_loss
+from .loss import FocalLoss, SmoothL1Loss, fused_pyramid_loss
 
 DEFAULT_RATIOS = [1.0, 2.0, 0.5]
 DEFAULT_SCALES = [4 * 2 ** (i / 3) for i in range(3)]
@@ -251,18 +251,22 @@ class Model(nn.Module):
         """Focal + smooth-L1 losses summed over levels and normalised by the number of foreground
         anchors (reference model.py:186-210); `depth` is -1 ignore / 0 background / class+1."""
         cls_total, box_total, foreground = 0.0, 0.0, 0.0
-        fused = self.fused_loss and cls_heads[0].is_cuda
+        if self.fused_loss and cls_heads[0].is_cuda:
+            # targets of every level (one HIP launch each; the class map is implied by depth and not even built), then focal
+            # + smooth-L1 + masks + sums of ALL levels in one HIP pass -- and one more in backward (csrc/loss.hpp)
+            depths, box_targets = [], []
+            for cls_head in cls_heads:
+                stride = x.shape[-1] / cls_head.shape[-1]
+                _, box_target, depth = self._extract_targets(targets, stride, cls_head.shape[-2:], False)
+                depths.append(depth)
+                box_targets.append(box_target)
+            cls_sums, box_sums, fg = fused_pyramid_loss(cls_heads, box_heads, depths, box_targets, self.cls_criterion.alpha,
+                                                        self.cls_criterion.gamma, self.box_criterion.beta)
+            foreground = fg.clamp(min=1).sum()              # per level, as the reference clamps (model.py:196)
+            return cls_sums.sum() / foreground, box_sums.sum() / foreground
         for cls_head, box_head in zip(cls_heads, box_heads):
             stride = x.shape[-1] / cls_head.shape[-1]
-            cls_target, box_target, depth = self._extract_targets(targets, stride, cls_head.shape[-2:], not fused)
-            if fused:
-                # focal + smooth-L1 + masks + sums of this level in one HIP pass (and one in backward); the class
-                # target is implied by depth, so the one-hot map above was not even built
-                cls_sum, box_sum, fg = fused_level_loss(cls_head, box_head, depth, box_target, self.cls_criterion.alpha,
-                                                        self.cls_criterion.gamma, self.box_criterion.beta)
-                foreground = foreground + fg.clamp(min=1)
-                cls_total, box_total = cls_total + cls_sum, box_total + box_sum
-                continue
+            cls_target, box_target, depth = self._extract_targets(targets, stride, cls_head.shape[-2:])
             foreground = foreground + (depth > 0).sum().float().clamp(min=1)
             cls_loss = self.cls_criterion(cls_head.view_as(cls_target).float(), cls_target)
             cls_total = cls_total + (cls_loss * (depth >= 0).expand_as(cls_target).float()).sum()
