@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Builds the compiled operator module retinanet-examples_amd/odtk/_C_ext*.so from csrc/extensions.cpp: host C++ only
+"""Builds the compiled operator module retinanet-examples_amd/odtk/_C_ext*.so from csrc/odtk_binding.cpp: host C++ only
 (g++), against PyTorch-ROCm's headers, linked to libodtk_hip.so next to it.  One explicit compiler command, in-tree
 output (the .so travels to the GPU box with the snapshot; a JIT cache under ~/.cache would not)."""
 import os
@@ -19,7 +19,7 @@ def target():
 def build(force=False):
     import torch
     from torch.utils import cpp_extension as ce
-    out, src = target(), os.path.join(HERE, 'extensions.cpp')
+    out, src = target(), os.path.join(HERE, 'odtk_binding.cpp')
     deps = [src, os.path.join(HERE, '..', '..', 'include', 'odtk_hip.h')]
     if not force and os.path.isfile(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps):
         return out

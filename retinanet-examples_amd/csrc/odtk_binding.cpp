@@ -1,4 +1,4 @@
-// extensions.cpp -- the reference's operator module (NVIDIA/retinanet-examples csrc/extensions.cpp:47-158, :184-201)
+// odtk_binding.cpp -- the reference's operator module (NVIDIA/retinanet-examples csrc/extensions.cpp:47-158, :184-201)
 // re-homed on the MI355X C ABI (include/odtk_hip.h, libodtk_hip.so): a compiled torch extension exporting
 //
 //     decode(cls_head, box_head, anchors, scale, score_thresh, top_n, rotated=False) -> [scores, boxes, classes]

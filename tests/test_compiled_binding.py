@@ -1,4 +1,4 @@
-"""The compiled operator module retinanet-examples_amd/odtk/_C_ext (csrc/extensions.cpp): the reference's pybind
+"""The compiled operator module retinanet-examples_amd/odtk/_C_ext (csrc/odtk_binding.cpp): the reference's pybind
 surface (csrc/extensions.cpp:184-201 -- decode, nms, iou, Engine) as a real torch extension over the C ABI, i.e. the
 code INTEGRATION.md section 2 asks a maintainer of the reference to write, compiled and exercised:
   * CPU: it imports, exports the reference's names with the reference's positional signatures, and refuses CPU /
