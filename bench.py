@@ -219,6 +219,10 @@ def main():
                     help='torch.backends.cudnn.benchmark = False (MIOpen immediate mode instead of find mode)')
     ap.add_argument('--rotated-bbox', action='store_true', help='BASELINE config 5: 27 anchors, 6 box parameters, '
                                                                 'rotated decode + polygon-IoU NMS')
+    ap.add_argument('--unit-rotation', action='store_true',
+                    help="with --rotated-bbox: bias the box head's (sin, cos) outputs to (0, 1) and the deltas to 0, as a trained rotated "
+                         "model emits them; the reference's random init puts the -4.6 class prior on all six outputs "
+                         "(model.py:121-122), i.e. 6.5x inflated, mutually overlapping quads")
     ap.add_argument('--no-fuse', action='store_true',
                     help='time the eager nn.Module graph under autocast (Model.fused_graph = False) instead of the '
                          'BN-folded engine Model.forward uses by default')
@@ -254,6 +258,11 @@ def main():
     torch.manual_seed(0)
     model = Model(backbones=args.backbone, classes=80, rotated_bbox=args.rotated_bbox)
     model.initialize(None)
+    if args.rotated_bbox and args.unit_rotation:
+        with torch.no_grad():
+            bias = model.box_head[-1].bias.view(model.num_anchors, 6)
+            bias.zero_()
+            bias[:, 5] = 1.0
     model = model.to(dev).to(memory_format=torch.channels_last).eval()
     model.fused_postprocess = args.postproc == 'fused'
     fuse_graph = not args.no_fuse and args.postproc == 'fused'
@@ -462,7 +471,8 @@ def main():
                     'are >= %.2f (SURVEY 8d sparse-realistic; logit sigma %.4f -> %.4f); %d detections in the last batch'
                     % (100 * args.fraction, model.threshold, sigma0, sigma1, n_det),
             'config': {'workload': '%s %s inference%s, bs=%d per GPU at %dx%d, HIP decode x5 + NMS'
-                                   % (args.backbone, args.dtype, ' --rotated-bbox' if args.rotated_bbox else '',
+                                   % (args.backbone, args.dtype, (' --rotated-bbox' + (' (unit (sin, cos) head bias)' if args.unit_rotation else ''))
+                                      if args.rotated_bbox else '',
                                       args.batch, args.height, args.width),
                        'global_batch': args.batch * world, 'image': [args.height, args.width],
                        'parallelism': 'replicas x%d (no data-path collective)' % world,
