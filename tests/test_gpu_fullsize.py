@@ -218,3 +218,56 @@ def test_full_size_rotated_vs_oracle():
         for k, name in ((0, 'scores'), (1, 'boxes'), (2, 'classes')):
             assert np.array_equal(det[k][b].view(np.uint32), ref_nms[k][0].view(np.uint32)), 'image %d: nms %s' % (b, name)
         assert int((ref_nms[0] > 0).sum()) > 20
+
+
+def test_config2_parity_subrun_on_captured_model_heads():
+    """SURVEY 8(d), config 2, literally: RN50FPN, bf16, channels_last, randn(8, 3, 800, 1280) -- capture the 10 head tensors
+    of the TIMED engine, feed the same fp32 post-sigmoid tensors to the oracle (CPU) and to the HIP op: indices bit-exact,
+    scores / classes bit-exact, boxes within tolerance; and the fused path the step actually runs (raw bf16 channels_last
+    logits, sigmoid and head bias inside the kernels) must produce the same bits as the strict op on those tensors."""
+    import bench
+    from odtk.model import Model
+    torch.manual_seed(0)
+    model = Model('ResNet50FPN', classes=80)
+    model.initialize(None)
+    model = model.cuda().to(memory_format=torch.channels_last).eval()
+    x = torch.randn(8, 3, 800, 1280, generator=torch.Generator().manual_seed(0)).cuda().contiguous(memory_format=torch.channels_last)
+    engine = lambda: model.inference_engine(torch.bfloat16)
+    bench.calibrate_cls_head(model, lambda t: engine().heads(t), x, bench.SPEC_FRACTION, model.threshold)
+    with torch.no_grad():
+        cls_heads, box_heads = engine().heads(x)                               # bf16 channels_last, bias applied
+        raw_cls, raw_box, cls_bias, box_bias = engine().heads_without_last_bias(x)
+    for s in STRIDES:
+        model.level_anchors(s)
+    thr, top_n = model.threshold, model.top_n
+    # what the reference's op receives (model.py:140,160; box.py:263): fp32 NCHW post-sigmoid scores, fp32 deltas
+    scores = [c.sigmoid().float().contiguous() for c in cls_heads]
+    deltas = [b.float().contiguous() for b in box_heads]
+    strict = _C.decode_levels(scores, deltas, [model.anchors[s] for s in STRIDES], STRIDES, thr, top_n, False, return_indices=True)
+    fused = _C.decode_levels(cls_heads, box_heads, [model.anchors[s] for s in STRIDES], STRIDES, thr, top_n, False,
+                             return_indices=True, logits=True)
+    for a, b in zip(strict, fused):
+        assert torch.equal(a, b)                                               # fused sigmoid / bf16 / NHWC == strict op
+    # the bias-folded form reads DIFFERENT tensors (conv output without bias; bias added in fp32 inside the kernel, one
+    # rounding less than the engine's bf16 bias pass), so it is compared with the strict op on ITS OWN materialised scores
+    fold_scores = [(r.float() + cls_bias.view(1, -1, 1, 1)).sigmoid().to(torch.bfloat16).float().contiguous() for r in raw_cls]
+    fold_deltas = [(r.float() + box_bias.view(1, -1, 1, 1)).contiguous() for r in raw_box]
+    strict_fold = _C.decode_levels(fold_scores, fold_deltas, [model.anchors[s] for s in STRIDES], STRIDES, thr, top_n, False,
+                                   return_indices=True)
+    folded = _C.decode_levels(raw_cls, raw_box, [model.anchors[s] for s in STRIDES], STRIDES, thr, top_n, False,
+                              return_indices=True, logits=True, cls_bias=cls_bias, box_bias=box_bias)
+    for a, b in zip(strict_fold, folded):
+        assert torch.equal(a, b)
+    det = box.detect(scores, deltas, STRIDES, model.anchors, thr, top_n, model.nms, model.detections)
+    strict = [t.cpu() for t in strict]
+    det = [t.cpu() for t in det]
+    for b in range(8):
+        per_level = [box_oracle.decode(s[b:b + 1].cpu(), d[b:b + 1].cpu(), st, thr, top_n, model.anchors[st], return_indices=True)
+                     for s, d, st in zip(scores, deltas, STRIDES)]
+        ref = [torch.cat(t, 1) for t in zip(*per_level)]
+        assert torch.equal(strict[3][b].long(), ref[3][0]) and torch.equal(strict[0][b], ref[0][0]) and torch.equal(strict[2][b], ref[2][0]), b
+        _boxes_close(strict[1][b], ref[1][0], 'image %d: boxes' % b)
+        ref_e2e = box_oracle.nms(ref[0], ref[1], ref[2], model.nms, model.detections)
+        assert torch.equal(det[0][b], ref_e2e[0][0]) and torch.equal(det[2][b], ref_e2e[2][0]), b
+        _boxes_close(det[1][b], ref_e2e[1][0], 'image %d: detections' % b)
+        assert int((det[0][b] > 0).sum()) == model.detections
