@@ -99,3 +99,28 @@ def test_config0_resnet18fpn_512_on_cpu():
     assert int((ref[0] > 0).sum()) > 20
     for got, want in zip((scores, boxes, classes), ref):
         assert torch.equal(got, want)
+
+
+def test_infer_driver_end_to_end_on_cpu():
+    """The inference driver (odtk/infer.py: Model.forward -> packed hand-off -> COCO records) with no GPU at all: config 0's
+    plumbing run, two batches of two 256x256 images."""
+    from odtk import infer as infer_mod
+    torch.manual_seed(1)
+    model = Model('ResNet18FPN', classes=12)
+    model.initialize(None)
+    model.eval()
+    with torch.no_grad():
+        model.cls_head[-1].weight.mul_(40.0)
+    g = torch.Generator().manual_seed(2)
+    batches = [(torch.randn(2, 3, 256, 256, generator=g), [10 + 2 * i, 11 + 2 * i], [0.5, 2.0]) for i in range(2)]
+    dets = infer_mod.infer(model, batches)
+    assert len(dets) > 20 and {d['image_id'] for d in dets} <= {10, 11, 12, 13}
+    with torch.no_grad():
+        scores, boxes, classes = model(batches[0][0].contiguous(memory_format=torch.channels_last))
+    first = [d for d in dets if d['image_id'] == 10]
+    n = int((scores[0] > 0).sum())
+    assert len(first) == n and n > 0
+    assert abs(first[0]['score'] - float(scores[0, 0])) < 1e-7 and first[0]['category_id'] == int(classes[0, 0])
+    x1, y1, x2, y2 = (boxes[0, 0] / 0.5).tolist()
+    assert np.allclose(first[0]['bbox'], [x1, y1, x2 - x1 + 1, y2 - y1 + 1], rtol=1e-6)
+    assert all(a['score'] >= b['score'] for a, b in zip(first, first[1:]))
