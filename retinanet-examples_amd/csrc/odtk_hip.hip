@@ -344,7 +344,8 @@ int nms_launch(const odtk::NmsArgs &na, int batch, size_t lds, hipStream_t strea
 }
 
 int nms_impl(int batch, const void *const *inputs, void *const *outputs, int n_outputs, size_t count,
-             int ndet, float thresh, uint32_t flags, void *workspace, size_t workspace_size, hipStream_t stream) {
+             int ndet, float thresh, uint32_t flags, void *workspace, size_t workspace_size, hipStream_t stream,
+             uint32_t sorted_run_len = 0) {
   if (batch <= 0 || count == 0 || count > ODTK_MAX_NMS_COUNT_SCRATCH || ndet <= 0 || ndet > ODTK_MAX_NMS_DETECTIONS)
     return ODTK_ERR_INVALID;
   // up to ODTK_MAX_NMS_COUNT candidates per image everything is LDS-resident and the kernel needs no global scratch
@@ -369,6 +370,7 @@ int nms_impl(int batch, const void *const *inputs, void *const *outputs, int n_o
   na.out_classes = static_cast<float *>(outputs[2]);
   na.out_indices = n_outputs > 3 ? static_cast<int32_t *>(outputs[3]) : nullptr;
   na.count = static_cast<uint32_t>(count);
+  na.run_len = sorted_run_len;
   na.ndet = ndet;
   na.thresh = thresh;
   na.flags = flags;
@@ -785,8 +787,9 @@ int odtk_detect(int batch_size, int n_levels, const odtk_level_t *levels, int nu
   int rc = decode_levels_impl(batch_size, n_levels, levels, num_anchors, num_classes, dtype, flags, score_thresh,
                               top_n, cat, 3, workspace, static_cast<size_t>(dec), static_cast<hipStream_t>(stream));
   if (rc != ODTK_OK) return rc;
+  // the candidates are decode_levels' own output: n_levels runs of top_n, each already in NMS order
   return nms_impl(batch_size, cat, outputs, 3, count, detections_per_im, nms_thresh, flags, ws + off_n,
-                  static_cast<size_t>(nms_ws), static_cast<hipStream_t>(stream));
+                  static_cast<size_t>(nms_ws), static_cast<hipStream_t>(stream), static_cast<uint32_t>(top_n));
 }
 
 }  // extern "C"
