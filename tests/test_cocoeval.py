@@ -1,0 +1,123 @@
+"""odtk/cocoeval.py (restatement of pycocotools' COCOeval, 'bbox'): hand-computed cases + the loop-by-loop
+restatement in oracle/cocoeval_loops.py on random data."""
+import io
+import random
+
+import numpy as np
+import pytest
+
+from odtk.cocoeval import COCOeval, box_iou
+from odtk.data import CocoIndex
+from oracle import cocoeval_loops
+
+
+def _gt(boxes, image_id=1, cat=1, crowd=(), first_id=1, areas=None):
+    return [{'id': first_id + k, 'image_id': image_id, 'category_id': cat, 'bbox': list(map(float, b)),
+             'area': float(b[2] * b[3]) if areas is None else areas[k], 'iscrowd': int(k in crowd)}
+            for k, b in enumerate(boxes)]
+
+
+def _dt(rows, image_id=1, cat=1):
+    return [{'image_id': image_id, 'category_id': cat, 'score': s, 'bbox': list(map(float, b))} for s, b in rows]
+
+
+def _stats(gt, dt, images=(1,), cats=(1,)):
+    index = CocoIndex(dataset={'images': [{'id': i} for i in images], 'annotations': gt,
+                               'categories': [{'id': c} for c in cats]})
+    ev = COCOeval(index, index.loadRes(dt), 'bbox')
+    ev.evaluate()
+    ev.accumulate()
+    text = io.StringIO()
+    stats = ev.summarize(out=lambda line: text.write(line + '\n'))
+    return stats, ev, text.getvalue()
+
+
+def test_perfect_detections():
+    gt = _gt([[0, 0, 10, 10], [50, 50, 40, 40]])
+    stats, _, text = _stats(gt, _dt([(0.9, [0, 0, 10, 10]), (0.8, [50, 50, 40, 40])]))
+    one = pytest.approx(1.0, abs=1e-12)                                       # tp / (tp + fp + eps)
+    assert stats[0] == one and stats[1] == one and stats[2] == one
+    assert stats[3] == one and stats[4] == one and stats[5] == -1.0          # small, medium; no large box
+    assert stats[6] == 0.5 and stats[7] == stats[8] == 1.0                    # AR@1 sees one of the two boxes
+    lines = text.splitlines()
+    assert lines[0] == ' Average Precision  (AP) @[ IoU=0.50:0.95 | area=   all | maxDets=100 ] = 1.000'
+    assert lines[6] == ' Average Recall     (AR) @[ IoU=0.50:0.95 | area=   all | maxDets=  1 ] = 0.500'
+    assert lines[1].startswith(' Average Precision  (AP) @[ IoU=0.50      | area=   all')
+
+
+def test_a_false_positive_ahead_of_two_hits_gives_two_thirds():
+    gt = _gt([[0, 0, 10, 10], [50, 50, 40, 40]])
+    dt = _dt([(0.9, [200, 200, 10, 10]), (0.8, [0, 0, 10, 10]), (0.7, [50, 50, 40, 40])])
+    stats, _, _ = _stats(gt, dt)
+    # TP 0,1,2 / FP 1,1,1 -> precision 0, 1/2, 2/3, envelope 2/3 at every recall level, every IoU threshold
+    assert stats[0] == pytest.approx(2 / 3, abs=1e-12) and stats[1] == pytest.approx(2 / 3, abs=1e-12)
+    assert stats[8] == 1.0 and stats[6] == 0.0                                # the top detection is the miss
+
+
+def test_iou_077_counts_at_six_of_ten_thresholds():
+    stats, _, _ = _stats(_gt([[0, 0, 10, 10]]), _dt([(0.9, [0, 0, 10, 7.7])]))
+    assert box_iou([[0, 0, 10, 7.7]], [[0, 0, 10, 10]], [False])[0, 0] == pytest.approx(0.77)
+    assert stats[0] == pytest.approx(0.6) and stats[1] == pytest.approx(1.0) and stats[2] == pytest.approx(1.0)
+    assert stats[3] == pytest.approx(0.6) and stats[4] == -1.0 and stats[5] == -1.0
+    assert stats[8] == pytest.approx(0.6)
+
+
+def test_crowd_box_absorbs_detections_without_penalty():
+    gt = _gt([[0, 0, 100, 100], [0, 0, 10, 10]], crowd=(0,))
+    dt = _dt([(0.9, [0, 0, 10, 10]), (0.8, [50, 50, 10, 10]), (0.7, [60, 60, 10, 10])])
+    stats, ev, _ = _stats(gt, dt)
+    assert stats[0] == pytest.approx(1.0) and stats[8] == 1.0
+    first = ev.evalImgs[0]
+    assert first['dtMatches'][0].tolist() == [2, 1, 1]                        # the crowd box is taken twice
+    assert first['dtIgnore'][0].tolist() == [False, True, True]
+    assert box_iou([[50, 50, 10, 10]], [[0, 0, 100, 100]], [True])[0, 0] == 1.0
+
+
+def test_equal_iou_goes_to_the_later_box_and_area_ranges_ignore_outsiders():
+    gt = _gt([[0, 0, 10, 10], [0, 0, 10, 10]])
+    _, ev, _ = _stats(gt, _dt([(0.9, [0, 0, 10, 10])]))
+    assert ev.evalImgs[0]['dtMatches'][:, 0].tolist() == [2] * 10
+    gt = _gt([[0, 0, 10, 10]])
+    stats, _, _ = _stats(gt, _dt([(0.9, [300, 300, 200, 200]), (0.8, [0, 0, 10, 10])]))
+    assert stats[0] == pytest.approx(0.5) and stats[3] == pytest.approx(1.0) and stats[5] == -1.0
+
+
+def test_no_detections_and_annotation_area_field():
+    stats, _, _ = _stats(_gt([[0, 0, 10, 10]]), [])
+    assert stats[0] == 0.0 and stats[8] == 0.0 and stats[4] == -1.0
+    gt = _gt([[0, 0, 10, 10]], areas=[5000.0])                                # the file's `area`, not w * h, picks the range
+    stats, _, _ = _stats(gt, _dt([(0.9, [0, 0, 10, 10])]))
+    assert stats[3] == -1.0 and stats[4] == pytest.approx(1.0)
+    with pytest.raises(NotImplementedError):
+        index = CocoIndex(dataset={'images': [], 'annotations': []})
+        COCOeval(index, index, 'segm')
+
+
+@pytest.mark.parametrize('seed', [0, 1, 2])
+def test_equals_the_loop_restatement_on_random_scenes(seed):
+    rng = random.Random(seed)
+    images, cats = [3, 5, 8, 13], [2, 9, 4]
+    gt, dt = [], []
+    for img in images:
+        for _ in range(rng.randint(0, 9)):
+            w, h = rng.choice([6, 20, 50, 120]), rng.choice([6, 20, 50, 120])
+            box = [rng.randint(0, 200), rng.randint(0, 200), w, h]
+            gt.append({'id': len(gt) + 1, 'image_id': img, 'category_id': rng.choice(cats), 'bbox': [float(v) for v in box],
+                       'area': float(w * h), 'iscrowd': int(rng.random() < 0.15)})
+            for _ in range(rng.randint(0, 3)):                                # detections near this box, sometimes exact copies
+                jitter = [rng.choice([0, 0, 1, -2, 5, 9]) for _ in range(4)]
+                cand = [float(box[0] + jitter[0]), float(box[1] + jitter[1]), float(max(1, w + jitter[2])), float(max(1, h + jitter[3]))]
+                dt.append({'image_id': img, 'category_id': gt[-1]['category_id'] if rng.random() < 0.8 else rng.choice(cats),
+                           'score': rng.choice([0.9, 0.8, 0.8, round(rng.random(), 2)]), 'bbox': cand})
+        for _ in range(rng.randint(0, 4)):                                    # strays
+            dt.append({'image_id': img, 'category_id': rng.choice(cats), 'score': round(rng.random(), 2),
+                       'bbox': [float(rng.randint(0, 300)), float(rng.randint(0, 300)), float(rng.randint(4, 150)), float(rng.randint(4, 150))]})
+    index = CocoIndex(dataset={'images': [{'id': i} for i in images], 'annotations': gt, 'categories': [{'id': c} for c in cats]})
+    res = index.loadRes(dt)
+    ev = COCOeval(index, res, 'bbox')
+    ev.evaluate()
+    ev.accumulate()
+    got = ev.summarize(out=lambda line: None)
+    want = cocoeval_loops.stats(gt, list(res.anns.values()), images, cats)
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-12)
+    assert 0 < got[0] < 1
