@@ -143,7 +143,7 @@ class CocoDataset(data.dataset.Dataset):
         self.rotate_augment = rotate_augment
         self.augment_brightness, self.augment_contrast = augment_brightness, augment_contrast
         self.augment_hue, self.augment_saturation = augment_hue, augment_saturation
-        self.coco = CocoIndex(annotations)
+        self.coco = CocoIndex(dataset=annotations) if isinstance(annotations, dict) else CocoIndex(annotations)
         self.ids = list(self.coco.imgs.keys())
         if 'categories' in self.coco.dataset:
             self.categories_inv = {k: i for i, k in enumerate(self.coco.getCatIds())}

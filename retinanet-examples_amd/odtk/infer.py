@@ -13,10 +13,14 @@ path takes 0.2 ms per batch that loop IS the wall time of `odtk infer`.  Here:
     `.tolist()` values, duplicate image ids (DistributedSampler padding) dropped after their first
     occurrence, zero-score padding rows dropped.
 
-Dataset reading, COCO evaluation and the CLI stay out of scope (SURVEY.md 8 / DESIGN.md 7): `infer` takes
-any iterable of (images, ids, ratios) batches.
+`infer_batches` takes any iterable of (images, ids, ratios) batches; `infer` is the reference's entry point
+(same positional arguments, infer.py:18-19): images under `path` (+ optional COCO annotations) through
+odtk/data.py, the loop above, then -- when annotations with ground truth were given -- AP / AR from
+odtk/cocoeval.py in place of pycocotools.
 """
 import json
+import os
+import time
 
 import numpy as np
 import torch
@@ -91,18 +95,22 @@ def detections_to_coco(scores, boxes, classes, ids, ratios, rotated_bbox=False, 
     return out
 
 
-def infer(model, batches, rotated_bbox=False, category_ids=None, detections_file=None, dataset=None):
+def infer_batches(model, batches, rotated_bbox=False, category_ids=None, detections_file=None, dataset=None,
+                  on_batch=None):
     """Run `model` (eval-mode Model or FusedRetinaNet) over `batches` = iterable of
     (images [B,3,H,W] on the model's device, ids [B], ratios [B]); gather every rank's detections with
     one collective; on rank 0 convert them and optionally write the reference's JSON document
     (`{'annotations': [...], 'images': ..., 'categories': ...}`, reference infer.py:150-158).
-    Returns the detection list on rank 0, None elsewhere."""
+    Returns the detection list on rank 0, None elsewhere.  `on_batch(i, forward_seconds)`: progress hook."""
     packed = []
     detections_per_image, nb = None, 6 if rotated_bbox else 4
     with torch.no_grad():
-        for images, ids, ratios in batches:
+        for i, (images, ids, ratios) in enumerate(batches):
             images = images.contiguous(memory_format=torch.channels_last)
+            started = time.time()
             scores, boxes, classes = model(images)
+            if on_batch is not None:
+                on_batch(i, time.time() - started)
             detections_per_image = scores.shape[1]
             ids = torch.as_tensor(ids, device=scores.device)
             ratios = torch.as_tensor(ratios, device=scores.device)
@@ -124,3 +132,93 @@ def infer(model, batches, rotated_bbox=False, category_ids=None, detections_file
             with open(path, 'w') as f:
                 json.dump(doc, f, indent=4)
     return detections
+
+
+def infer(model, path, detections_file, resize, max_size, batch_size, mixed_precision=True, is_master=True, world=0,
+          annotations=None, with_apex=False, use_dali=False, is_validation=False, verbose=True, rotated_bbox=False,
+          num_workers=2):
+    """Run inference on the images under `path` -- the reference's `infer.infer` (infer.py:18-177), same
+    arguments.  Returns `COCOeval.stats` (mAP first) when ground truth was given, None when nothing was
+    detected, 0 otherwise (and on the ranks other than the master), as the reference does.
+
+    `mixed_precision` on a GPU = bf16 autocast, which routes `Model.forward` to the bf16 engine (the reference
+    only implements it through apex O2, fp16).  `with_apex` / `use_dali` name dependencies the north star
+    drops: asking for them is an error, not a silent fallback."""
+    from .cocoeval import COCOeval
+    from .data import DataIterator, RotatedDataIterator
+    from .utils import Profiler
+    if use_dali or with_apex:
+        raise RuntimeError('DALI and apex are not part of this build (use the default loader / torch autocast)')
+    net = model.module if hasattr(model, 'module') else model
+    if not annotations:                                           # every file of the directory, ids by position
+        annotations = {'images': [{'id': i, 'file_name': f} for i, f in enumerate(sorted(os.listdir(path)))]}
+    if verbose:
+        print('Preparing dataset...')
+    iterator_class = RotatedDataIterator if rotated_bbox else DataIterator
+    device = torch.device('cuda', torch.cuda.current_device()) if torch.cuda.is_available() else torch.device('cpu')
+    data_iterator = iterator_class(path, resize, max_size, batch_size, net.stride, max(world, 1), annotations,
+                                   training=False, device=device, num_workers=num_workers)
+    if verbose:
+        print(data_iterator)
+    if not is_validation and device.type == 'cuda':
+        model = model.to(memory_format=torch.channels_last).cuda()
+    was_training = net.training
+    model.eval()
+    if verbose:
+        print('   backend: pytorch')
+        print('    device: {} {}'.format(world, 'cpu' if device.type == 'cpu' else 'GPU' if world == 1 else 'GPUs'))
+        print('     batch: {}, precision: {}'.format(batch_size, 'mixed' if mixed_precision else 'full'))
+        print(' BBOX type:', 'rotated' if rotated_bbox else 'axis aligned')
+        print('Running inference...')
+
+    profiler = Profiler(['infer', 'fw'])
+    size, batches = len(data_iterator.ids), len(data_iterator)
+
+    def progress(i, forward_seconds):
+        profiler.totals['fw'] += forward_seconds
+        profiler.counts['fw'] += 1
+        profiler.means['fw'] = profiler.totals['fw'] / profiler.counts['fw']
+        profiler.bump('infer')
+        if verbose and (profiler.totals['infer'] > 60 or i == batches - 1):
+            print('[{:{len}}/{}] {:.3f}s/{}-batch (fw: {:.3f}s), {:.1f} im/s'.format(
+                min((i + 1) * batch_size, size), size, profiler.means['infer'], batch_size, profiler.means['fw'],
+                batch_size / profiler.means['infer'], len=len(str(size))), flush=True)
+            profiler.reset()
+
+    has_truth = 'annotations' in data_iterator.coco.dataset
+    amp = mixed_precision and device.type == 'cuda'
+    with torch.autocast(device.type, dtype=torch.bfloat16, enabled=amp):
+        detections = infer_batches(model, data_iterator, rotated_bbox=rotated_bbox,
+                                   category_ids=data_iterator.coco.getCatIds() if has_truth else None,
+                                   on_batch=progress)
+    if verbose:
+        print('Gathering results...')
+    if was_training:
+        model.train()
+    if not is_master:
+        return 0
+    if not detections:
+        print('No detections!')
+        return None
+    doc = {'annotations': detections, 'images': data_iterator.coco.dataset['images']}
+    if 'categories' in data_iterator.coco.dataset:
+        doc['categories'] = data_iterator.coco.dataset['categories']
+    if detections_file:
+        if verbose:
+            print('Writing {}...'.format(detections_file))
+        for name in ([detections_file] if isinstance(detections_file, str) else detections_file):
+            with open(name, 'w') as f:
+                json.dump(doc, f, indent=4)
+    if has_truth:
+        if rotated_bbox:
+            if verbose:
+                print('Rotated boxes: the polygon-mask evaluation of the reference (pycocotools segm) is not provided.')
+            return 0
+        if verbose:
+            print('Evaluating model...')
+        evaluation = COCOeval(data_iterator.coco, data_iterator.coco.loadRes(detections), 'bbox')
+        evaluation.evaluate()
+        evaluation.accumulate()
+        evaluation.summarize(out=print if verbose else (lambda line: None))
+        return evaluation.stats                                   # mAP and mAR
+    return 0

@@ -26,6 +26,7 @@ from torch.optim import SGD
 from torch.optim.lr_scheduler import LambdaLR
 
 from .backbones.layers import convert_fixedbn_model
+from .utils import ignore_sigint, post_metrics
 
 
 class SyntheticBatches:
@@ -62,14 +63,14 @@ class SyntheticBatches:
 def lr_schedule(warmup, milestones, gamma):
     """reference train.py:52-56: linear warm-up from 0.1x, then gamma per passed milestone."""
     def schedule(step):
-        if step < warmup:
+        if warmup and step <= warmup:
             return 0.9 * step / warmup + 0.1
         return gamma ** len([m for m in milestones if m <= step])
     return schedule
 
 
 def prepare(model, device, lr=0.01, world=1, rank=0, warmup=1000, milestones=(), gamma=0.1, state=None,
-            bucket_cap_mb=25):
+            bucket_cap_mb=25, weight_decay=0.0001):
     """Frozen-BN conversion, channels_last, optimizer, DDP wrapper, LR schedule (reference train.py:29-59)."""
     model = convert_fixedbn_model(model)
     model = model.to(device)
@@ -78,7 +79,7 @@ def prepare(model, device, lr=0.01, world=1, rank=0, warmup=1000, milestones=(),
     model.freeze_unused_params()
     # every parameter, frozen ones included, exactly like the reference (train.py:34): the param-group layout is
     # part of the checkpoint format (optimizer.load_state_dict), and SGD skips parameters without a gradient
-    optimizer = SGD(model.parameters(), lr=lr, weight_decay=0.0001, momentum=0.9)
+    optimizer = SGD(model.parameters(), lr=lr, weight_decay=weight_decay, momentum=0.9)
     net = model
     if world > 1:
         net = DistributedDataParallel(model, device_ids=[device.index] if device.type == 'cuda' else None,
@@ -125,9 +126,14 @@ def reduce_losses(cls_loss, box_loss, world, extra=None):
     return both
 
 
-def train(model, state, batches, iterations, device, lr=0.01, warmup=1000, milestones=(), gamma=0.1, world=1,
-          rank=0, mixed_precision=True, log_every=60.0, save_path=None, verbose=True, log_interval=None):
-    """The training loop of reference train.py:18-214 minus apex / DALI / TensorBoard.
+def train_batches(model, state, batches, iterations, device, lr=0.01, warmup=1000, milestones=(), gamma=0.1, world=1,
+                  rank=0, mixed_precision=True, log_every=60.0, save_path=None, verbose=True, log_interval=None,
+                  weight_decay=0.0001, validate=None, val_iterations=None, on_report=None):
+    """The training loop of reference train.py:18-214 over any source of (images, targets) batches.
+
+    `validate(net, iteration)` is called on EVERY rank (it gathers detections) after iteration `iterations` and after every
+    `val_iterations`-th one (reference train.py:185); `on_report(iteration, focal, box, seconds_per_step, lr)` on
+    rank 0 at each logging step (metrics / scalar logs).
 
     Logging / checkpoint cadence.  The reference all-reduces both losses and tests them on the host EVERY
     step (train.py:126-138: two collectives + one host sync per iteration).  Here the losses are summed on
@@ -137,7 +143,8 @@ def train(model, state, batches, iterations, device, lr=0.01, warmup=1000, miles
     where `interval` starts at `log_interval` (default 10) and is re-derived at each logging step from
     RANK 0's measured step time (target: one report per `log_every` seconds) and handed to every rank
     inside the loss all-reduce itself."""
-    model, net, optimizer, scheduler = prepare(model, device, lr, world, rank, warmup, milestones, gamma, state)
+    model, net, optimizer, scheduler = prepare(model, device, lr, world, rank, warmup, milestones, gamma, state,
+                                              weight_decay=weight_decay)
     amp_dtype = torch.float16 if (mixed_precision and device.type == 'cuda') else None
     scaler = torch.amp.GradScaler('cuda', enabled=amp_dtype is not None) if amp_dtype is not None else None
     iteration = state.get('iteration', 0) if state else 0
@@ -158,11 +165,14 @@ def train(model, state, batches, iterations, device, lr=0.01, warmup=1000, miles
             raise RuntimeError('Loss is diverging!\nTry lowering the learning rate.')
         if rank == 0 and verbose:
             print('[{:{w}}/{}] focal loss: {:.3f}, box loss: {:.3f}, {:.3f}s/{}-batch, {:.1f} im/s, lr: {:.2g}'.format(
-                iteration, iterations, cls_mean, box_mean, per_step, seen // max(n_mark, 1), seen / max(now - t_mark, 1e-9),
+                iteration, iterations, cls_mean, box_mean, per_step, int(round(seen / max(n_mark, 1))), seen / max(now - t_mark, 1e-9),
                 scheduler.get_last_lr()[0], w=len(str(iterations))), flush=True)
+        if rank == 0 and on_report is not None:
+            on_report(iteration, cls_mean, box_mean, per_step, scheduler.get_last_lr()[0])
         if rank == 0 and save_path:
-            model.save({'path': save_path, 'iteration': iteration, 'optimizer': optimizer.state_dict(),
-                        'scheduler': scheduler.state_dict()})
+            with ignore_sigint():
+                model.save({'path': save_path, 'iteration': iteration, 'optimizer': optimizer.state_dict(),
+                            'scheduler': scheduler.state_dict()})
         interval = max(1, int(round(agreed)))
         next_log = iteration + interval
         t_mark, n_mark, cls_sum, box_sum = time.time(), 0, None, None
@@ -185,8 +195,108 @@ def train(model, state, batches, iterations, device, lr=0.01, warmup=1000, miles
             if iteration >= next_log or iteration == iterations:
                 report()
                 seen = 0
+            if validate is not None and (iteration == iterations or (val_iterations and iteration % val_iterations == 0)):
+                validate(net, iteration)
+                net.train()
+                t_mark = time.time() if n_mark == 0 else t_mark     # validation time is not step time
         if not progressed:                                           # empty data source: nothing will ever change
             break
     if n_mark:                                                       # the source ran dry between two reports
         report()
     return iteration
+
+
+class ScalarLog:
+    """`logdir` of the reference is a TensorBoard directory (train.py:81-86); tensorboard is not installed here,
+    so scalars go through `SummaryWriter` when it imports and into `<logdir>/scalars.jsonl` otherwise."""
+
+    def __init__(self, logdir):
+        import json
+        import os
+        os.makedirs(logdir, exist_ok=True)
+        self._json, self.writer, self.file = json, None, None
+        try:
+            from torch.utils.tensorboard import SummaryWriter
+            self.writer = SummaryWriter(log_dir=logdir)
+        except Exception:                                           # noqa: BLE001 -- any import failure
+            self.file = open(os.path.join(logdir, 'scalars.jsonl'), 'a')
+
+    def add_scalar(self, tag, value, iteration):
+        if self.writer is not None:
+            self.writer.add_scalar(tag, value, iteration)
+        else:
+            self.file.write(self._json.dumps({'tag': tag, 'value': float(value), 'iteration': int(iteration)}) + '\n')
+            self.file.flush()
+
+    def close(self):
+        (self.writer or self.file).close()
+
+
+VALIDATION_TAGS = ['Validation_Precision/mAP', 'Validation_Precision/mAP@0.50IoU', 'Validation_Precision/mAP@0.75IoU',
+                   'Validation_Precision/mAP (small)', 'Validation_Precision/mAP (medium)', 'Validation_Precision/mAP (large)',
+                   'Validation_Recall/mAR (max 1 Dets)', 'Validation_Recall/mAR (max 10 Dets)',
+                   'Validation_Recall/mAR (max 100 Dets)', 'Validation_Recall/mAR (small)', 'Validation_Recall/mAR (medium)',
+                   'Validation_Recall/mAR (large)']
+
+
+def train(model, state, path, annotations, val_path, val_annotations, resize, max_size, jitter, batch_size, iterations,
+          val_iterations, lr, warmup, milestones, gamma, rank=0, world=1, mixed_precision=True, with_apex=False,
+          use_dali=False, verbose=True, metrics_url=None, logdir=None, rotate_augment=False, augment_brightness=0.0,
+          augment_contrast=0.0, augment_hue=0.0, augment_saturation=0.0, regularization_l2=0.0001, rotated_bbox=False,
+          absolute_angle=False, num_workers=2, device=None):
+    """Train `model` on the images under `path` -- the reference's `train.train` (train.py:18-214), same
+    arguments: COCO-style annotations through odtk/data.py (`jitter` = the range of short-side sizes),
+    `train_batches` above, periodic validation through `infer.infer`, checkpoints to `state['path']`, scalars
+    to `logdir`, metrics to `metrics_url`.  `with_apex` / `use_dali` are errors (dropped dependencies)."""
+    from . import infer as infer_module
+    from .data import DataIterator, RotatedDataIterator
+    if use_dali or with_apex:
+        raise RuntimeError('DALI and apex are not part of this build (use the default loader / torch autocast)')
+    if device is None:
+        device = torch.device('cuda', torch.cuda.current_device()) if torch.cuda.is_available() else torch.device('cpu')
+    if verbose:
+        print('Preparing dataset...')
+    extra = {'absolute_angle': absolute_angle} if rotated_bbox else {}
+    data_iterator = (RotatedDataIterator if rotated_bbox else DataIterator)(
+        path, jitter, max_size, batch_size, model.stride, world, annotations, training=True,
+        rotate_augment=rotate_augment, augment_brightness=augment_brightness, augment_contrast=augment_contrast,
+        augment_hue=augment_hue, augment_saturation=augment_saturation, device=device, num_workers=num_workers, **extra)
+    if verbose:
+        print(data_iterator)
+        print('    device: {} {}'.format(world, 'cpu' if device.type == 'cpu' else 'GPU' if world == 1 else 'GPUs'))
+        print('     batch: {}, precision: {}'.format(batch_size, 'mixed' if mixed_precision else 'full'))
+        print(' BBOX type:', 'rotated' if rotated_bbox else 'axis aligned')
+        print('Training model for {} iterations...'.format(iterations))
+    is_master = rank == 0
+    log = ScalarLog(logdir) if (is_master and logdir is not None) else None
+    if log is not None and verbose:
+        print('Writing logs to: {}'.format(logdir))
+    def on_report(iteration, focal, box, per_step, learning_rate):
+        if log is not None:
+            log.add_scalar('focal_loss', focal, iteration)
+            log.add_scalar('box_loss', box, iteration)
+            log.add_scalar('learning_rate', learning_rate, iteration)
+        if metrics_url:
+            post_metrics(metrics_url, {'focal loss': focal, 'box loss': box, 'im_s': batch_size / max(per_step, 1e-9),
+                                       'lr': learning_rate})
+
+    def validate(net, iteration):
+        stats = infer_module.infer(net, val_path, None, resize, max_size, batch_size, annotations=val_annotations,
+                                   mixed_precision=mixed_precision, is_master=is_master, world=world,
+                                   is_validation=True, verbose=False, rotated_bbox=rotated_bbox, num_workers=num_workers)
+        validate.last = stats
+        if log is not None and stats is not None and not isinstance(stats, int):
+            for tag, value in zip(VALIDATION_TAGS, stats):
+                log.add_scalar(tag, value, iteration)
+
+    validate.last = None
+    try:
+        done = train_batches(model, state or {}, data_iterator, iterations, device, lr=lr, warmup=warmup,
+                             milestones=milestones, gamma=gamma, world=world, rank=rank, mixed_precision=mixed_precision,
+                             save_path=(state or {}).get('path'), verbose=verbose, weight_decay=regularization_l2,
+                             validate=validate if val_annotations else None, val_iterations=val_iterations,
+                             on_report=on_report)
+    finally:
+        if log is not None:
+            log.close()
+    return done, validate.last

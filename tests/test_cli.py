@@ -1,0 +1,151 @@
+"""The `odtk` command line on the CPU (BASELINE.json configs[0] plumbing, through the reference's entry point):
+train -> checkpoint -> resume -> infer -> detections JSON + AP, on the committed five-image data set."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from odtk import main as cli
+from odtk.model import Model
+
+DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'data')
+ANN = os.path.join(DATA, 'annotations.json')
+
+
+@pytest.fixture(autouse=True)
+def _few_threads():
+    before = torch.get_num_threads()
+    torch.set_num_threads(4)
+    yield
+    torch.set_num_threads(before)
+
+
+def test_parser_defaults_are_the_reference_ones():
+    a = cli.parse(['train', 'm.pth', '--annotations', 'a.json'])
+    assert (a.backbone, a.classes, a.resize, a.max_size, a.jitter) == (['ResNet50FPN'], 80, 800, 1333, [640, 1024])
+    assert (a.iters, a.milestones, a.lr, a.warmup, a.gamma, a.val_iters) == (90000, [60000, 80000], 0.01, 1000, 0.1, 8000)
+    assert (a.augment_brightness, a.augment_hue, a.regularization_l2, a.anchor_ious) == (0.002, 0.0002, 0.0001, [0.4, 0.5])
+    assert a.master == '127.0.0.1:29500' and not a.full_precision and not a.rotated_bbox
+    b = cli.parse(['infer', 'm.pth'])
+    assert (b.output, b.resize, b.max_size, b.annotations) == (['detections.json'], 800, 1333, None)
+    c = cli.parse(['export', 'm.pth', 'm.plan'])
+    assert c.size == [1280] and c.dynamic_batch_opts == [1, 8, 16]
+
+
+def test_train_resume_infer_round_trip(tmp_path, capsys):
+    model_path = str(tmp_path / 'tiny.pth')
+    logdir = str(tmp_path / 'logs')
+    common = ['--annotations', ANN, '--images', DATA, '--backbone', 'ResNet18FPN', '--classes', '3', '--batch', '2',
+              '--resize', '128', '--max-size', '160', '--jitter', '96', '128', '--warmup', '2', '--lr', '0.001',
+              '--full-precision', '--workers', '0', '--val-annotations', ANN, '--val-iters', '2', '--logdir', logdir]
+    done, _ = cli.main(['train', model_path, '--iters', '3'] + common)
+    assert done == 3 and os.path.isfile(model_path)
+    out = capsys.readouterr().out
+    assert 'Initializing model...' in out and 'Training model for 3 iterations...' in out and '[3/3] focal loss:' in out
+    _, state = Model.load(model_path)
+    assert state['iteration'] == 3 and 'optimizer' in state and 'scheduler' in state
+    scalars = [json.loads(line) for line in open(os.path.join(logdir, 'scalars.jsonl'))]
+    assert {'focal_loss', 'box_loss', 'learning_rate'} <= {s['tag'] for s in scalars}
+
+    done, _ = cli.main(['train', model_path, '--iters', '5'] + common)           # resumes at 3
+    out = capsys.readouterr().out
+    assert done == 5 and 'Loading model from tiny.pth...' in out and '[5/5] focal loss:' in out
+    assert Model.load(model_path)[1]['iteration'] == 5
+
+    # a network whose class prior is lifted so that detections exist (random weights score 0.01 < 0.05)
+    model, _ = Model.load(model_path)
+    with torch.no_grad():
+        model.cls_head[-1].bias.fill_(0.0)
+    lifted = str(tmp_path / 'lifted.pth')
+    model.save({'path': lifted})
+    outputs = [str(tmp_path / 'd1.json'), str(tmp_path / 'd2.json')]
+    stats = cli.main(['infer', lifted, '--images', DATA, '--annotations', ANN, '--output'] + outputs +
+                     ['--batch', '2', '--resize', '128', '--max-size', '160', '--workers', '0', '--full-precision'])
+    out = capsys.readouterr().out
+    assert 'Running inference...' in out and 'Evaluating model...' in out and 'Average Precision  (AP) @[ IoU=0.50:0.95' in out
+    assert isinstance(stats, np.ndarray) and stats.shape == (12,) and -1 <= stats[0] <= 1
+    doc = json.load(open(outputs[0]))
+    assert doc == json.load(open(outputs[1]))
+    assert set(doc) == {'annotations', 'images', 'categories'} and len(doc['images']) == 5
+    det = doc['annotations'][0]
+    assert set(det) == {'image_id', 'score', 'category_id', 'bbox'} and det['category_id'] in (7, 3, 11)
+    assert len(det['bbox']) == 4 and det['image_id'] in (100, 103, 106, 109, 112)
+    per_image = {}
+    for d in doc['annotations']:
+        per_image[d['image_id']] = per_image.get(d['image_id'], 0) + 1
+    assert max(per_image.values()) <= 100
+
+    # without annotations: every file of the directory, ids by position, no evaluation
+    images_only = tmp_path / 'images'
+    images_only.mkdir()
+    for name in ('im0.png', 'im3.png'):
+        (images_only / name).write_bytes(open(os.path.join(DATA, name), 'rb').read())
+    result = cli.main(['infer', lifted, '--images', str(images_only), '--output', str(tmp_path / 'plain.json'),
+                       '--batch', '2', '--resize', '128', '--max-size', '160', '--workers', '0', '--full-precision'])
+    assert result == 0
+    plain = json.load(open(tmp_path / 'plain.json'))
+    assert [im['file_name'] for im in plain['images']] == ['im0.png', 'im3.png'] and 'categories' not in plain
+    assert {d['image_id'] for d in plain['annotations']} <= {0, 1}
+    assert {d['category_id'] for d in plain['annotations']} <= {0, 1, 2}           # class indices: no category table
+
+
+def test_dropped_paths_are_refused_loudly(tmp_path):
+    with pytest.raises(RuntimeError, match='does not exist'):
+        cli.main(['infer', str(tmp_path / 'missing.pth')])
+    plan = tmp_path / 'model.plan'
+    plan.write_bytes(b'')
+    with pytest.raises(RuntimeError, match='TensorRT engines are not supported'):
+        cli.main(['infer', str(plan)])
+    bad = tmp_path / 'model.bin'
+    bad.write_bytes(b'')
+    with pytest.raises(RuntimeError, match='Invalid model format'):
+        cli.main(['infer', str(bad)])
+    model = Model('ResNet18FPN', classes=2)
+    model.initialize(None)
+    path = str(tmp_path / 'm.pth')
+    model.save({'path': path})
+    with pytest.raises(NotImplementedError, match='TensorRT'):
+        cli.main(['export', path, str(tmp_path / 'm.plan')])
+    with pytest.raises(RuntimeError, match='DALI and apex'):
+        cli.main(['infer', path, '--images', DATA, '--with-dali', '--workers', '0'])
+    with pytest.raises(RuntimeError, match='DALI and apex'):
+        cli.main(['train', str(tmp_path / 'n.pth'), '--annotations', ANN, '--images', DATA, '--backbone', 'ResNet18FPN',
+                  '--with-apex', '--workers', '0'])
+
+
+def test_two_cpu_ranks_launched_like_torchrun_agree_with_one(tmp_path):
+    """`python -m odtk.main infer` as two gloo ranks (RANK / WORLD_SIZE in the environment): the data set is sharded
+    by DistributedSampler, the detections gathered with one collective, the sampler's padding duplicates dropped --
+    rank 0 writes the same document a single process does (one image per step in both runs: the padded canvas of
+    a batch is part of the network's input)."""
+    import subprocess
+    import sys
+    model = Model('ResNet18FPN', classes=3)
+    model.initialize(None)
+    with torch.no_grad():
+        model.cls_head[-1].bias.fill_(0.0)
+    path = str(tmp_path / 'm.pth')
+    model.save({'path': path})
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    base = [sys.executable, '-W', 'ignore', '-m', 'odtk.main', 'infer', path, '--images', DATA, '--annotations', ANN,
+            '--resize', '128', '--max-size', '160', '--workers', '0', '--full-precision']
+    env = dict(os.environ, PYTHONPATH=os.path.join(root, 'retinanet-examples_amd'), OMP_NUM_THREADS='2')
+    env.pop('RANK', None), env.pop('WORLD_SIZE', None)
+    single = str(tmp_path / 'single.json')
+    subprocess.run(base + ['--batch', '1', '--output', single], env=env, check=True, timeout=300, capture_output=True)
+    port = 29500 + os.getpid() % 2000
+    procs = []
+    for rank in range(2):
+        rank_env = dict(env, RANK=str(rank), WORLD_SIZE='2', LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        procs.append(subprocess.Popen(base + ['--batch', '2', '--output', str(tmp_path / ('rank%d.json' % rank))], env=rank_env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert 'Average Precision' in outs[0] and 'Average Precision' not in outs[1]
+    assert not os.path.exists(tmp_path / 'rank1.json')
+    one, two = json.load(open(single)), json.load(open(tmp_path / 'rank0.json'))
+    key = lambda d: (d['image_id'], -d['score'], d['category_id'], tuple(d['bbox']))
+    assert sorted(one['annotations'], key=key) == sorted(two['annotations'], key=key)
+    assert len(one['annotations']) > 0 and one['images'] == two['images']

@@ -113,7 +113,7 @@ def test_infer_driver_end_to_end_on_cpu():
         model.cls_head[-1].weight.mul_(40.0)
     g = torch.Generator().manual_seed(2)
     batches = [(torch.randn(2, 3, 256, 256, generator=g), [10 + 2 * i, 11 + 2 * i], [0.5, 2.0]) for i in range(2)]
-    dets = infer_mod.infer(model, batches)
+    dets = infer_mod.infer_batches(model, batches)
     assert len(dets) > 20 and {d['image_id'] for d in dets} <= {10, 11, 12, 13}
     with torch.no_grad():
         scores, boxes, classes = model(batches[0][0].contiguous(memory_format=torch.channels_last))

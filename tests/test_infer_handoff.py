@@ -113,7 +113,7 @@ def test_infer_driver_writes_the_reference_document(tmp_path):
     batches = [(torch.full((2, 3, 8, 8), 0.1 * k), torch.tensor([10 * k, 10 * k + 1]), torch.tensor([1.0, 2.0])) for k in range(3)]
     out = tmp_path / 'det.json'
     dataset = {'images': [{'id': 0}], 'categories': [{'id': 3}]}
-    dets = infer.infer(_StubModel(5), batches, detections_file=str(out), dataset=dataset)
+    dets = infer.infer_batches(_StubModel(5), batches, detections_file=str(out), dataset=dataset)
     assert len(dets) == 6 * 4                           # 6 images x (5 - 1 zero-score row)
     doc = json.load(open(out))
     assert doc['annotations'] == dets and doc['images'] == dataset['images'] and doc['categories'] == dataset['categories']

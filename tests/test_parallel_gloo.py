@@ -103,7 +103,7 @@ def _infer_worker(rank, world, port, q):
     parallel.init_from_env('gloo')
     # rank r owns images 100*r + {0, 1, 2, 3} in two batches of two
     batches = [(torch.zeros(2, 3, 4, 4), torch.tensor([100 * rank + 2 * k, 100 * rank + 2 * k + 1]), torch.ones(2)) for k in range(2)]
-    dets = infer.infer(_Stub(rank), batches)
+    dets = infer.infer_batches(_Stub(rank), batches)
     q.put((rank, None if dets is None else [(d['image_id'], d['category_id'], d['bbox'][2]) for d in dets]))
     dist.destroy_process_group()
 

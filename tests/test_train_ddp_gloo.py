@@ -130,7 +130,7 @@ def _train_worker(rank, world, port, q, tmp):
     source = _SlowFiniteSource(rank, world)
     path = os.path.join(tmp, 'ckpt.pth')
     # log_every far below one step: a per-rank clock would fire on different iterations on the two ranks
-    done = T.train(model, {}, source, 8, torch.device('cpu'), lr=0.001, warmup=4, world=world, rank=rank,
+    done = T.train_batches(model, {}, source, 8, torch.device('cpu'), lr=0.001, warmup=4, world=world, rank=rank,
                    mixed_precision=False, log_every=0.01, save_path=path, verbose=False)
     flat = torch.cat([p.detach().flatten() for p in model.parameters()])
     gathered = [torch.empty_like(flat) for _ in range(world)]
