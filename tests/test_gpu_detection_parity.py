@@ -151,6 +151,24 @@ def candidate_paths(model, x):
     return out
 
 
+def coco_ap(truth, dets):
+    """COCO AP (IoU 0.50:0.95, odtk/cocoeval.py) of `dets` against `truth`, both (scores, boxes, classes) triples
+    of [B, D(, 4)] tensors; one COCO image per batch entry, ground truth = the entries of `truth` with score > 0."""
+    from odtk.cocoeval import COCOeval
+    from odtk.data import CocoIndex
+    from odtk.infer import detections_to_coco
+    batch = truth[0].shape[0]
+    ids, ones = torch.arange(batch), torch.ones(batch)
+    as_coco = lambda t: detections_to_coco(t[0].float().cpu(), t[1].float().cpu(), t[2].float().cpu(), ids, ones)
+    gt = [dict(d, id=k + 1, area=d['bbox'][2] * d['bbox'][3], iscrowd=0) for k, d in enumerate(as_coco(truth))]
+    index = CocoIndex(dataset={'images': [{'id': i} for i in range(batch)], 'annotations': gt,
+                               'categories': [{'id': c} for c in sorted({d['category_id'] for d in gt})]})
+    ev = COCOeval(index, index.loadRes(as_coco(dets)), 'bbox')
+    ev.evaluate()
+    ev.accumulate()
+    return float(ev.summarize(out=lambda line: None)[0])
+
+
 # |delta score| bounds per path, measured on MI355X with tools/detection_parity_probe.py (r02: engine_fp32 1.0e-5,
 # engine_bf16 0.049, eager autocast 0.26) and rounded up
 MARGIN = {'engine_fp32': 2e-4, 'engine_bf16': 0.08, 'eager_autocast_bf16': 0.3}
@@ -188,3 +206,14 @@ def test_engines_agree_with_fp32_eager_plus_oracle():
     wide = agreement(ref, paths['eager_autocast_bf16'], MARGIN['eager_autocast_bf16'], min_iou=0.5)
     assert same['matched'] < 0.5 * same['eligible'], same
     assert wide['matched'] >= 0.98 * wide['eligible'] and wide['max_dscore'] > MARGIN['engine_bf16'], wide
+
+    # the acceptance metric itself (COCO AP, odtk/cocoeval.py) with the planted objects as ground truth = the reference
+    # pipeline's detections scoring >= 0.15: every path is scored against the same truth, the reference pipeline included
+    # (its own low-score detections are its false positives)
+    planted = ref[0] >= 0.15
+    truth = (ref[0] * planted, ref[1] * planted[..., None], ref[2] * planted)
+    ap = {name: coco_ap(truth, dets) for name, dets in [('reference', ref)] + list(paths.items())}
+    print('COCO AP against the planted objects:', {k: round(v, 4) for k, v in ap.items()})
+    assert ap['reference'] > 0.5, ap
+    assert abs(ap['engine_fp32'] - ap['reference']) <= 2e-3, ap          # the same detector
+    assert abs(ap['engine_bf16'] - ap['reference']) <= 0.15, ap          # bf16 arithmetic: reported, loosely bounded

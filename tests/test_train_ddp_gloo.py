@@ -176,7 +176,8 @@ def _trajectory_worker(rank, world, port, q, steps, every_level):
     for s in range(steps):
         c, b = T.train_step(net, opt, sched, None, data[s][rank:rank + 1], target[s][rank:rank + 1])
         losses.append(T.reduce_losses(c, b, world).tolist())
-    q.put((rank, losses, torch.cat([p.detach().flatten() for p in model.parameters()])))
+    # numpy, not a tensor: a tensor travels as a file descriptor the parent must fetch while this process is alive
+    q.put((rank, losses, torch.cat([p.detach().flatten() for p in model.parameters()]).numpy()))
     dist.destroy_process_group()
 
 
@@ -256,4 +257,4 @@ def test_two_ranks_reproduce_one_rank_trajectory(every_level):
         for g_, w_ in zip(got, want):
             assert abs(g_ - w_) <= 1e-4 * max(1.0, abs(w_)), (res[0][1], single)     # fp32 noise of different conv batch shapes
     scale = single_params.abs().max().item()
-    assert (res[0][2] - single_params).abs().max().item() <= 1e-4 * scale
+    assert (torch.from_numpy(res[0][2]) - single_params).abs().max().item() <= 1e-4 * scale
