@@ -10,8 +10,10 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <atomic>
 #include <cstring>
 #include <mutex>
+#include <utility>
 #include <vector>
 
 #include "../../include/odtk_hip.h"
@@ -44,7 +46,7 @@ int hip_fail(hipError_t e, const char *what) {
 struct EventPair { hipEvent_t start, stop; };
 struct Profiler {
   std::mutex mu;
-  unsigned on = 0;   // bit k set: kernel id k is timed
+  std::atomic<unsigned> on{0};   // bit k set: kernel id k is timed (read on every launch without the lock)
   std::vector<EventPair> pending[ODTK_KERNEL_COUNT];
   std::vector<EventPair> spare;
 };
@@ -54,9 +56,9 @@ constexpr size_t kMaxPendingEvents = 1 << 16;
 struct KernelTimer {   // RAII: records start now and stop at scope exit, on `stream`
   int id; hipStream_t stream; EventPair ev; bool active = false;
   KernelTimer(int id_, hipStream_t s) : id(id_), stream(s) {
-    if (!((g_prof.on >> id) & 1u)) return;
+    if (!((g_prof.on.load(std::memory_order_relaxed) >> id) & 1u)) return;
     std::lock_guard<std::mutex> lock(g_prof.mu);
-    if (!((g_prof.on >> id) & 1u) || g_prof.pending[id].size() >= kMaxPendingEvents) return;
+    if (!((g_prof.on.load(std::memory_order_relaxed) >> id) & 1u) || g_prof.pending[id].size() >= kMaxPendingEvents) return;
     if (!g_prof.spare.empty()) { ev = g_prof.spare.back(); g_prof.spare.pop_back(); }
     else if (hipEventCreate(&ev.start) != hipSuccess || hipEventCreate(&ev.stop) != hipSuccess) return;
     active = hipEventRecord(ev.start, stream) == hipSuccess;
@@ -75,7 +77,7 @@ struct KernelTimer {   // RAII: records start now and stop at scope exit, on `st
 // dispatch latency on both sides (measured: 57.9 vs 52.8 us for the same prefilter launches).
 template <typename K, typename... Args>
 void timed_launch(int id, K kernel, dim3 grid, dim3 block, size_t lds, hipStream_t stream, Args... args) {
-  if ((g_prof.on >> id) & 1u) {
+  if ((g_prof.on.load(std::memory_order_relaxed) >> id) & 1u) {
     EventPair ev;
     bool ok = false;
     {
@@ -93,6 +95,23 @@ void timed_launch(int id, K kernel, dim3 grid, dim3 block, size_t lds, hipStream
     }
   }
   hipLaunchKernelGGL(kernel, grid, block, lds, stream, args...);
+}
+
+// Kernels that want more than 64 KiB of dynamic LDS opt in with hipFuncSetAttribute -- an attribute of the function ON
+// THE CURRENT DEVICE, so it is set once per (kernel, device), not once per process (a process that drives several GPUs
+// would otherwise launch on the second one without it).
+int allow_dynamic_lds(const void *kernel, size_t bytes, const char *what) {
+  static std::mutex mu;
+  static std::vector<std::pair<const void *, int>> done;
+  int device = 0;
+  ODTK_HIP_TRY(hipGetDevice(&device));
+  std::lock_guard<std::mutex> lock(mu);
+  for (const auto &d : done)
+    if (d.first == kernel && d.second == device) return ODTK_OK;
+  const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
+  if (e != hipSuccess) return hip_fail(e, what);
+  done.emplace_back(kernel, device);
+  return ODTK_OK;
 }
 
 constexpr size_t kAlign = 256;
@@ -189,11 +208,10 @@ int launch_decode(bool rotated, uint32_t tiles, int n_seg, size_t scan_lds, cons
   if (da.sort_cap > static_cast<uint32_t>(odtk::kSortCap)) {
     // top_n > 4096 (the reference has no cap): the sort buffer moves to 128 KiB of dynamic LDS
     constexpr size_t big_lds = sizeof(uint64_t) * odtk::kSortCapBig;
-    static const hipError_t attr6 = hipFuncSetAttribute(reinterpret_cast<const void *>(&odtk::select_decode_kernel<6, T, kLogits, odtk::kSortCapBig>),
-                                                        hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
-    static const hipError_t attr4 = hipFuncSetAttribute(reinterpret_cast<const void *>(&odtk::select_decode_kernel<4, T, kLogits, odtk::kSortCapBig>),
-                                                        hipFuncAttributeMaxDynamicSharedMemorySize, big_lds);
-    if (attr6 != hipSuccess || attr4 != hipSuccess) return hip_fail(attr6 != hipSuccess ? attr6 : attr4, "hipFuncSetAttribute(select_decode_kernel)");
+    const void *big = rotated ? reinterpret_cast<const void *>(&odtk::select_decode_kernel<6, T, kLogits, odtk::kSortCapBig>)
+                              : reinterpret_cast<const void *>(&odtk::select_decode_kernel<4, T, kLogits, odtk::kSortCapBig>);
+    const int rc = allow_dynamic_lds(big, big_lds, "hipFuncSetAttribute(select_decode_kernel)");
+    if (rc != ODTK_OK) return rc;
     if (rotated)
       timed_launch(ODTK_KERNEL_SELECT, odtk::select_decode_kernel<6, T, kLogits, odtk::kSortCapBig>, dim3(n_seg), dim3(odtk::kSelThreads), big_lds, stream, da);
     else
@@ -333,11 +351,10 @@ int decode_levels_impl(int batch, int n_levels, const odtk_level_t *levels, int 
 
 template <int NB, bool kGlobalKeys>
 int nms_launch(const odtk::NmsArgs &na, int batch, size_t lds, hipStream_t stream) {
-  // opt this kernel in to the full 160 KiB of LDS once (thread-safe static initialisation)
-  static const hipError_t attr_err =
-      hipFuncSetAttribute(reinterpret_cast<const void *>(&odtk::nms_kernel<NB, kGlobalKeys>),
-                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  if (attr_err != hipSuccess) return hip_fail(attr_err, "hipFuncSetAttribute(nms_kernel)");
+  // opt this kernel in to the full 160 KiB of LDS (once per device)
+  const int rc = allow_dynamic_lds(reinterpret_cast<const void *>(&odtk::nms_kernel<NB, kGlobalKeys>), 160 * 1024,
+                                   "hipFuncSetAttribute(nms_kernel)");
+  if (rc != ODTK_OK) return rc;
   timed_launch(ODTK_KERNEL_NMS, odtk::nms_kernel<NB, kGlobalKeys>, dim3(batch), dim3(odtk::kNmsThreads), lds, stream, na);
   ODTK_HIP_TRY(hipGetLastError());
   return ODTK_OK;
@@ -407,7 +424,8 @@ int bias_act_launch(void *y, const float *bias, const void *res, uint64_t n, uin
     hipLaunchKernelGGL((odtk::bias_act_scalar_kernel<T, kRes, kRelu>), dim3(static_cast<unsigned>(blocks)), dim3(256),
                        0, stream, y, bias, res, done, n, channels);
   }
-  return hipGetLastError() == hipSuccess ? ODTK_OK : ODTK_ERR_HIP;
+  ODTK_HIP_TRY(hipGetLastError());
+  return ODTK_OK;
 }
 
 template <typename T>
@@ -522,6 +540,7 @@ int decode_single(bool rotated, int batch, const void *const *inputs, void *cons
     return ODTK_ERR_INVALID;
   if (A == 0 || A > ODTK_MAX_ANCHORS || anchors_len != 4 * A || (!anchors && workspace && workspace_size))
     return ODTK_ERR_INVALID;
+  if (C == 0 || C > 0x7fffffff) return ODTK_ERR_INVALID;
   const bool query = !workspace || !workspace_size;
   if (!query && (!inputs || !inputs[0] || !inputs[1])) return ODTK_ERR_INVALID;
   odtk_level_t lv;
@@ -551,7 +570,7 @@ int odtk_debug_set_trace(void *device_buffer) {
 
 int odtk_profile_enable(int on) {
   std::lock_guard<std::mutex> lock(g_prof.mu);
-  g_prof.on = on < 0 ? ~0u : static_cast<unsigned>(on);
+  g_prof.on.store(on < 0 ? ~0u : static_cast<unsigned>(on), std::memory_order_relaxed);
   return ODTK_OK;
 }
 
@@ -561,15 +580,16 @@ int odtk_profile_collect(double total_ms[ODTK_KERNEL_COUNT], int launches[ODTK_K
   for (int k = 0; k < ODTK_KERNEL_COUNT; ++k) {
     total_ms[k] = 0.0;
     launches[k] = 0;
-    for (const EventPair &ev : g_prof.pending[k]) {
+    while (!g_prof.pending[k].empty()) {                    // an event pair leaves `pending` before anything can fail
+      const EventPair ev = g_prof.pending[k].back();
+      g_prof.pending[k].pop_back();
+      g_prof.spare.push_back(ev);
       ODTK_HIP_TRY(hipEventSynchronize(ev.stop));
       float ms = 0.0f;
       ODTK_HIP_TRY(hipEventElapsedTime(&ms, ev.start, ev.stop));
       total_ms[k] += ms;
       ++launches[k];
-      g_prof.spare.push_back(ev);
     }
-    g_prof.pending[k].clear();
   }
   return ODTK_OK;
 }
