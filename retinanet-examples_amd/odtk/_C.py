@@ -170,6 +170,8 @@ def decode(cls_head, box_head, anchors, scale, score_thresh, top_n, rotated=Fals
     batch, channels, height, width = cls_head.shape
     arr, n = _anchor_array(anchors)
     num_anchors = n // 4
+    if num_anchors == 0 or n % 4 or channels % num_anchors:
+        raise RuntimeError('decode: %d anchor values do not describe the %d channels of cls_head' % (n, channels))
     num_classes = channels // num_anchors
     if box_head.shape != (batch, num_anchors * nb, height, width):
         raise RuntimeError('box_head shape %s does not match cls_head %s' % (tuple(box_head.shape), tuple(cls_head.shape)))
