@@ -216,4 +216,6 @@ def test_engines_agree_with_fp32_eager_plus_oracle():
     print('COCO AP against the planted objects:', {k: round(v, 4) for k, v in ap.items()})
     assert ap['reference'] > 0.5, ap
     assert abs(ap['engine_fp32'] - ap['reference']) <= 2e-3, ap          # the same detector
-    assert abs(ap['engine_bf16'] - ap['reference']) <= 0.15, ap          # bf16 arithmetic: reported, loosely bounded
+    # measured on MI355X (round 2): reference 1.0, engine_fp32 1.0, engine_bf16 0.9833, eager autocast bf16 0.7668
+    assert abs(ap['engine_bf16'] - ap['reference']) <= 0.05, ap          # bf16 arithmetic of the timed path
+    assert ap['eager_autocast_bf16'] < ap['engine_bf16'] - 0.1, ap       # the eager graph's damped logits cost AP
