@@ -112,6 +112,17 @@ def normalise_batch(packed, table=None, dtype=torch.float32):
     return pixels.permute(0, 3, 1, 2)
 
 
+def _batch_buffer(shape):
+    """Uninitialised uint8 tensor for a collated batch.  Inside a loader worker it is born in shared memory, which is
+    how the batch reaches the main process anyway (torch's default collate does the same): one first touch of the pages
+    instead of two (private buffer, then the copy into a fresh shared segment)."""
+    if data.get_worker_info() is None:
+        return torch.empty(shape, dtype=torch.uint8)
+    proto = torch.empty(0, dtype=torch.uint8)
+    storage = proto._typed_storage()._new_shared(math.prod(shape), device=proto.device)
+    return proto.new(storage).resize_(*shape)
+
+
 def _adjust_hue(im, factor):
     """Shift the hue channel by `factor` turns (|factor| <= 0.5), wrapping: what torchvision's PIL
     `adjust_hue` does (the reference calls it, data.py:101-105; torchvision is absent here)."""
@@ -125,7 +136,7 @@ def _adjust_hue(im, factor):
 
 
 class CocoDataset(data.dataset.Dataset):
-    """One image (and its boxes) per item.  Items are `(pixels uint8 [h, w, 3], ...)`: normalisation and
+    """One image (and its boxes) per item.  Items are `(pixels uint8 [h, w, 4] = R, G, B, 255, ...)`: normalisation and
     padding are done per BATCH (see the module docstring); everything else follows reference data.py:13-181.
 
     The random decisions of training are drawn from `random` in the reference's order (resize jitter,
@@ -213,7 +224,8 @@ class CocoDataset(data.dataset.Dataset):
                 im, boxes = self._flip(im, boxes)
             im = self._colour(im)
             target = torch.cat([boxes, categories], dim=1)
-        pixels = torch.from_numpy(np.array(im, dtype=np.uint8))              # [h, w, 3], own memory
+        # [h, w, 4] = R, G, B, 255: PIL writes the `valid` byte of the batch format, and collate then moves whole rows
+        pixels = torch.from_numpy(np.array(im.convert('RGBA'), dtype=np.uint8))
         if self.training:
             return pixels, target
         return pixels, image_id, ratio
@@ -248,10 +260,13 @@ class CocoDataset(data.dataset.Dataset):
         up = lambda d: d + (stride - d % stride) % stride
         height = max(up(p.shape[0]) for p in pixels)
         width = max(up(p.shape[1]) for p in pixels)
-        packed = torch.zeros(len(pixels), height, width, 4, dtype=torch.uint8)
+        packed = _batch_buffer((len(pixels), height, width, 4))
+        view = packed.numpy()
         for k, p in enumerate(pixels):
-            packed[k, :p.shape[0], :p.shape[1], :3] = p
-            packed[k, :p.shape[0], :p.shape[1], 3] = 255
+            h, w = p.shape[:2]
+            view[k, :h, :w] = p.numpy()                                     # rows of 4 * w contiguous bytes
+            view[k, :h, w:] = 0                                             # only the padding is cleared
+            view[k, h:] = 0
         if self.training:
             targets = [item[1] for item in batch]
             rows = max(t.shape[0] for t in targets)
@@ -336,7 +351,10 @@ class DataIterator:
         self.sampler = data.distributed.DistributedSampler(self.dataset, **sampler_args) if world > 1 else None
         self.dataloader = data.DataLoader(self.dataset, batch_size=batch_size // world, sampler=self.sampler,
                                           collate_fn=self.dataset.collate_fn, num_workers=num_workers,
-                                          pin_memory=self.device.type == 'cuda')
+                                          pin_memory=self.device.type == 'cuda',
+                                          # training walks the data set epoch after epoch: keep the workers (starting one
+                                          # costs ~0.2 s next to an initialised HIP runtime, profiles/r02_loader_probe.txt)
+                                          persistent_workers=bool(training and num_workers > 0))
 
     def __repr__(self):
         return '\n'.join(['    loader: pytorch', '    resize: {}, max: {}'.format(self.resize, self.max_size)])

@@ -81,7 +81,8 @@ def parse(args):
                    default=[0.4, 0.5])
     p.add_argument('--absolute-angle', help='regress absolute angle (rather than -45 to 45 degrees.',
                    action='store_true')
-    p.add_argument('--workers', metavar='num', type=int, help='data loader workers per process', default=2)
+    p.add_argument('--workers', metavar='num', type=int, default=8,
+                   help='data loader workers per process (the reference hard-codes 2; ~6 feed one MI355X)')
 
     p = subparsers.add_parser('infer', help='run inference')
     p.add_argument('model', type=str, help='path to model')
@@ -96,7 +97,8 @@ def parse(args):
     p.add_argument('--with-dali', help='(dropped dependency: refused)', action='store_true')
     p.add_argument('--full-precision', help='inference in full precision', action='store_true')
     p.add_argument('--rotated-bbox', help='inference using a rotated bounding box model', action='store_true')
-    p.add_argument('--workers', metavar='num', type=int, help='data loader workers per process', default=2)
+    p.add_argument('--workers', metavar='num', type=int, default=8,
+                   help='data loader workers per process (the reference hard-codes 2; ~6 feed one MI355X)')
 
     p = subparsers.add_parser('export', help='export a model into a TensorRT engine (dropped: refused)')
     p.add_argument('model', type=str, help='path to model')

@@ -24,9 +24,9 @@ def _normalised(pixels, stride):
     """One item the way the reference returns it: normalised CHW float, zero-padded to the stride."""
     h, w = pixels.shape[:2]
     up = lambda d: d + (stride - d % stride) % stride
+    assert pixels.shape[2] == 4 and bool((pixels[..., 3] == 255).all())       # R, G, B, valid
     packed = torch.zeros(1, up(h), up(w), 4, dtype=torch.uint8)
-    packed[0, :h, :w, :3] = pixels
-    packed[0, :h, :w, 3] = 255
+    packed[0, :h, :w] = pixels
     return D.normalise_batch(packed)[0]
 
 
@@ -133,3 +133,15 @@ def test_colour_jitter_runs_and_keeps_geometry():
     b, tb = plain[1]
     assert a.shape == b.shape and torch.equal(ta, tb)
     assert not torch.equal(a, b)
+
+
+def test_worker_processes_deliver_the_same_batches():
+    """Batches collated inside loader workers are born in shared memory (`_batch_buffer`); same bytes as in-process."""
+    plain = D.DataIterator(HERE, 128, 200, 2, 32, 1, ANN, training=False, num_workers=0, device='cpu')
+    worked = D.DataIterator(HERE, 128, 200, 2, 32, 1, ANN, training=False, num_workers=2, device='cpu')
+    for (a, ia, ra), (b, ib, rb) in zip(plain, worked):
+        assert torch.equal(a, b) and torch.equal(ia, ib) and torch.equal(ra, rb)
+    train = D.DataIterator(HERE, [96, 128], 200, 2, 32, 1, ANN, training=True, num_workers=2, device='cpu')
+    assert train.dataloader.persistent_workers
+    for _ in range(2):                                            # two epochs on the same workers
+        assert sum(images.shape[0] for images, _ in train) == 5
