@@ -189,7 +189,7 @@ def infer(model, path, detections_file, resize, max_size, batch_size, mixed_prec
     amp = mixed_precision and device.type == 'cuda'
     with torch.autocast(device.type, dtype=torch.bfloat16, enabled=amp):
         detections = infer_batches(model, data_iterator, rotated_bbox=rotated_bbox,
-                                   category_ids=data_iterator.coco.getCatIds() if has_truth else None,
+                                   category_ids=(data_iterator.coco.getCatIds() or None) if has_truth else None,
                                    on_batch=progress)
     if verbose:
         print('Gathering results...')

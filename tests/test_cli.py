@@ -149,3 +149,29 @@ def test_two_cpu_ranks_launched_like_torchrun_agree_with_one(tmp_path):
     key = lambda d: (d['image_id'], -d['score'], d['category_id'], tuple(d['bbox']))
     assert sorted(one['annotations'], key=key) == sorted(two['annotations'], key=key)
     assert len(one['annotations']) > 0 and one['images'] == two['images']
+
+
+def test_two_cpu_ranks_train_with_validation(tmp_path):
+    """`python -m odtk.main train` as two gloo ranks with periodic validation: DDP gradient all-reduces, the logging
+    all-reduce and the validation all_gather interleave identically on both ranks (a mispaired collective would hang or
+    corrupt), rank 0 alone writes the checkpoint, and the replicas end up with identical weights."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = str(tmp_path / 'ddp.pth')
+    base = [sys.executable, '-W', 'ignore', '-m', 'odtk.main', 'train', path, '--annotations', ANN, '--images', DATA,
+            '--backbone', 'ResNet18FPN', '--classes', '3', '--batch', '2', '--resize', '128', '--max-size', '160',
+            '--jitter', '96', '128', '--iters', '5', '--warmup', '2', '--lr', '0.001', '--full-precision', '--workers', '0',
+            '--val-annotations', ANN, '--val-iters', '2']
+    env = dict(os.environ, PYTHONPATH=os.path.join(root, 'retinanet-examples_amd'), OMP_NUM_THREADS='2')
+    port = 31500 + os.getpid() % 2000
+    procs = []
+    for rank in range(2):
+        rank_env = dict(env, RANK=str(rank), WORLD_SIZE='2', LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        procs.append(subprocess.Popen(base, env=rank_env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert '[5/5] focal loss:' in outs[0] and 'focal loss' not in outs[1]
+    assert 'device: 2 cpu' in outs[0]
+    _, state = Model.load(path)
+    assert state['iteration'] == 5
