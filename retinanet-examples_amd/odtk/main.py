@@ -25,93 +25,94 @@ from . import infer, train
 from .model import Model
 
 
+def _flag(name, kind=None, default=None, text='', **extra):
+    """One row of the flag tables below: (name, argparse keyword arguments)."""
+    spec = dict(extra, help=text)
+    if kind is bool:
+        spec['action'] = 'store_true'
+    else:
+        spec.update(type=kind, default=default)
+    return name, spec
+
+
+_DROPPED = 'names a dependency this build drops; refused at run time'
+_SIZES = [_flag('--batch', int, None, 'images per step over all GPUs (default: 2 per GPU)', metavar='size'),
+          _flag('--resize', int, 800, 'short side after resizing', metavar='scale'),
+          _flag('--max-size', int, 1333, 'cap on the long side after resizing', metavar='max')]
+_COMMON = [_flag('--with-apex', bool, text=_DROPPED), _flag('--with-dali', bool, text=_DROPPED),
+           _flag('--workers', int, 8, 'loader processes per GPU (the reference hard-codes 2; ~6 feed one MI355X)', metavar='num')]
+
+# same names, types and defaults as the reference's parser (main.py:15-118)
+TRAIN_FLAGS = [
+    _flag('--annotations', str, None, 'COCO-style annotation file', metavar='path', required=True),
+    _flag('--images', str, '.', 'image directory', metavar='path'),
+    _flag('--backbone', str, ['ResNet50FPN'], 'one backbone or several', nargs='+'),
+    _flag('--classes', int, 80, 'number of object classes', metavar='num'),
+    *_SIZES,
+    _flag('--jitter', int, [640, 1024], 'range of short-side sizes drawn per image', nargs=2, metavar='min max'),
+    _flag('--iters', int, 90000, 'training iterations', metavar='number'),
+    _flag('--milestones', int, [60000, 80000], 'iterations at which the learning rate drops', nargs='*'),
+    _flag('--schedule', float, 1, 'stretch factor for --iters and --milestones', metavar='scale'),
+    _flag('--full-precision', bool, text='fp32 instead of mixed precision'),
+    _flag('--lr', float, 0.01, 'peak learning rate', metavar='value'),
+    _flag('--warmup', int, 1000, 'iterations of linear warm-up', metavar='iterations'),
+    _flag('--gamma', float, 0.1, 'learning-rate factor at a milestone', metavar='value'),
+    _flag('--override', bool, text='start from scratch even if the model file exists'),
+    _flag('--val-annotations', str, None, 'annotation file of the validation set', metavar='path'),
+    _flag('--val-images', str, None, 'image directory of the validation set', metavar='path'),
+    _flag('--post-metrics', str, None, 'POST training metrics to this address', metavar='url'),
+    _flag('--fine-tune', str, None, 'initialise from this checkpoint', metavar='path'),
+    _flag('--logdir', str, None, 'directory for scalar logs', metavar='logdir'),
+    _flag('--val-iters', int, 8000, 'iterations between two validations', metavar='number'),
+    *_COMMON,
+    _flag('--augment-rotate', bool, text='random quarter turns'),
+    _flag('--augment-free-rotate', float, [0, 0], 'accepted for compatibility (unused by the reference as well)', nargs=2,
+          metavar='value value'),
+    _flag('--augment-brightness', float, 0.002, 'sigma of the brightness factor', metavar='value'),
+    _flag('--augment-contrast', float, 0.002, 'sigma of the contrast factor', metavar='value'),
+    _flag('--augment-hue', float, 0.0002, 'sigma of the hue shift', metavar='value'),
+    _flag('--augment-saturation', float, 0.002, 'sigma of the saturation factor', metavar='value'),
+    _flag('--regularization-l2', float, 0.0001, 'weight decay', metavar='value'),
+    _flag('--rotated-bbox', bool, text='boxes are [x, y, w, h, theta]'),
+    _flag('--anchor-ious', float, [0.4, 0.5], 'background / foreground overlap thresholds', nargs=2, metavar='value value'),
+    _flag('--absolute-angle', bool, text='regress the absolute angle instead of -45..45 degrees'),
+]
+INFER_FLAGS = [
+    _flag('--images', str, '.', 'image directory', metavar='path'),
+    _flag('--annotations', str, None, 'annotation file: evaluate against it', metavar='annotations'),
+    _flag('--output', str, ['detections.json'], 'JSON file(s) for the detections', nargs='+', metavar='file'),
+    *_SIZES, *_COMMON,
+    _flag('--full-precision', bool, text='fp32 instead of mixed precision'),
+    _flag('--rotated-bbox', bool, text='the model predicts rotated boxes'),
+]
+EXPORT_FLAGS = [                                                   # parsed for compatibility; `export` itself is refused
+    _flag('--size', int, [1280], nargs='+', metavar='height width'), _flag('--full-precision', bool), _flag('--int8', bool),
+    _flag('--calibration-batches', int, 2, metavar='size'), _flag('--calibration-images', str, '', metavar='path'),
+    _flag('--calibration-table', str, '', metavar='path'), _flag('--verbose', bool), _flag('--rotated-bbox', bool),
+    _flag('--dynamic-batch-opts', int, [1, 8, 16], nargs=3, metavar='value value value'),
+]
+
+
 def parse(args):
     parser = argparse.ArgumentParser(description='ODTK: Object Detection Toolkit.')
-    parser.add_argument('--master', metavar='address:port', type=str, help='Address and port of the master worker',
-                        default='127.0.0.1:29500')
-    subparsers = parser.add_subparsers(help='sub-command', dest='command')
-    subparsers.required = True
-    devcount = max(1, torch.cuda.device_count())
-
-    p = subparsers.add_parser('train', help='train a network')
-    p.add_argument('model', type=str, help='path to output model or checkpoint to resume from')
-    p.add_argument('--annotations', metavar='path', type=str, help='path to COCO style annotations', required=True)
-    p.add_argument('--images', metavar='path', type=str, help='path to images', default='.')
-    p.add_argument('--backbone', action='store', type=str, nargs='+', help='backbone model (or list of)',
-                   default=['ResNet50FPN'])
-    p.add_argument('--classes', metavar='num', type=int, help='number of classes', default=80)
-    p.add_argument('--batch', metavar='size', type=int, help='batch size', default=2 * devcount)
-    p.add_argument('--resize', metavar='scale', type=int, help='resize to given size', default=800)
-    p.add_argument('--max-size', metavar='max', type=int, help='maximum resizing size', default=1333)
-    p.add_argument('--jitter', metavar='min max', type=int, nargs=2, help='jitter size within range', default=[640, 1024])
-    p.add_argument('--iters', metavar='number', type=int, help='number of iterations to train for', default=90000)
-    p.add_argument('--milestones', action='store', type=int, nargs='*',
-                   help='list of iteration indices where learning rate decays', default=[60000, 80000])
-    p.add_argument('--schedule', metavar='scale', type=float, help='scale schedule (affecting iters and milestones)',
-                   default=1)
-    p.add_argument('--full-precision', help='train in full precision', action='store_true')
-    p.add_argument('--lr', metavar='value', help='learning rate', type=float, default=0.01)
-    p.add_argument('--warmup', metavar='iterations', help='numer of warmup iterations', type=int, default=1000)
-    p.add_argument('--gamma', metavar='value', type=float, help='multiplicative factor of learning rate decay',
-                   default=0.1)
-    p.add_argument('--override', help='override model', action='store_true')
-    p.add_argument('--val-annotations', metavar='path', type=str, help='path to COCO style validation annotations')
-    p.add_argument('--val-images', metavar='path', type=str, help='path to validation images')
-    p.add_argument('--post-metrics', metavar='url', type=str, help='post metrics to specified url')
-    p.add_argument('--fine-tune', metavar='path', type=str, help='fine tune a pretrained model')
-    p.add_argument('--logdir', metavar='logdir', type=str, help='directory where to write logs')
-    p.add_argument('--val-iters', metavar='number', type=int, help='number of iterations between each validation',
-                   default=8000)
-    p.add_argument('--with-apex', help='(dropped dependency: refused)', action='store_true')
-    p.add_argument('--with-dali', help='(dropped dependency: refused)', action='store_true')
-    p.add_argument('--augment-rotate', help='use four-fold rotational augmentation', action='store_true')
-    p.add_argument('--augment-free-rotate', type=float, metavar='value value', nargs=2, default=[0, 0],
-                   help='rotate images by an arbitrary angle, between min and max (in degrees)')
-    p.add_argument('--augment-brightness', metavar='value', type=float, help='adjust the brightness of the image.',
-                   default=0.002)
-    p.add_argument('--augment-contrast', metavar='value', type=float, help='adjust the contrast of the image.',
-                   default=0.002)
-    p.add_argument('--augment-hue', metavar='value', type=float, help='adjust the hue of the image.', default=0.0002)
-    p.add_argument('--augment-saturation', metavar='value', type=float, help='adjust the saturation of the image.',
-                   default=0.002)
-    p.add_argument('--regularization-l2', metavar='value', type=float, help='L2 regularization for optim',
-                   default=0.0001)
-    p.add_argument('--rotated-bbox', help='detect rotated bounding boxes [x, y, w, h, theta]', action='store_true')
-    p.add_argument('--anchor-ious', metavar='value value', type=float, nargs=2, help='anchor/bbox overlap threshold',
-                   default=[0.4, 0.5])
-    p.add_argument('--absolute-angle', help='regress absolute angle (rather than -45 to 45 degrees.',
-                   action='store_true')
-    p.add_argument('--workers', metavar='num', type=int, default=8,
-                   help='data loader workers per process (the reference hard-codes 2; ~6 feed one MI355X)')
-
-    p = subparsers.add_parser('infer', help='run inference')
-    p.add_argument('model', type=str, help='path to model')
-    p.add_argument('--images', metavar='path', type=str, help='path to images', default='.')
-    p.add_argument('--annotations', metavar='annotations', type=str, help='evaluate using provided annotations')
-    p.add_argument('--output', metavar='file', type=str, nargs='+', help='save detections to specified JSON file(s)',
-                   default=['detections.json'])
-    p.add_argument('--batch', metavar='size', type=int, help='batch size', default=2 * devcount)
-    p.add_argument('--resize', metavar='scale', type=int, help='resize to given size', default=800)
-    p.add_argument('--max-size', metavar='max', type=int, help='maximum resizing size', default=1333)
-    p.add_argument('--with-apex', help='(dropped dependency: refused)', action='store_true')
-    p.add_argument('--with-dali', help='(dropped dependency: refused)', action='store_true')
-    p.add_argument('--full-precision', help='inference in full precision', action='store_true')
-    p.add_argument('--rotated-bbox', help='inference using a rotated bounding box model', action='store_true')
-    p.add_argument('--workers', metavar='num', type=int, default=8,
-                   help='data loader workers per process (the reference hard-codes 2; ~6 feed one MI355X)')
-
-    p = subparsers.add_parser('export', help='export a model into a TensorRT engine (dropped: refused)')
-    p.add_argument('model', type=str, help='path to model')
-    p.add_argument('export', type=str, help='path to exported output')
-    p.add_argument('--size', metavar='height width', type=int, nargs='+', default=[1280])
-    p.add_argument('--full-precision', action='store_true')
-    p.add_argument('--int8', action='store_true')
-    p.add_argument('--calibration-batches', metavar='size', type=int, default=2)
-    p.add_argument('--calibration-images', metavar='path', type=str, default='')
-    p.add_argument('--calibration-table', metavar='path', type=str, default='')
-    p.add_argument('--verbose', action='store_true')
-    p.add_argument('--rotated-bbox', action='store_true')
-    p.add_argument('--dynamic-batch-opts', metavar='value value value', type=int, nargs=3, default=[1, 8, 16])
+    parser.add_argument('--master', metavar='address:port', type=str, default='127.0.0.1:29500',
+                        help='rendezvous of the per-GPU workers')
+    commands = parser.add_subparsers(help='sub-command', dest='command')
+    commands.required = True
+    per_gpu = 2 * max(1, torch.cuda.device_count())
+    for name, positional, flags, text in (
+            ('train', [('model', 'checkpoint to write (and to resume from when it exists)')], TRAIN_FLAGS, 'train a network'),
+            ('infer', [('model', 'checkpoint to load')], INFER_FLAGS, 'run inference'),
+            ('export', [('model', 'checkpoint to load'), ('export', 'output file')], EXPORT_FLAGS,
+             'TensorRT export (dropped: refused)')):
+        sub = commands.add_parser(name, help=text)
+        for arg, arg_text in positional:
+            sub.add_argument(arg, type=str, help=arg_text)
+        for flag, spec in flags:
+            spec = dict(spec)
+            if flag == '--batch':
+                spec['default'] = per_gpu
+            sub.add_argument(flag, **spec)
     return parser.parse_args(args)
 
 

@@ -175,3 +175,36 @@ def test_two_cpu_ranks_train_with_validation(tmp_path):
     assert 'device: 2 cpu' in outs[0]
     _, state = Model.load(path)
     assert state['iteration'] == 5
+
+
+@pytest.mark.skipif(not os.path.isfile('/root/reference/odtk/main.py'), reason='reference tree not present')
+@pytest.mark.parametrize('argv', [
+    ['train', 'm.pth', '--annotations', 'a.json'],
+    ['train', 'm.pth', '--annotations', 'a.json', '--images', 'i', '--backbone', 'ResNet18FPN', 'ResNet34FPN', '--classes', '7',
+     '--batch', '4', '--resize', '512', '--max-size', '640', '--jitter', '480', '640', '--iters', '100', '--milestones', '50', '70',
+     '--schedule', '0.5', '--full-precision', '--lr', '0.1', '--warmup', '5', '--gamma', '0.3', '--override',
+     '--val-annotations', 'v.json', '--val-images', 'vi', '--post-metrics', 'http://x', '--fine-tune', 'f.pth', '--logdir', 'l',
+     '--val-iters', '10', '--augment-rotate', '--augment-free-rotate', '1', '2', '--augment-brightness', '0.1',
+     '--augment-contrast', '0.2', '--augment-hue', '0.3', '--augment-saturation', '0.4', '--regularization-l2', '0.5',
+     '--rotated-bbox', '--anchor-ious', '0.3', '0.6', '--absolute-angle', '--with-apex', '--with-dali'],
+    ['--master', 'host:1234', 'infer', 'm.pth'],
+    ['infer', 'm.pth', '--images', 'i', '--annotations', 'a.json', '--output', 'a.json', 'b.json', '--batch', '16', '--resize', '600',
+     '--max-size', '900', '--with-apex', '--with-dali', '--full-precision', '--rotated-bbox'],
+    ['export', 'm.pth', 'out.plan'],
+    ['export', 'm.pth', 'out.onnx', '--size', '800', '1280', '--full-precision', '--int8', '--calibration-batches', '4',
+     '--calibration-images', 'c', '--calibration-table', 't', '--verbose', '--rotated-bbox', '--dynamic-batch-opts', '1', '4', '8'],
+])
+def test_parser_equals_the_reference_parser(argv):
+    """The reference's own `parse` (odtk/main.py:15-118, lifted out of its module: the module's imports need apex /
+    TensorRT) and this one give the same namespace for the same command line; `--workers` is the one extra flag here."""
+    import argparse
+    import ast
+    source = open('/root/reference/odtk/main.py').read()
+    fn = next(n for n in ast.parse(source).body if isinstance(n, ast.FunctionDef) and n.name == 'parse')
+    scope = {'argparse': argparse, 'torch': torch}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), 'reference main.py', 'exec'), scope)
+    want = vars(scope['parse'](list(argv)))
+    got = vars(cli.parse(list(argv)))
+    if argv[0] != 'export' and 'export' not in argv[:3]:
+        assert got.pop('workers') == 8
+    assert got == want
