@@ -1,16 +1,19 @@
-"""Feature Pyramid Network P3..P7 (https://arxiv.org/abs/1612.03144) on top of a ResNet.
+"""Feature Pyramid Network P3..P7 (https://arxiv.org/abs/1612.03144) on top of a ResNet, ResNeXt or MobileNetV2.
 
 Attribute names (features, lateral3-5, pyramid6-7, smooth3-5) and therefore state_dict keys are the
 ones reference checkpoints use (reference odtk/backbones/fpn.py:12-61)."""
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .mobilenet import MobileNet
 from .resnet import ResNet, BasicBlock, Bottleneck
 
 FPN_CHANNELS = 256
 RESNET_DEPTHS = {'ResNet18FPN': ([2, 2, 2, 2], BasicBlock), 'ResNet34FPN': ([3, 4, 6, 3], BasicBlock),
                  'ResNet50FPN': ([3, 4, 6, 3], Bottleneck), 'ResNet101FPN': ([3, 4, 23, 3], Bottleneck),
                  'ResNet152FPN': ([3, 8, 36, 3], Bottleneck)}
+# (depths, groups, width per group) -- reference fpn.py:83-89
+RESNEXT = {'ResNeXt50_32x4dFPN': ([3, 4, 6, 3], 32, 4), 'ResNeXt101_32x8dFPN': ([3, 4, 23, 3], 32, 8)}
 
 
 class FPN(nn.Module):
@@ -18,7 +21,10 @@ class FPN(nn.Module):
         super().__init__()
         self.stride = 128                      # P7
         self.features = features
-        widths = [w * features.bottleneck.expansion for w in (128, 256, 512)]          # C3, C4, C5
+        if isinstance(features, MobileNet):
+            widths = [32, 96, 320]                                                       # features 6, 13, 17
+        else:
+            widths = [w * features.bottleneck.expansion for w in (128, 256, 512)]      # C3, C4, C5
         for level, width in zip((3, 4, 5), widths):
             setattr(self, 'lateral%d' % level, nn.Conv2d(width, FPN_CHANNELS, kernel_size=1))
         self.pyramid6 = nn.Conv2d(widths[-1], FPN_CHANNELS, kernel_size=3, stride=2, padding=1)
@@ -57,3 +63,17 @@ def _make(name):
 
 
 ResNet18FPN, ResNet34FPN, ResNet50FPN, ResNet101FPN, ResNet152FPN = (_make(n) for n in RESNET_DEPTHS)
+
+
+def ResNeXt50_32x4dFPN():
+    layers, groups, width = RESNEXT['ResNeXt50_32x4dFPN']
+    return FPN(ResNet(layers=layers, bottleneck=Bottleneck, outputs=[3, 4, 5], groups=groups, width_per_group=width))
+
+
+def ResNeXt101_32x8dFPN():
+    layers, groups, width = RESNEXT['ResNeXt101_32x8dFPN']
+    return FPN(ResNet(layers=layers, bottleneck=Bottleneck, outputs=[3, 4, 5], groups=groups, width_per_group=width))
+
+
+def MobileNetV2FPN():
+    return FPN(MobileNet(outputs=[6, 13, 17]))

@@ -34,14 +34,16 @@ class BasicBlock(nn.Module):
 class Bottleneck(nn.Module):
     expansion = 4
 
-    def __init__(self, cin, width, stride=1, downsample=None):
+    def __init__(self, cin, width, stride=1, downsample=None, groups=1, base_width=64):
         super().__init__()
+        out = width * 4
+        width = int(width * (base_width / 64.0)) * groups     # ResNeXt: `groups` paths of `base_width`-scaled width
         self.conv1 = nn.Conv2d(cin, width, 1, bias=False)
         self.bn1 = nn.BatchNorm2d(width)
-        self.conv2 = _conv3x3(width, width, stride)      # stride on the 3x3 (torchvision "v1.5")
+        self.conv2 = nn.Conv2d(width, width, 3, stride=stride, padding=1, groups=groups, bias=False)   # stride on the 3x3 ("v1.5")
         self.bn2 = nn.BatchNorm2d(width)
-        self.conv3 = nn.Conv2d(width, width * 4, 1, bias=False)
-        self.bn3 = nn.BatchNorm2d(width * 4)
+        self.conv3 = nn.Conv2d(width, out, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(out)
         self.relu = nn.ReLU(inplace=True)
         self.downsample = downsample
 
@@ -54,8 +56,11 @@ class Bottleneck(nn.Module):
 
 
 class ResNet(nn.Module):
-    def __init__(self, layers=(3, 4, 6, 3), bottleneck=Bottleneck, outputs=(5,)):
+    def __init__(self, layers=(3, 4, 6, 3), bottleneck=Bottleneck, outputs=(5,), groups=1, width_per_group=64):
         super().__init__()
+        if (groups, width_per_group) != (1, 64) and bottleneck is not Bottleneck:
+            raise ValueError('grouped / widened paths (ResNeXt) need the Bottleneck block')
+        extra = {'groups': groups, 'base_width': width_per_group} if bottleneck is Bottleneck else {}
         self.stride = 128
         self.bottleneck = bottleneck
         self.outputs = list(outputs)
@@ -74,7 +79,7 @@ class ResNet(nn.Module):
                 down = None
                 if stride != 1 or cin != cout:
                     down = nn.Sequential(nn.Conv2d(cin, cout, 1, stride=stride, bias=False), nn.BatchNorm2d(cout))
-                blocks.append(bottleneck(cin, width, stride, down))
+                blocks.append(bottleneck(cin, width, stride, down, **extra))
                 cin = cout
             setattr(self, 'layer%d' % (i + 1), nn.Sequential(*blocks))
         self.avgpool = nn.AdaptiveAvgPool2d((1, 1))

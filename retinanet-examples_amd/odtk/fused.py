@@ -52,7 +52,7 @@ class _Conv(nn.Module):
         w, b = fold_conv_bn(conv, bn)
         self.register_buffer('weight', w.to(dtype).contiguous(memory_format=torch.channels_last))
         self.register_buffer('bias', b.contiguous())
-        self.stride, self.padding, self.relu = conv.stride, conv.padding, relu
+        self.stride, self.padding, self.relu, self.groups = conv.stride, conv.padding, relu, conv.groups
         # pointwise: a GEMM over [N*H*W, Cin] with the whole epilogue fused (set False to A/B against MIOpen)
         # (a strided 1x1 convolution -- the downsample branch -- is the same GEMM on the subsampled pixels)
         self.pointwise = (tuple(conv.kernel_size) == (1, 1) and tuple(conv.padding) == (0, 0) and conv.groups == 1
@@ -60,7 +60,7 @@ class _Conv(nn.Module):
 
     def conv_only(self, x):
         """The convolution without its epilogue (the caller owns the bias)."""
-        y = F.conv2d(x, self.weight, None, self.stride, self.padding)
+        y = F.conv2d(x, self.weight, None, self.stride, self.padding, groups=self.groups)
         return y if y.is_contiguous(memory_format=torch.channels_last) else y.contiguous(memory_format=torch.channels_last)
 
     def forward(self, x, residual=None):
@@ -68,7 +68,7 @@ class _Conv(nn.Module):
             if tuple(self.stride) != (1, 1):
                 x = x[:, :, ::self.stride[0], ::self.stride[1]].contiguous(memory_format=torch.channels_last)
             return _C.gemm_bias_act(x, self.weight, self.bias, residual, self.relu)
-        y = F.conv2d(x, self.weight, None, self.stride, self.padding)
+        y = F.conv2d(x, self.weight, None, self.stride, self.padding, groups=self.groups)
         if not y.is_contiguous(memory_format=torch.channels_last):
             y = y.contiguous(memory_format=torch.channels_last)
         return _C.bias_act_(y, self.bias, residual, self.relu)
@@ -76,7 +76,7 @@ class _Conv(nn.Module):
 
     def conv_then_pool(self, x):
         """conv -> bias -> ReLU -> maxpool 3x3/s2 with the epilogue folded into the pooling pass."""
-        y = F.conv2d(x, self.weight, None, self.stride, self.padding)
+        y = F.conv2d(x, self.weight, None, self.stride, self.padding, groups=self.groups)
         if y.dtype in (torch.bfloat16, torch.float16) and y.shape[1] % 8 == 0:
             return _C.bias_act_maxpool(y.contiguous(memory_format=torch.channels_last), self.bias, self.relu)
         return F.max_pool2d(_C.bias_act_(y.contiguous(memory_format=torch.channels_last), self.bias, None, self.relu), 3, 2, 1)
