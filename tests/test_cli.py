@@ -208,3 +208,44 @@ def test_parser_equals_the_reference_parser(argv):
     if argv[0] != 'export' and 'export' not in argv[:3]:
         assert got.pop('workers') == 8
     assert got == want
+
+
+def test_config0_through_the_command_line_equals_the_oracle(tmp_path):
+    """BASELINE configs[0] end to end as a user runs it: one 512x512 image FILE, ResNet18FPN on the CPU,
+    `odtk infer --full-precision` -> detections JSON; the same pixels through the data set + the model's heads + the
+    pinned oracle's decode / nms + the hand-off conversion must give the identical records."""
+    from PIL import Image
+    from oracle import box_oracle
+    from odtk import data as D
+    from odtk.infer import detections_to_coco
+    images = tmp_path / 'images'
+    images.mkdir()
+    rng = np.random.default_rng(0)
+    Image.fromarray(rng.integers(0, 256, (512, 512, 3), dtype=np.uint8), 'RGB').save(images / 'one.png')
+    torch.manual_seed(0)
+    model = Model('ResNet18FPN', classes=80)
+    model.initialize(None)
+    model.eval()
+    it = D.DataIterator(str(images), 512, 512, 1, model.stride, 1, {'images': [{'id': 0, 'file_name': 'one.png'}]},
+                        training=False, num_workers=0, device='cpu')
+    (x, ids, ratios), = list(it)
+    assert tuple(x.shape) == (1, 3, 512, 512) and float(ratios) == 1.0
+    with torch.no_grad():
+        cls_heads, _ = model.heads(x)
+        bias = model.cls_head[-1].bias.view(1, -1, 1, 1)
+        sigma = torch.cat([(c - bias).flatten() for c in cls_heads]).std()
+        model.cls_head[-1].weight.mul_(0.7 / sigma)                          # the class prior alone gives zero detections
+        cls_heads, box_heads = model.heads(x)
+    path = str(tmp_path / 'config0.pth')
+    model.save({'path': path})
+    out = str(tmp_path / 'detections.json')
+    assert cli.main(['infer', path, '--images', str(images), '--output', out, '--batch', '1', '--resize', '512',
+                     '--max-size', '512', '--workers', '0', '--full-precision']) == 0
+    got = json.load(open(out))['annotations']
+    strides = [512 // c.shape[-1] for c in cls_heads]
+    for s in strides:
+        model.level_anchors(s)
+    ref = box_oracle.postprocess([c.sigmoid() for c in cls_heads], box_heads, strides, model.anchors, model.threshold,
+                                 model.top_n, model.nms, model.detections)
+    want = detections_to_coco(ref[0], ref[1], ref[2], ids, ratios.view(-1))
+    assert len(want) > 20 and got == want
