@@ -18,7 +18,6 @@ Differences, all deliberate:
   * `decode_levels` / `detect` are additions: all pyramid levels x the whole batch in one
     enqueue, with no host synchronisation (GPU only).
 """
-import math
 
 import torch
 
