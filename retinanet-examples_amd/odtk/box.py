@@ -370,5 +370,17 @@ def detect(cls_heads, box_heads, strides, anchors_per_stride, threshold=0.05, to
     for t in cls_heads:
         _require_gpu(t, 'detect')
     pairs = [_pair(c, b) for c, b in zip(cls_heads, box_heads)]
+    if len(pairs) > _C.MAX_LEVELS:
+        # a model with several backbones has 5 levels per backbone (reference model.py:138): the level table of one call
+        # holds MAX_LEVELS, so decode in groups and hand the concatenation to nms (its candidate count is not capped)
+        def bias_of(bias, lo, hi):
+            return bias[lo:hi] if isinstance(bias, (list, tuple)) else bias
+        parts = []
+        for lo in range(0, len(pairs), _C.MAX_LEVELS):
+            hi = min(lo + _C.MAX_LEVELS, len(pairs))
+            parts.append(_C.decode_levels([p[0] for p in pairs[lo:hi]], [p[1] for p in pairs[lo:hi]], anchors[lo:hi],
+                                          strides[lo:hi], threshold, top_n, rotated, logits=logits,
+                                          cls_bias=bias_of(cls_bias, lo, hi), box_bias=bias_of(box_bias, lo, hi)))
+        return _C.nms(*[torch.cat(t, 1) for t in zip(*parts)], nms, ndetections, rotated)
     return _C.detect([p[0] for p in pairs], [p[1] for p in pairs], anchors, strides, threshold, top_n, nms,
                      ndetections, rotated, logits=logits, cls_bias=cls_bias, box_bias=box_bias)

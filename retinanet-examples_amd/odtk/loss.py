@@ -112,6 +112,12 @@ class _FusedPyramidLoss(torch.autograd.Function):
 def fused_pyramid_loss(cls_heads, box_heads, depths, box_targets, alpha=0.25, gamma=2.0, beta=0.11):
     """`fused_level_loss` for every pyramid level at once: per-level (cls_sums [L], box_sums [L], foreground [L]) from ONE
     HIP launch forward and ONE backward (a training step: two launches where the per-level form needs ten)."""
+    from . import _C
+    if len(cls_heads) > _C.MAX_LEVELS:              # several backbones: 5 levels each; one launch covers MAX_LEVELS
+        groups = [fused_pyramid_loss(cls_heads[i:i + _C.MAX_LEVELS], box_heads[i:i + _C.MAX_LEVELS], depths[i:i + _C.MAX_LEVELS],
+                                     box_targets[i:i + _C.MAX_LEVELS], alpha, gamma, beta)
+                  for i in range(0, len(cls_heads), _C.MAX_LEVELS)]
+        return tuple(torch.cat(parts) for parts in zip(*groups))
     pairs = [_as_written_pair(c, b) for c, b in zip(cls_heads, box_heads)]
     n = len(pairs)
     return _FusedPyramidLoss.apply(n, alpha, gamma, beta, *[p[0] for p in pairs], *[p[1] for p in pairs],

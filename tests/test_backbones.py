@@ -70,3 +70,20 @@ def test_model_runs_and_round_trips_a_checkpoint(name, tmp_path):
     assert torch.equal(out[0], scores) and torch.equal(out[1], boxes)
     loss = model.train()([x, torch.tensor([[[10., 10., 60., 60., 1.]]])])
     assert all(torch.isfinite(v) for v in loss)
+
+
+def test_two_backbones_give_ten_levels_on_the_cpu_path():
+    """`--backbone A B` (reference main.py:37, model.py:138): the heads run on both pyramids -- ten levels."""
+    torch.manual_seed(0)
+    model = Model(['ResNet18FPN', 'MobileNetV2FPN'], classes=3)
+    model.initialize(None)
+    with torch.no_grad():
+        model.cls_head[-1].bias.fill_(0.0)
+    x = torch.randn(1, 3, 128, 128)
+    cls_heads, box_heads = model.eval().heads(x)
+    assert len(cls_heads) == 10 and [c.shape[-1] for c in cls_heads] == [16, 8, 4, 2, 1] * 2
+    scores, boxes, classes = model(x)
+    assert scores.shape == (1, 100) and int((scores > 0).sum()) > 0
+    loss = model.train()([x, torch.tensor([[[10., 10., 60., 60., 1.]]])])
+    assert all(torch.isfinite(v) for v in loss)
+    assert sorted(model.unused_modules) == ['classifier', 'fc', 'features.18']

@@ -53,3 +53,18 @@ def test_detect_equals_decode_levels_then_nms(n_levels, top_n, kind, dtype, empt
     if empty_level is not None:
         assert int((dec[0][:, empty_level * top_n:(empty_level + 1) * top_n] > 0).sum()) == 0
     assert int((one[0] > 0).sum(1).max()) > 0
+
+
+@pytest.mark.parametrize('n_levels,top_n', [(7, 300), (10, 1000)])
+def test_more_levels_than_one_level_table_holds(n_levels, top_n):
+    """A model with two backbones hands over ten levels (reference model.py:138); one call's level table holds six, so
+    `box.detect` decodes in groups.  Must equal the reference's own sequence: per-level decode, cat, nms."""
+    cls, dl, strides, anchors = _heads(5, 2, 'dense', torch.float32, seed=77)
+    more = _heads(5, 2, 'dense', torch.float32, seed=78)
+    cls, dl, strides = (cls + more[0])[:n_levels], (dl + more[1])[:n_levels], (strides + more[2])[:n_levels]
+    got = box.detect(cls, dl, strides, anchors, 0.05, top_n, 0.5, 100, logits=True)
+    per_level = [box.decode(c.sigmoid(), d, s, 0.05, top_n, anchors[s]) for c, d, s in zip(cls, dl, strides)]
+    want = box.nms(*[torch.cat(t, 1) for t in zip(*per_level)], 0.5, 100)
+    for a, b, what in zip(got, want, ('scores', 'boxes', 'classes')):
+        assert torch.equal(a, b), what
+    assert int((got[0] > 0).sum()) > 0
