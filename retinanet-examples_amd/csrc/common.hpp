@@ -78,4 +78,10 @@ __device__ __forceinline__ float tmin_nan(float a, float b) { return (a < b || a
 // 1 ulp of this (measured: 1.1 % of inputs differ, by exactly 1 ulp) -- see DESIGN.md "exp".
 __device__ __forceinline__ float exp_cr(float x) { return static_cast<float>(exp(static_cast<double>(x))); }
 
+// Zero fill of a 16-byte aligned region (workspace counters / selection state), grid-stride.
+__global__ __launch_bounds__(256) void clear_kernel(uint4 *p, size_t n) {
+  const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+  for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+
 }  // namespace odtk

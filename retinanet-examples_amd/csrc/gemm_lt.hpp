@@ -86,6 +86,7 @@ struct Plan {
   hipblasLtMatrixLayout_t a = nullptr, b = nullptr, c = nullptr;
   hipblasLtMatmulAlgo_t algo;
   size_t workspace = 0;
+  bool tuned = true;     // false: chosen without timing (first seen while the stream was being captured)
 };
 using Key = std::tuple<int, uint64_t, uint32_t, uint32_t, int, int, int>;   // device, m, n, k, dtype, relu, residual
 
@@ -130,6 +131,21 @@ inline int make_plan(Plan *p, void *y, const void *x, const void *w, const float
 
   const float alpha = 1.0f, beta = residual ? 1.0f : 0.0f;
   const void *c_ptr = residual ? residual : y;
+  // A stream that is being captured into a hipGraph cannot be timed (hipEventSynchronize would invalidate the capture):
+  // a shape first seen during a capture takes the heuristic's first usable candidate and is NOT remembered as tuned -- the
+  // caller (gemm_bias_act) keeps the plan only for the graph's own launches and re-plans on the next eager call.
+  hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing(stream, &capturing);
+  if (capturing != hipStreamCaptureStatusNone) {
+    for (int i = 0; i < n_found; ++i) {
+      if (found[i].state != HIPBLAS_STATUS_SUCCESS || found[i].workspaceSize > workspace_size) continue;
+      p->algo = found[i].algo;
+      p->workspace = found[i].workspaceSize;
+      p->tuned = false;
+      return ODTK_OK;
+    }
+    return ODTK_ERR_UNSUPPORTED;
+  }
   hipEvent_t e0, e1;
   if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return ODTK_ERR_HIP;
   float best_ms = 1e30f;
@@ -170,6 +186,17 @@ inline int gemm_bias_act(void *y, const void *x, const void *w, const float *bia
   const Key key{device, m, n, k, dtype, relu ? 1 : 0, residual ? 1 : 0};
   std::lock_guard<std::mutex> lock(mutex());     // descriptors carry the bias pointer: one call at a time
   auto it = plans().find(key);
+  if (it != plans().end() && !it->second.tuned) {
+    // planned blind inside a capture: time the candidates now if this call is an eager one
+    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(stream, &capturing);
+    if (capturing == hipStreamCaptureStatusNone) {
+      Api &a = api();
+      a.LayoutDestroy(it->second.a); a.LayoutDestroy(it->second.b); a.LayoutDestroy(it->second.c); a.DescDestroy(it->second.desc);
+      plans().erase(it);
+      it = plans().end();
+    }
+  }
   if (it == plans().end()) {
     Plan p;
     const int rc = make_plan(&p, y, x, w, bias, residual, m, n, k, dtype, relu, workspace, workspace_size, stream);

@@ -202,6 +202,7 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsArgs a) {
   // per run (below) and neither the key list, nor the min / max pass, nor the radix selection are needed (measured before:
   // compaction 1.8 + selection 10.8 us of the kernel's 36).
   const uint32_t n_runs = a.run_len ? count / a.run_len : 0;
+  static_assert(ODTK_MAX_LEVELS <= 8, "the sorted-run state (s_misc[72..111]) holds 8 runs; run_len is set by odtk_detect only");
   const bool runs = a.run_len >= 64 && n_runs * a.run_len == count && n_runs >= 1 && n_runs <= 8;   // block-uniform
   uint32_t *s_valid = s_misc + 72, *s_cursor = s_misc + 80, *s_members = s_misc + 88;   // per run (s_misc[72..95])
   uint64_t *s_probe = reinterpret_cast<uint64_t *>(s_misc + 96);                       // per run (s_misc[96..111])

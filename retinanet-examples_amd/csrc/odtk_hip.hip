@@ -337,7 +337,16 @@ int decode_levels_impl(int batch, int n_levels, const odtk_level_t *levels, int 
   da.trace = g_trace;
 
   const int n_seg = batch * n_levels;
-  ODTK_HIP_TRY(hipMemsetAsync(ws + lay.counts_off, 0, lay.zero_bytes - lay.counts_off, stream));   // counters + selection state
+  // counters + selection state start at zero.  A kernel of our own, not hipMemsetAsync: a memset NODE inside a hipGraph
+  // was the cause of round 2's "capture -> destroy -> capture again -> GPU memory fault" (tools/graph_bisect.py: graphs of
+  // kernel nodes only -- nms -- survive three capture / destroy rounds, any graph holding this memset faulted on a replay
+  // that followed an eager memset of the same size); a plain kernel node has no such history, and costs the same launch.
+  {
+    const size_t words = (lay.zero_bytes - lay.counts_off) / sizeof(uint4);                 // both ends are 256-byte aligned
+    const unsigned blocks = static_cast<unsigned>((words + 255) / 256 < 1024 ? (words + 255) / 256 : 1024);
+    hipLaunchKernelGGL(odtk::clear_kernel, dim3(blocks), dim3(256), 0, stream, reinterpret_cast<uint4 *>(ws + lay.counts_off), words);
+    ODTK_HIP_TRY(hipGetLastError());
+  }
   const bool rotated = (flags & ODTK_FLAG_ROTATED) != 0, logits = (flags & ODTK_FLAG_LOGITS) != 0;
   if (dtype == ODTK_F32)
     return logits ? launch_decode<odtk::F32, true>(rotated, tiles, n_seg, scan_lds, sa, da, stream)

@@ -145,8 +145,15 @@ _workspaces = {}
 
 
 def _workspace(device, nbytes):
-    """Scratch owned by the binding, cached per (device, stream): never shared between streams."""
+    """Scratch owned by the binding, cached per (device, stream): never shared between streams.
+    While the stream is being captured into a hipGraph nothing is cached and nothing cached is used: the buffer of a
+    captured call is allocated for that call and belongs to the graph (torch serves allocations made during a capture
+    from the graph's private pool and keeps that pool alive exactly as long as the graph), so a graph never reads
+    scratch that an eager call -- or another graph -- may grow, replace or overwrite, and the cache never holds
+    memory of a graph that no longer exists."""
     stream = torch.cuda.current_stream(device)
+    if torch.cuda.is_current_stream_capturing() and not os.environ.get('ODTK_WS_CACHE_IN_CAPTURE'):
+        return torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device), stream.cuda_stream
     key = (device.index, stream.cuda_stream)
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
@@ -534,13 +541,17 @@ _GEMM_READY = []
 
 
 def _gemm_setup(device):
-    """Bind hipBLASLt (the copy PyTorch ships, so that one copy of the soname serves the process) and
-    keep one 32 MiB scratch buffer per device."""
+    """Bind hipBLASLt (the copy PyTorch ships, so that one copy of the soname serves the process) and keep one 32 MiB
+    scratch buffer per (device, stream) -- GEMMs on different streams may run at the same time.  Inside a hipGraph
+    capture the buffer is allocated for the call and belongs to the graph (see `_workspace`)."""
     if not gemm_available():
         raise RuntimeError('gemm_bias_act: hipBLASLt could not be bound (odtk_gemm_init failed)')
-    if device not in _GEMM_WORKSPACE:
-        _GEMM_WORKSPACE[device] = torch.empty(32 << 20, dtype=torch.uint8, device=device)
-    return _GEMM_WORKSPACE[device]
+    if torch.cuda.is_current_stream_capturing():
+        return torch.empty(32 << 20, dtype=torch.uint8, device=device)
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    if key not in _GEMM_WORKSPACE:
+        _GEMM_WORKSPACE[key] = torch.empty(32 << 20, dtype=torch.uint8, device=device)
+    return _GEMM_WORKSPACE[key]
 
 
 def gemm_available():

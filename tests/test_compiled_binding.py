@@ -12,6 +12,7 @@ import numpy as np
 import pytest
 import torch
 
+from oracle import box_check
 from odtk import _C, box
 
 try:
@@ -74,7 +75,9 @@ def test_ext_decode_vs_reference_fixture(path):
                         int(g['stride']), float(g['threshold']), int(g['top_n']))
     _bits(out[0], g['out_scores'], 'scores')
     _bits(out[2], g['out_classes'], 'classes')
-    assert np.abs(out[1].cpu().numpy().astype(np.float64) - g['out_boxes']).max() <= 1.3e-4
+    stride = int(g['stride'])
+    box_check.check_decode(out[1], g['out_boxes'], [g['cls']], [g['box']], [stride], {stride: torch.from_numpy(g['anchors'])},
+                           float(g['threshold']), int(g['top_n']))      # 1e-4, or proven exp rounding (oracle/box_check.py)
     with pytest.raises(RuntimeError, match='must be contiguous'):
         _C_ext.decode(torch.from_numpy(g['cls']).cuda().transpose(2, 3), torch.from_numpy(g['box']).cuda(),
                       g['anchors'].reshape(-1).tolist(), int(g['stride']), float(g['threshold']), int(g['top_n']))

@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-from oracle import box_oracle, c_oracle
+from oracle import box_check, box_oracle, c_oracle
 from odtk import box
 from odtk.model import Model
 
@@ -56,10 +56,10 @@ def test_config0_resnet18fpn_512_plumbing():
     gpu_scores = [c.sigmoid() for c in cls_heads]
     hip = box.detect(gpu_scores, box_heads, strides, model.anchors, model.threshold, model.top_n, model.nms,
                      model.detections)
-    ref2 = box_oracle.postprocess([c.cpu() for c in gpu_scores], [b.cpu() for b in box_heads], strides,
-                                  model.anchors, model.threshold, model.top_n, model.nms, model.detections)
+    ref2 = box_check.reference_with_proof([c.cpu() for c in gpu_scores], [b.cpu() for b in box_heads], strides,
+                                          model.anchors, model.threshold, model.top_n, model.nms, model.detections)
     assert torch.equal(hip[0].cpu(), ref2[0]) and torch.equal(hip[2].cpu(), ref2[2])
-    assert (hip[1].cpu() - ref2[1]).abs().max() <= 1.3e-4
+    box_check.check_boxes(hip[1], ref2[1], ref2[3], ref2[4], 'config 1 boxes')       # 1e-4, or proven exp rounding
     for f, h in zip(fused, hip):
         assert torch.equal(f, h)
 

@@ -4,7 +4,8 @@ bs 16 = 245.7 M, rotated bs 8 = 368.6 M) on the GPU, checked two ways:
 (1) against the ORACLE at full size, image by image (`test_full_size_vs_oracle*`): the same head tensors go
     to `oracle.box_oracle` (torch CPU restatement pinned to the reference's odtk/box.py; ~50 ms - 1 s per
     image) / `oracle.c_oracle` (rotated) and to the HIP path.  Decode: flat indices, scores and classes bit
-    for bit, boxes within max(1e-4, 2 ulp) of the torch oracle (see `_boxes_close`) and bit for bit against the
+    for bit, boxes within 1e-4 of the torch oracle -- a coordinate beyond it only with proof that it is the reference's exp
+    rounding (see `_boxes_close`, oracle/box_check.py) -- and bit for bit against the
     C oracle; NMS: kept positions, scores, boxes, classes bit for bit on identical candidates, and the whole
     pipeline end to end.  This is where the > 4096-candidate
     radix descent, the multi-workgroup selection passes, 2-tile spans and the 16 sub-lists see real densities.
@@ -20,7 +21,7 @@ import numpy as np
 import pytest
 import torch
 
-from oracle import box_oracle, c_oracle
+from oracle import box_check, box_oracle, c_oracle
 from odtk import _C, box, synthetic
 
 pytestmark = pytest.mark.gpu
@@ -132,20 +133,19 @@ def test_full_size_saturated_and_empty():
 # ------------------------------------------------------------------------------------------------
 # (1) the oracle at full size
 # ------------------------------------------------------------------------------------------------
-BOX_ATOL = 1e-4
+EXP_ROUNDING_CASES = {}        # test id -> coordinates beyond 1e-4 that were proven to be the reference's exp rounding
 
 
-def _boxes_close(got, ref, what):
-    """The only operation of the path that is not bit-reproducible across implementations is exp(): torch's CPU
-    exp (what the reference computes with) is off the correctly rounded value by 1 ulp on 1.1 % of its inputs
-    (measured; it is a closed vector-library routine, not reproducible elsewhere), the kernel and the C oracle
-    round correctly.  One ulp of exp() moves `pw` by one ulp, and `pcx -+ 0.5 * pw (- 1)` rounds twice more, so a
-    corner can land 2 ulp of its own magnitude away: 1.2e-4 at 512..1024 px (seen once in ~40 000 boxes at full
-    size), 2.4e-4 beyond.  Tolerance = max(1e-4, 2 ulp)."""
-    got, ref = got.double(), ref.double()
-    tol = torch.maximum(torch.full_like(ref, BOX_ATOL), 2 * torch.from_numpy(np.spacing(ref.abs().float().numpy())).double())
-    bad = (got - ref).abs() > tol
-    assert not bool(bad.any()), '%s: max |diff| %.3g' % (what, float((got - ref).abs()[bad].max()))
+def _boxes_close(got, ref, proof, what, tally):
+    """The north star's bar: 1e-4.  The only operation of the path that is not bit-reproducible across implementations is
+    exp(): torch's CPU exp (what the reference computes with) is 1 ulp off the correctly rounded value on 1.1 % of its
+    inputs, the kernel and the C oracle round correctly, so a corner hundreds of pixels out can land 2 ulp = 1.2e-4 away
+    (seen once in ~40 000 boxes at full size).  Such a coordinate is accepted only with proof (oracle/box_check.py): bit-equal
+    to the C restatement AND no further from the float64 evaluation of box.py:97-111 than the reference's own value."""
+    exact, truth = proof
+    n = box_check.check_boxes(got, ref, exact, truth, what)
+    EXP_ROUNDING_CASES[tally] = EXP_ROUNDING_CASES.get(tally, 0) + n
+    return n
 
 
 @pytest.mark.parametrize('kind,dtype,logits,channels_last,batch', [
@@ -178,18 +178,21 @@ def test_full_size_vs_oracle(kind, dtype, logits, channels_last, batch):
         assert torch.equal(dec[3][b].long(), ref[3][0]), 'image %d: flat indices' % b
         assert torch.equal(dec[0][b], ref[0][0]), 'image %d: scores' % b
         assert torch.equal(dec[2][b], ref[2][0]), 'image %d: classes' % b
-        _boxes_close(dec[1][b], ref[1][0], 'image %d: boxes' % b)
+        proof = box_check.ImageProof(scores, deltas, STRIDES, anchors, thr, top_n, ref[3][0])
+        tally = 'full_size[%s-%s-bs%d]' % (kind, str(dtype).split('.')[-1], batch)
+        _boxes_close(dec[1][b], ref[1][0], (proof.exact, proof.truth), 'image %d: boxes' % b, tally)
         # NMS on identical candidates (the HIP decode's): everything bit for bit, kept positions included
         ref_nms = box_oracle.nms(dec[0][b:b + 1], dec[1][b:b + 1], dec[2][b:b + 1], nms_thr, ndet, return_indices=True)
         assert torch.equal(hip_nms[3][b].long(), ref_nms[3][0]), 'image %d: kept positions' % b
         for k in range(3):
             assert torch.equal(hip_nms[k][b], ref_nms[k][0]), 'image %d: nms output %d' % (b, k)
         # the whole pipeline, oracle end to end
-        ref_e2e = box_oracle.nms(ref[0], ref[1], ref[2], nms_thr, ndet)
+        ref_e2e = box_oracle.nms(ref[0], ref[1], ref[2], nms_thr, ndet, return_indices=True)
         assert torch.equal(det[0][b], ref_e2e[0][0]) and torch.equal(det[2][b], ref_e2e[2][0]), 'image %d: end to end' % b
-        _boxes_close(det[1][b], ref_e2e[1][0], 'image %d: end-to-end boxes' % b)
+        _boxes_close(det[1][b], ref_e2e[1][0], proof.at(ref_e2e[3][0]), 'image %d: end-to-end boxes' % b, tally)
         assert int((det[0][b] > 0).sum()) == ndet
     assert n_dense_segments >= batch          # P3 (at least) went through the > 4096-candidate selection path
+    print('%s: %d box coordinates beyond 1e-4, each proven to be exp rounding' % (tally, EXP_ROUNDING_CASES.get(tally, 0)))
 
 
 def test_full_size_rotated_vs_oracle():
@@ -266,8 +269,11 @@ def test_config2_parity_subrun_on_captured_model_heads():
                      for s, d, st in zip(scores, deltas, STRIDES)]
         ref = [torch.cat(t, 1) for t in zip(*per_level)]
         assert torch.equal(strict[3][b].long(), ref[3][0]) and torch.equal(strict[0][b], ref[0][0]) and torch.equal(strict[2][b], ref[2][0]), b
-        _boxes_close(strict[1][b], ref[1][0], 'image %d: boxes' % b)
-        ref_e2e = box_oracle.nms(ref[0], ref[1], ref[2], model.nms, model.detections)
+        proof = box_check.ImageProof([s[b:b + 1].cpu() for s in scores], [d[b:b + 1].cpu() for d in deltas], STRIDES, model.anchors,
+                                     thr, top_n, ref[3][0])
+        _boxes_close(strict[1][b], ref[1][0], (proof.exact, proof.truth), 'image %d: boxes' % b, 'config2_subrun')
+        ref_e2e = box_oracle.nms(ref[0], ref[1], ref[2], model.nms, model.detections, return_indices=True)
         assert torch.equal(det[0][b], ref_e2e[0][0]) and torch.equal(det[2][b], ref_e2e[2][0]), b
-        _boxes_close(det[1][b], ref_e2e[1][0], 'image %d: detections' % b)
+        _boxes_close(det[1][b], ref_e2e[1][0], proof.at(ref_e2e[3][0]), 'image %d: detections' % b, 'config2_subrun')
         assert int((det[0][b] > 0).sum()) == model.detections
+    print('config 2 sub-run: %d box coordinates beyond 1e-4, each proven to be exp rounding' % EXP_ROUNDING_CASES.get('config2_subrun', 0))

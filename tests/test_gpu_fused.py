@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 import torch
 
-from oracle import box_oracle
+from oracle import box_check, box_oracle
 from odtk import _C, box, synthetic
 
 pytestmark = pytest.mark.gpu
@@ -56,7 +56,8 @@ def test_fused_equals_strict_on_torch_materialised_scores(dtype, channels_last, 
     ref = [torch.cat(t, 1) for t in zip(*ref)]
     assert torch.equal(fused[3].cpu().long(), ref[3])
     assert torch.equal(fused[0].cpu(), ref[0]) and torch.equal(fused[2].cpu(), ref[2])
-    assert (fused[1].cpu() - ref[1]).abs().max() <= 1.3e-4
+    box_check.check_decode(fused[1], ref[1], [c.cpu() for c in scores], [d.cpu() for d in deltas], strides, anchors, 0.05, 400,
+                           ref_indices=ref[3])                    # 1e-4; beyond it only with proof (oracle/box_check.py)
     # full detect
     det = box.detect(cls, dl, strides, anchors, 0.05, 400, 0.5, 100, logits=True)
     det_ref = box_oracle.nms(ref[0], ref[1], ref[2], 0.5, 100)
@@ -75,7 +76,8 @@ def test_scores_without_logits_in_16bit_and_nhwc():
     ref = [torch.cat(t, 1) for t in zip(*ref)]
     assert torch.equal(out[3].cpu().long(), ref[3])
     assert torch.equal(out[0].cpu(), ref[0]) and torch.equal(out[2].cpu(), ref[2])
-    assert (out[1].cpu() - ref[1]).abs().max() <= 1.3e-4
+    box_check.check_decode(out[1], ref[1], [c.float().cpu().contiguous() for c in scores16], [d.float().cpu().contiguous() for d in dl16],
+                           strides, anchors, 0.05, 300, ref_indices=ref[3])
 
 
 def test_fused_threshold_edges_and_saturation():

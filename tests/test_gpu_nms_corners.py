@@ -1,0 +1,159 @@
+"""Corners the C ABI allows (include/odtk_hip.h limits) that no other GPU test visits -- each against the C restatement
+(oracle/c/odtk_oracle.c, pinned to the reference's box.py / nms_iou.cu), kept positions and every output bit for bit:
+
+  * detections_per_im in {301, 1024, 2048} (the kept list outgrows one 1024-candidate round; ODTK_MAX_NMS_DETECTIONS = 2048)
+    x {axis-aligned, rotated} x {stand-alone nms on arbitrary input, `detect` (sorted-run mode: nms consumes decode_levels'
+    per-level lists as runs), more than ODTK_MAX_NMS_COUNT = 7680 candidates per image (key list in the workspace)};
+  * n_levels = 6 = ODTK_MAX_LEVELS in ONE odtk_detect call (other tests use 5, or 7 / 10 split over two calls);
+  * rotated decode with top_n = 5000 (> 4096: the 128 KiB dynamic-LDS select_decode variant) and its nms;
+  * a `run_len` that does not qualify for the sorted-run mode (top_n < 64) must take the generic path with the same result.
+(More than 8 runs cannot be expressed through the ABI: run_len is set by odtk_detect only and ODTK_MAX_LEVELS is 6 --
+csrc/nms.hpp carries a static_assert instead of a run-time guard.)
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import c_oracle
+from odtk import _C, box, synthetic
+
+pytestmark = pytest.mark.gpu
+
+RATIOS = [1.0, 2.0, 0.5]
+SCALES = [4 * 2 ** (i / 3) for i in range(3)]
+ANGLES = [-np.pi / 6, 0, np.pi / 6]
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def same_bits(hip, ref, what):
+    for k, name in enumerate(('scores', 'boxes', 'classes')):
+        assert np.array_equal(bits(hip[k].cpu().numpy()), bits(ref[k])), '%s: %s differ' % (what, name)
+
+
+def random_candidates(seed, batch, count, n_cls, rotated, spread, quantise=False):
+    g = torch.Generator().manual_seed(seed)
+    ctr = torch.rand(batch, count, 2, generator=g) * spread + 20
+    wh = torch.rand(batch, count, 2, generator=g) * 40 + 2
+    boxes = torch.cat([ctr - wh / 2, ctr + wh / 2], 2)
+    if rotated:
+        th = (torch.rand(batch, count, generator=g) - 0.5) * 3.0
+        boxes = torch.cat([boxes, th.sin()[..., None], th.cos()[..., None]], 2)
+    scores = torch.rand(batch, count, generator=g)
+    if quantise:
+        scores = (scores * 64).round() / 64                          # massive ties, some zeros
+    classes = torch.randint(0, n_cls, (batch, count), generator=g).float()
+    return scores, boxes, classes
+
+
+@pytest.mark.parametrize('rotated', [False, True], ids=['axis', 'rotated'])
+@pytest.mark.parametrize('ndet', [301, 1024, 2048])
+@pytest.mark.parametrize('count,n_cls,thr,spread,quantise', [
+    (5000, 80, 0.5, 2000.0, False),      # LDS-resident keys, mostly survivors: the kept list passes 1024 and 2048
+    (3000, 3, 0.3, 60.0, True),          # heavy suppression + ties: every candidate examined, ~500 kept, many rounds
+    (10000, 80, 0.5, 1500.0, False),     # > ODTK_MAX_NMS_COUNT: key list in the workspace
+], ids=['lds-5000', 'ties-3000', 'scratch-10000'])
+def test_standalone_nms_long_kept_lists(rotated, ndet, count, n_cls, thr, spread, quantise):
+    if rotated and count == 10000:
+        count = 8000                                                  # (the single-threaded C oracle's polygon clips: keep it in seconds)
+    scores, boxes, classes = random_candidates(1000 + ndet + count + rotated, 2, count, n_cls, rotated, spread, quantise)
+    out = _C.nms(scores.cuda(), boxes.cuda(), classes.cuda(), thr, ndet, rotated, return_indices=True)
+    ref = c_oracle.nms(scores.numpy(), boxes.numpy(), classes.numpy(), thr, ndet, rotated=rotated)
+    assert np.array_equal(out[3].cpu().numpy().astype(np.int64), ref[3]), 'kept positions'
+    same_bits(out, ref, 'nms')
+    kept = int((out[0] > 0).sum(1).max())
+    assert kept > 300, kept                                           # the kept list really outgrows the default geometry
+
+
+def _pyramid(batch, A, C, height, width, kind, seed, nb, strides):
+    cls, dl = [], []
+    shapes = synthetic.level_shapes(height, width, strides)
+    for i, (h, w) in enumerate(shapes):
+        lg, d = synthetic.make_level(batch, A, C, h, w, kind, seed + i, nb, stride=strides[i])
+        cls.append(lg.sigmoid())
+        dl.append(d)
+    sizes = [c[0].numel() for c in cls]
+    joint = synthetic.make_unique_scores(torch.cat([c.reshape(batch, -1) for c in cls], 1), 0.05)
+    cls = [j.reshape(c.shape) for j, c in zip(joint.split(sizes, 1), cls)]
+    return cls, dl
+
+
+def _oracle_detect(cls, dl, strides, anchors, thr, top_n, nms_thr, ndet, rotated):
+    per = [c_oracle.decode(c.numpy(), d.numpy(), s, thr, top_n, (anchors[s][0] if rotated else anchors[s]).numpy(), rotated=rotated)
+           for c, d, s in zip(cls, dl, strides)]
+    cat = [np.concatenate(t, 1) for t in zip(*per)]
+    return cat, c_oracle.nms(cat[0], cat[1], cat[2], nms_thr, ndet, rotated=rotated)
+
+
+@pytest.mark.parametrize('rotated', [False, True], ids=['axis', 'rotated'])
+@pytest.mark.parametrize('ndet,top_n', [(301, 1000), (1024, 1000), (2048, 1000), (2048, 2000)],
+                         ids=['d301', 'd1024', 'd2048', 'd2048-top2000-scratch-keys'])
+def test_detect_sorted_run_mode_long_kept_lists(rotated, ndet, top_n):
+    """`detect`: nms reads decode_levels' output as sorted runs.  top_n = 2000 x 5 levels = 10 000 candidates per image puts
+    the key list in the workspace (sorted-run mode of the kGlobalKeys kernel)."""
+    strides = [8, 16, 32, 64, 128]
+    A, nb = (27, 6) if rotated else (9, 4)
+    cls, dl = _pyramid(2, A, 12, 256, 384, 'dense', 4100 + ndet + top_n, nb, strides)
+    anchors = {s: (box.generate_anchors_rotated(s, RATIOS, SCALES, ANGLES) if rotated else box.generate_anchors(s, RATIOS, SCALES))
+               for s in strides}
+    out = box.detect([c.cuda() for c in cls], [d.cuda() for d in dl], strides, anchors, 0.05, top_n, 0.5, ndet, rotated)
+    cat, ref = _oracle_detect(cls, dl, strides, anchors, 0.05, top_n, 0.5, ndet, rotated)
+    same_bits(out, ref, 'detect')
+    assert int((out[0] > 0).sum(1).max()) > 300
+    # the two-call form on the same candidates (generic mode of nms) agrees with the sorted-run mode
+    dec = _C.decode_levels([c.cuda() for c in cls], [d.cuda() for d in dl], [anchors[s][0] if rotated else anchors[s] for s in strides],
+                           strides, 0.05, top_n, rotated)
+    for k in range(3):
+        assert np.array_equal(bits(dec[k].cpu().numpy()), bits(cat[k])), 'decode output %d' % k
+    two = _C.nms(dec[0], dec[1], dec[2], 0.5, ndet, rotated)
+    for a, b in zip(out, two):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('rotated', [False, True], ids=['axis', 'rotated'])
+def test_six_levels_in_one_call(rotated):
+    """ODTK_MAX_LEVELS = 6 levels through ONE odtk_detect / odtk_decode_levels call (6 sorted runs in nms)."""
+    strides = [4, 8, 16, 32, 64, 128]
+    A, nb = (27, 6) if rotated else (9, 4)
+    cls, dl = _pyramid(3, A, 7, 128, 192, 'dense', 515 + rotated, nb, strides)
+    assert len(cls) == 6
+    anchors = {s: (box.generate_anchors_rotated(s, RATIOS, SCALES, ANGLES) if rotated else box.generate_anchors(s, RATIOS, SCALES))
+               for s in strides}
+    out = box.detect([c.cuda() for c in cls], [d.cuda() for d in dl], strides, anchors, 0.05, 300, 0.5, 150, rotated)
+    cat, ref = _oracle_detect(cls, dl, strides, anchors, 0.05, 300, 0.5, 150, rotated)
+    same_bits(out, ref, 'detect, 6 levels')
+    dec = _C.decode_levels([c.cuda() for c in cls], [d.cuda() for d in dl], [anchors[s][0] if rotated else anchors[s] for s in strides],
+                           strides, 0.05, 300, rotated, return_indices=True)
+    assert np.array_equal(dec[3].cpu().numpy().astype(np.int64), cat[3])
+    assert int((out[0] > 0).sum()) > 100
+
+
+def test_rotated_top_n_5000():
+    """Rotated decode with top_n > 4096 (select_decode's 128 KiB dynamic-LDS variant, <6, ..., 16384>) and the nms that
+    follows: 2 levels x 5000 = 10 000 candidates per image (workspace key list)."""
+    strides = [8, 16]
+    cls, dl = _pyramid(2, 27, 10, 192, 256, 'dense', 77, 6, strides)
+    anchors = {s: box.generate_anchors_rotated(s, RATIOS, SCALES, ANGLES) for s in strides}
+    n_cand = [int((c[0] >= 0.05).sum()) for c in cls]
+    assert n_cand[0] > 5000                                            # the cut at 5000 is real on P3
+    dec = _C.decode_levels([c.cuda() for c in cls], [d.cuda() for d in dl], [anchors[s][0] for s in strides], strides, 0.05, 5000,
+                           True, return_indices=True)
+    cat, ref = _oracle_detect(cls, dl, strides, anchors, 0.05, 5000, 0.5, 300, True)
+    assert np.array_equal(dec[3].cpu().numpy().astype(np.int64), cat[3]), 'selected indices / order'
+    for k in range(3):
+        assert np.array_equal(bits(dec[k].cpu().numpy()), bits(cat[k])), 'decode output %d' % k
+    out = box.detect([c.cuda() for c in cls], [d.cuda() for d in dl], strides, anchors, 0.05, 5000, 0.5, 300, True)
+    same_bits(out, ref, 'detect, rotated, top_n 5000')
+
+
+@pytest.mark.parametrize('top_n', [37, 63, 64])
+def test_short_runs_take_the_generic_path(top_n):
+    """run_len < 64 does not qualify for the sorted-run mode (csrc/nms.hpp): same answer through the generic rounds."""
+    strides = [8, 16, 32, 64, 128]
+    cls, dl = _pyramid(2, 9, 5, 128, 128, 'dense', 900 + top_n, 4, strides)
+    anchors = {s: box.generate_anchors(s, RATIOS, SCALES) for s in strides}
+    out = box.detect([c.cuda() for c in cls], [d.cuda() for d in dl], strides, anchors, 0.05, top_n, 0.5, 100)
+    _, ref = _oracle_detect(cls, dl, strides, anchors, 0.05, top_n, 0.5, 100, False)
+    same_bits(out, ref, 'detect, top_n %d' % top_n)
