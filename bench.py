@@ -179,11 +179,12 @@ def run_train(args, rank, local_rank, world, dev):
             quiet_step()
         quiet, _ = parallel.timed_steps(quiet_step, max(args.steps // 2, 5), torch.cuda.synchronize, dev)
         exposed = round((elapsed / args.steps - quiet / max(args.steps // 2, 5)) * 1e3, 3)
+    line = None
     if rank == 0:
         images = per_gpu * world * args.steps
         grad_bytes = sum(p.numel() * 4 for p in model.parameters() if p.requires_grad)
         line = {
-            'metric': 'images/sec training (fwd + FocalLoss/SmoothL1 + bwd + SGD), RN50FPN 800px, 2 img/GPU',
+            'metric': 'images/sec training (fwd + FocalLoss/SmoothL1 + bwd + SGD), %s %dpx, %d img/GPU' % (short_name(args.backbone), args.height, per_gpu),
             'value': round(images / elapsed, 2), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype,
@@ -196,9 +197,11 @@ def run_train(args, rank, local_rank, world, dev):
             'exposed_allreduce_ms': exposed, 'hip_kernels': hip_kernels,
             'loss': {'focal': round(float(both[0]), 5), 'box': round(float(both[1]), 5)},
         }
-        print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+    return line
+
+
+def short_name(backbone):
+    return backbone.replace('ResNet', 'RN').replace('ResNeXt', 'RNX')
 
 
 def main():
@@ -234,7 +237,12 @@ def main():
                     help="fused: sigmoid+decode+nms read the bf16 channels_last head tensors in place (3 launches); "
                          "reference: the reference's op sequence (sigmoid, .contiguous(), .float(), decode x5, cat, nms)")
     ap.add_argument('--no-fused-loss', action='store_true', help='train mode: torch losses instead of the HIP focal/smooth-L1 kernel')
+    ap.add_argument('--no-other-configs', action='store_true',
+                    help="default 1-GPU run: skip the legs for BASELINE.json's other configurations (`other_configs` on the line)")
+    ap.add_argument('--other-steps', type=int, default=20, help='timed steps of each other_configs leg')
     args = ap.parse_args()
+    default_run = all(getattr(args, k) == ap.get_default(k) for k in
+                      ('mode', 'backbone', 'batch', 'height', 'width', 'dtype', 'rotated_bbox', 'no_fuse', 'postproc', 'fraction'))
     if args.batch is None:
         args.batch = 8 if args.mode == 'infer' else 2
     if args.dtype is None:
@@ -249,10 +257,103 @@ def main():
     miopen_find = not args.no_miopen_find
     torch.backends.cudnn.benchmark = miopen_find
     if args.mode == 'train':
-        return run_train(args, rank, local_rank, world, dev)
+        line = run_train(args, rank, local_rank, world, dev)
+    else:
+        line = run_infer(args, rank, world, dev)
+        # BASELINE.json's other configurations behind the headline (1 GPU, default invocation only): RN101FPN bs 16 (config 4),
+        # --rotated-bbox bs 8 (config 5), the per-GPU share of config 3 (fp32 training, 2 images) and the batch-1 latency the
+        # reference publishes for its TensorRT engines (README.md:26-34; timing loop extras/cppapi/infer.cpp:69-77)
+        if world == 1 and rank == 0 and default_run and not args.no_other_configs:
+            line['other_configs'] = other_configs(args, rank, local_rank, world, dev)
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
 
+
+def leg_args(args, **over):
+    leg = copy.copy(args)
+    leg.steps, leg.warmup, leg.cpu_seconds, leg.no_eager_leg = args.other_steps, min(args.warmup, 5), 0.0, True
+    for k, v in over.items():
+        setattr(leg, k, v)
+    return leg
+
+
+def other_configs(args, rank, local_rank, world, dev):
+    legs = []
+
+    def run(name, fn):
+        t0 = time.perf_counter()
+        try:
+            line = fn()
+        except Exception as e:                                # a failing leg is reported, never hidden, and never takes the headline down
+            line = {'error': '%s: %s' % (type(e).__name__, e)}
+        line['leg'] = name
+        line['leg_wall_s'] = round(time.perf_counter() - t0, 1)
+        legs.append(line)
+        torch.cuda.empty_cache()
+        log('[bench] leg %s: %s' % (name, {k: line.get(k) for k in ('value', 'unit', 'ms_per_step', 'error', 'leg_wall_s')}))
+
+    run('config 4: ResNet101FPN bf16 inference bs 16', lambda: run_infer(leg_args(args, backbone='ResNet101FPN', batch=16), rank, world, dev))
+    run('config 5: ResNet50FPN --rotated-bbox bf16 inference bs 8', lambda: run_infer(leg_args(args, rotated_bbox=True), rank, world, dev))
+    run('config 5 with a unit (sin, cos) head bias', lambda: run_infer(leg_args(args, rotated_bbox=True, unit_rotation=True), rank, world, dev))
+    run('config 3 (per-GPU share): ResNet50FPN fp32 training, 2 images per GPU',
+        lambda: run_train(leg_args(args, mode='train', batch=2, dtype='fp32'), rank, local_rank, world, dev))
+    run('batch-1 latency: ResNet50FPN bf16', lambda: run_latency(leg_args(args, batch=1), dev))
+    return legs
+
+
+def run_latency(args, dev):
+    """Batch-1 latency of Model.forward, the figure the reference publishes for its TensorRT engines (README.md:26-34: RN50FPN
+    11 ms on A100, 18 ms on V100, fp16, bs 1, post-processing included).  Timed like its loop (extras/cppapi/infer.cpp:69-77):
+    one synchronous call after the other, wall time / count.  `graph`: the same call replayed as ONE hipGraph
+    (Model.forward(x, graph=True))."""
+    from odtk.model import Model
+    amp_dtype = {'bf16': torch.bfloat16, 'fp16': torch.float16, 'fp32': None}[args.dtype]
+    torch.manual_seed(0)
+    model = Model(backbones=args.backbone, classes=80, rotated_bbox=args.rotated_bbox)
+    model.initialize(None)
+    model = model.to(dev).to(memory_format=torch.channels_last).eval()
+    x = torch.randn(1, 3, args.height, args.width, generator=torch.Generator().manual_seed(0)).to(dev).contiguous(memory_format=torch.channels_last)
+    calibrate_cls_head(model, lambda t: model.inference_engine(amp_dtype or torch.float32).heads(t), x, args.fraction, model.threshold)
+
+    def step(graph):
+        with torch.no_grad(), torch.autocast('cuda', dtype=amp_dtype, enabled=amp_dtype is not None):
+            return model(x, graph=graph)
+
+    out = {}
+    count = 100
+    for name, graph in (('eager', False), ('graph', True)):
+        try:
+            for _ in range(10):
+                det = step(graph)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(count):
+                step(graph)
+                torch.cuda.synchronize()                     # one inference at a time, like engine->infer()
+            sync_ms = (time.perf_counter() - t0) / count * 1e3
+            t0 = time.perf_counter()
+            for _ in range(count):
+                step(graph)
+            torch.cuda.synchronize()
+            out[name] = {'latency_ms': round(sync_ms, 3), 'back_to_back_ms': round((time.perf_counter() - t0) / count * 1e3, 3),
+                         'detections': int((det[0] > 0).sum())}
+        except Exception as e:
+            out[name] = {'error': '%s: %s' % (type(e).__name__, e)}
+    best = min((v['latency_ms'] for v in out.values() if 'latency_ms' in v), default=None)
+    return {'metric': 'batch-1 latency end-to-end (incl. decode+NMS), %s %dpx' % (short_name(args.backbone), args.height),
+            'latency_bs1_ms': best, 'value': best, 'unit': 'ms', 'higher_is_better': False, 'dtype': args.dtype, 'iterations': count,
+            'eager': out.get('eager'), 'graph': out.get('graph'),
+            'reference_published_ms': {'A100 TensorRT fp16': 11, 'V100 TensorRT fp16': 18, 'source': 'reference README.md:33 (other hardware, not a baseline)'},
+            'config': {'workload': '%s %s inference, bs=1 at %dx%d, Model.forward (eval), one synchronous call at a time'
+                                   % (args.backbone, args.dtype, args.height, args.width)}}
+
+
+def run_infer(args, rank, world, dev):
     from odtk import _C
     from odtk.model import Model
+    miopen_find = not args.no_miopen_find
 
     amp_dtype = {'bf16': torch.bfloat16, 'fp16': torch.float16, 'fp32': None}[args.dtype]
     torch.manual_seed(0)
@@ -474,9 +575,10 @@ def main():
                                      {k: round(v, 2) for k, v in pipeline_trials.items()}),
                         'postproc': postproc}
 
+    line = None
     if rank == 0:
         line = {
-            'metric': 'images/sec end-to-end (incl. decode+NMS), RN50FPN 800px bs=8',
+            'metric': 'images/sec end-to-end (incl. decode+NMS), %s %dpx bs=%d' % (short_name(args.backbone), args.height, args.batch),
             'value': round(value, 2), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype,
@@ -499,9 +601,8 @@ def main():
             'eager': eager,
             'cpu_baseline': cpu_baseline,
         }
-        print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+    model.__dict__['_engine_cache'].clear()
+    return line
 
 
 if __name__ == '__main__':

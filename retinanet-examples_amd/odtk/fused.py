@@ -146,6 +146,7 @@ class FusedRetinaNet(nn.Module):
         self.level_streams = True                                       # small pyramid levels on side HIP streams
         self._streams = None
         self.tower_plan = 0
+        self._graphs = {}                                               # input geometry -> (hipGraph, static input, outputs)
 
     def features(self, x):
         x = self.stem.conv_then_pool(x)                                  # conv1 -> (bias + ReLU + maxpool, one pass)
@@ -228,6 +229,37 @@ class FusedRetinaNet(nn.Module):
             x = x.to(self.dtype).contiguous(memory_format=torch.channels_last)
             cls, box = self._towers(self.features(x), False)
         return cls, box, self.cls_head[-1].bias, self.box_head[-1].bias
+
+    @torch.no_grad()
+    def replay(self, x):
+        """`forward(x)` as ONE hipGraph (torch.cuda.CUDAGraph = hipGraph on ROCm): captured once per input geometry, then
+        only the input copy and the graph launch remain on the host -- the ~300 launches of a step are what a batch-1 call
+        costs.  Every buffer the captured kernels touch (activations, the binding's scratch, outputs) is allocated during the
+        capture and therefore owned by the graph; nothing cached outside it is referenced (odtk/_C.py:_workspace).  The
+        returned tensors are copies (the graph's own output buffers are overwritten by the next replay)."""
+        m = self.model[0]                                                # (post-processing parameters are baked into the launches)
+        key = (tuple(x.shape), x.dtype, x.device, x.is_contiguous(memory_format=torch.channels_last),
+               m.threshold, m.top_n, m.nms, m.detections, self.level_streams, self.tower_plan)
+        entry = self._graphs.get(key)
+        if entry is None:
+            static_x = torch.empty_like(x)
+            static_x.copy_(x)
+            # warm-up on a side stream (MIOpen find results, hipBLASLt plans, lazily created streams) -- capture must find
+            # nothing left to initialise
+            side = torch.cuda.Stream(x.device)
+            side.wait_stream(torch.cuda.current_stream(x.device))
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    self.forward(static_x)
+            torch.cuda.current_stream(x.device).wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = self.forward(static_x)
+            entry = self._graphs[key] = (graph, static_x, out)
+        graph, static_x, out = entry
+        static_x.copy_(x)
+        graph.replay()
+        return [o.clone() for o in out]
 
     @torch.no_grad()
     def forward(self, x):

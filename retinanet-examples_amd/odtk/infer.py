@@ -155,7 +155,13 @@ def infer(model, path, detections_file, resize, max_size, batch_size, mixed_prec
     if verbose:
         print('Preparing dataset...')
     iterator_class = RotatedDataIterator if rotated_bbox else DataIterator
-    device = torch.device('cuda', torch.cuda.current_device()) if torch.cuda.is_available() else torch.device('cpu')
+    # where the model lives decides (validation inside train(): the caller placed it, possibly on the CPU of a GPU host); a
+    # stand-alone call on a CPU-resident model moves it to the GPU when there is one, like the reference (infer.py:51-53)
+    param_device = next(net.parameters()).device
+    if param_device.type == 'cuda' or is_validation or not torch.cuda.is_available():
+        device = param_device
+    else:
+        device = torch.device('cuda', torch.cuda.current_device())
     data_iterator = iterator_class(path, resize, max_size, batch_size, net.stride, max(world, 1), annotations,
                                    training=False, device=device, num_workers=num_workers)
     if verbose:
@@ -187,7 +193,10 @@ def infer(model, path, detections_file, resize, max_size, batch_size, mixed_prec
 
     has_truth = 'annotations' in data_iterator.coco.dataset
     amp = mixed_precision and device.type == 'cuda'
-    with torch.autocast(device.type, dtype=torch.bfloat16, enabled=amp):
+    # mixed precision = fp16, as in the reference (apex O2 / torch.cuda.amp, infer.py:55-57): 10 mantissa bits; the eager graph
+    # under bf16 autocast lost 14 % of the logit amplitude, which is what a model without a fused engine
+    # (several backbones, MobileNetV2) would have run through
+    with torch.autocast(device.type, dtype=torch.float16, enabled=amp):
         detections = infer_batches(model, data_iterator, rotated_bbox=rotated_bbox,
                                    category_ids=(data_iterator.coco.getCatIds() or None) if has_truth else None,
                                    on_batch=progress)

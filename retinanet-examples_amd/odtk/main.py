@@ -154,7 +154,11 @@ def worker(rank, args, world, spawned=False):
         address, port = args.master.rsplit(':', 1)
         os.environ.update({'MASTER_ADDR': address, 'MASTER_PORT': port, 'WORLD_SIZE': str(world), 'RANK': str(rank)})
     if torch.cuda.is_available():
-        torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', rank)))
+        local = int(os.environ.get('LOCAL_RANK', rank))
+        if local >= torch.cuda.device_count():
+            raise RuntimeError('rank %d (local rank %d) has no GPU: this host has %d -- one process per GPU' % (
+                rank, local, torch.cuda.device_count()))
+        torch.cuda.set_device(local)
     if world > 1 and not torch.distributed.is_initialized():
         torch.distributed.init_process_group(backend='nccl' if torch.cuda.is_available() else 'gloo',
                                              init_method='env://', world_size=world, rank=rank)

@@ -159,6 +159,15 @@ class Model(nn.Module):
         self.__dict__['_engine_cache'].clear()              # .to() / .cuda() / .float(): new storages
         return super()._apply(fn, *args, **kwargs)
 
+    def train(self, mode=True):
+        self.__dict__['_engine_rescan'] = True              # next eval call re-reads WHICH tensors the model is made of
+        return super().train(mode)
+
+    def invalidate_engine(self):
+        """Drop the cached inference engine (and its hipGraphs).  Needed after weight changes the cache cannot see: writes
+        through `.data` (`p.data.copy_()`, EMA swaps -- a separate version counter) between two eval calls."""
+        self.__dict__['_engine_cache'].clear()
+
     def inference_engine(self, dtype):
         """The cached BN-folded engine for `dtype`; None when this model has no fused form (several
         backbones, exotic blocks).  The engine is a SNAPSHOT of the weights, so it remembers the tensors it
@@ -170,7 +179,14 @@ class Model(nn.Module):
         hit = cache.get(dtype)
         if hit is not None:
             tensors, stamp, engine = hit
-            if [t._version for t in tensors] + [t.data_ptr() for t in tensors] == stamp:
+            if self.__dict__.pop('_engine_rescan', False):
+                # after every train() / eval() switch: is the model still MADE OF the tensors the engine was folded from?
+                # (a replaced submodule or Parameter keeps the old objects alive in `tensors`, version and address unchanged).
+                # The module walk costs ~0.4 ms, so it is not repeated on every call; between two switches use invalidate_engine()
+                current = list(self.parameters()) + list(self.buffers())
+                if len(current) != len(tensors) or any(a is not b for a, b in zip(current, tensors)):
+                    hit = None
+            if hit is not None and [t._version for t in tensors] + [t.data_ptr() for t in tensors] == stamp:
                 return engine
         if not FusedRetinaNet.supports(self):
             return None
@@ -178,6 +194,7 @@ class Model(nn.Module):
         tensors = list(self.parameters()) + list(self.buffers())
         engine = FusedRetinaNet(self, dtype)
         cache[dtype] = (tensors, [t._version for t in tensors] + [t.data_ptr() for t in tensors], engine)
+        self.__dict__.pop('_engine_rescan', None)
         return engine
 
     # ------------------------------------------------------------------ forward
@@ -194,7 +211,11 @@ class Model(nn.Module):
         pyramid = [feature for backbone in self.backbones.values() for feature in backbone(x)]
         return [self.cls_head(f) for f in pyramid], [self.box_head(f) for f in pyramid]
 
-    def forward(self, x, rotated_bbox=None):
+    def forward(self, x, rotated_bbox=None, graph=False):
+        """Reference surface (model.py:131): training -> (cls_loss, box_loss) of (images, targets); eval -> (scores, boxes,
+        classes).  graph=True (eval on a GPU, opt-in): the whole call -- engine + post-processing, ~300 launches -- is captured
+        once per input geometry into ONE hipGraph and replayed (batch 1: launch-bound eager); the graph
+        belongs to the engine and goes with it when the weights change."""
         if self.training:
             images, targets = x
             cls_heads, box_heads = self.heads(images)
@@ -206,7 +227,10 @@ class Model(nn.Module):
             dtype = torch.get_autocast_dtype('cuda') if torch.is_autocast_enabled('cuda') else self.cls_head[0].weight.dtype
             engine = self.inference_engine(dtype)
             if engine is not None:
-                return engine(x)
+                return engine.replay(x) if graph else engine(x)
+        if graph:
+            raise RuntimeError('Model.forward(graph=True) needs the fused inference engine (eval mode, GPU tensors, a single '
+                               'ResNet-FPN backbone)')
 
         cls_heads, box_heads = self.heads(x)
         strides = [x.shape[-1] // c.shape[-1] for c in cls_heads]

@@ -158,7 +158,8 @@ def train_batches(model, state, batches, iterations, device, lr=0.01, warmup=100
         nonlocal interval, next_log, t_mark, n_mark, cls_sum, box_sum
         now = time.time()
         per_step = (now - t_mark) / max(n_mark, 1)
-        proposal = max(1, min(100000, int(round(log_every / max(per_step, 1e-6))))) if adaptive else interval
+        proposal = max(1, min(1000, int(round(log_every / max(per_step, 1e-6))))) if adaptive else interval   # the divergence test
+        # below runs once per interval (the reference: every step, train.py:132-138): never let it drift past 1000 steps
         both = reduce_losses(cls_sum / n_mark, box_sum / n_mark, world, proposal if rank == 0 else 0.0)
         cls_mean, box_mean, agreed = (float(v) for v in both)       # the only host sync of the interval
         if not math.isfinite(cls_mean + box_mean):

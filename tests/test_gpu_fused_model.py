@@ -107,3 +107,44 @@ def test_engine_on_a_128px_image_whose_p7_level_is_1x1():
         model.cls_head[-1].bias.add_(0.5)
         after = model(x)[0]
     assert not torch.equal(before, after)
+
+
+def test_engine_cache_follows_the_weights_cpu():
+    """what the cached engine notices (no GPU needed: engines are only built here, never run).
+    In-place updates (optimizer steps, load_state_dict) bump the version counter -> re-fold on the next call.  A REPLACED
+    Parameter / submodule keeps the old tensor objects alive in the cache with unchanged versions: caught by the module walk
+    that follows every train() / eval() switch, or by invalidate_engine(); writes through `.data` are invisible to both and
+    need invalidate_engine() (documented on the method)."""
+    torch.manual_seed(0)
+    model = Model('ResNet18FPN', classes=4)
+    model.initialize(None)
+    model.eval()
+    e1 = model.inference_engine(torch.float32)
+    assert model.inference_engine(torch.float32) is e1                       # unchanged weights: cache hit
+    with torch.no_grad():
+        model.cls_head[0].weight.mul_(1.5)                                   # in-place: version bump
+    e2 = model.inference_engine(torch.float32)
+    assert e2 is not e1
+    # a replaced layer, between two eval calls with no mode switch: NOT seen (documented) ...
+    old = model.box_head[0]
+    model.box_head[0] = nn.Conv2d(256, 256, 3, padding=1)
+    assert model.inference_engine(torch.float32) is e2
+    # ... seen after the next train() / eval() switch (what every training loop does before validating)
+    model.train()
+    model.eval()
+    e3 = model.inference_engine(torch.float32)
+    assert e3 is not e2
+    assert torch.equal(e3.box_head[0].weight.float(), model.box_head[0].weight.detach())
+    assert not torch.equal(e3.box_head[0].weight.float(), old.weight.detach())
+    assert model.inference_engine(torch.float32) is e3                       # the walk is not repeated on every call
+    # a replaced Parameter object
+    model.cls_head[2].weight = nn.Parameter(torch.zeros_like(model.cls_head[2].weight))
+    model.eval()
+    e4 = model.inference_engine(torch.float32)
+    assert e4 is not e3 and float(e4.cls_head[1].weight.abs().max()) == 0.0
+    # .data writes: invisible, the public hook drops the engine
+    model.cls_head[2].weight.data.fill_(0.25)
+    assert model.inference_engine(torch.float32) is e4
+    model.invalidate_engine()
+    e5 = model.inference_engine(torch.float32)
+    assert e5 is not e4 and float(e5.cls_head[1].weight.float().mean()) == 0.25

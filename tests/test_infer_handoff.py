@@ -1,12 +1,61 @@
-"""Detection hand-off (odtk/infer.py): the vectorised COCO conversion against a per-detection checker
-that follows the reference's loop (reference odtk/infer.py:111-148, odtk/utils.py:83-101) step by
-step, and the end-to-end `infer` driver on a stub model (CPU)."""
+"""Detection hand-off (odtk/infer.py): the vectorised COCO conversion against
+  (1) fixtures produced by the REFERENCE's OWN per-detection loop (odtk/infer.py:104-148 + utils.py:83-101, lifted out of
+      its module and executed by oracle/gen_golden_handoff.py; tests/golden/handoff_*.{npz,json}), re-generated live when
+      /root/reference is present,
+  (2) a per-detection restatement of that loop on further seeded inputs,
+and the end-to-end `infer` driver on a stub model (CPU)."""
+import glob
 import json
+import os
 
 import numpy as np
+import pytest
 import torch
 
 from odtk import infer, parallel
+
+GOLDEN = os.path.join(os.path.dirname(__file__), 'golden')
+
+
+def _same_detections(got, ref, rotated):
+    assert len(got) == len(ref)
+    for g, r in zip(got, ref):
+        assert (g['image_id'], g['score'], g['category_id']) == (r['image_id'], r['score'], r['category_id'])
+        assert g['bbox'][:4] == r['bbox'][:4]                         # doubles, bit for bit
+        if rotated:
+            assert abs(g['bbox'][4] - r['bbox'][4]) <= 1e-15
+            assert np.allclose(g['segmentation'][0], r['segmentation'][0], rtol=0, atol=1e-9)   # matmul order / FMA
+            assert set(g) == set(r) == {'image_id', 'score', 'category_id', 'bbox', 'segmentation'}
+        else:
+            assert set(g) == set(r) == {'image_id', 'score', 'category_id', 'bbox'}
+
+
+@pytest.mark.parametrize('path', sorted(glob.glob(os.path.join(GOLDEN, 'handoff_*.npz'))), ids=os.path.basename)
+def test_coco_conversion_equals_the_references_own_loop(path):
+    """Fixtures = output of the reference's loop itself (not of a restatement)."""
+    z = np.load(path)
+    ref = json.load(open(path[:-4] + '.json'))
+    rotated = bool(z['rotated'])
+    cats = z['category_ids'].tolist() or None
+    args = [torch.from_numpy(z[k]) for k in ('scores', 'boxes', 'classes', 'ids', 'ratios')]
+    got = infer.detections_to_coco(*args, rotated_bbox=rotated, category_ids=cats)
+    assert len(ref) > 40
+    _same_detections(got, ref, rotated)
+    if not rotated:
+        assert json.dumps(got) == json.dumps(ref)                     # ... and so is the file the reference would write
+
+
+@pytest.mark.skipif(not os.path.isdir('/root/reference/odtk'), reason='reference tree not present (GPU box)')
+@pytest.mark.parametrize('rotated,seed,cats', [(False, 11, None), (True, 12, None), (False, 13, list(range(7, 87))), (True, 14, list(range(80)))])
+def test_coco_conversion_equals_the_reference_loop_run_live(rotated, seed, cats):
+    from oracle import gen_golden_handoff as G
+    run = G.reference_loop()
+    args = G.fake_results(8, 25, rotated, seed)
+    ref = run(args, rotated, cats)
+    for det in ref:
+        det['bbox'] = [float(v) for v in det['bbox']]
+    got = infer.detections_to_coco(*args, rotated_bbox=rotated, category_ids=cats)
+    _same_detections(got, ref, rotated)
 
 
 def _reference_loop(scores, boxes, classes, ids, ratios, rotated):
