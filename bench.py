@@ -351,7 +351,7 @@ def run_latency(args, dev):
 
 
 def run_infer(args, rank, world, dev):
-    from odtk import _C
+    from odtk import _C, parallel
     from odtk.model import Model
     miopen_find = not args.no_miopen_find
 

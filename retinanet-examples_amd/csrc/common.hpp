@@ -78,6 +78,17 @@ __device__ __forceinline__ float tmin_nan(float a, float b) { return (a < b || a
 // 1 ulp of this (measured: 1.1 % of inputs differ, by exactly 1 ulp) -- see DESIGN.md "exp".
 __device__ __forceinline__ float exp_cr(float x) { return static_cast<float>(exp(static_cast<double>(x))); }
 
+// A value that is the same in every lane, moved to scalar registers.  Values read from LDS (or derived from them) are
+// "divergent" to the compiler and live in VGPRs even when every lane holds the same number; block-wide state that stays
+// alive across register-hungry code (the polygon clip) belongs in SGPRs.
+__device__ __forceinline__ uint64_t uniform_u64(uint64_t v) {
+  const uint32_t lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v));
+  const uint32_t hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v >> 32));
+  return (static_cast<uint64_t>(hi) << 32) | lo;
+}
+template <typename T>
+__device__ __forceinline__ T *uniform_ptr(T *p) { return reinterpret_cast<T *>(uniform_u64(reinterpret_cast<uint64_t>(p))); }
+
 // Zero fill of a 16-byte aligned region (workspace counters / selection state), grid-stride.
 __global__ __launch_bounds__(256) void clear_kernel(uint4 *p, size_t n) {
   const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;

@@ -8,34 +8,46 @@
 // Semantics are the CPU path's (box.py:326-365): candidates `score > 0`, ordered score desc /
 // position asc, +1 pixel IoU, a box survives iff no higher-ranked KEPT box of the same class has
 // IoU > thresh with it (`!(iou <= thresh)`), stop after `ndetections` kept boxes.
-// IoU arithmetic is written in box.py's operation order (-ffp-contract=off).
+// IoU arithmetic is written in box.py's operation order (-ffp-contract=off); the rotated IoU follows
+// csrc/cuda/nms_iou.cu:114-248 (rotated_iou.hpp).
 //
 // Why this shape.  The reference (and a straightforward port) lets every kept box "push"
 // suppression onto all later boxes: count x kept IoU evaluations and one barrier per kept box, even
 // though only the first `ndetections` survivors are emitted.  Here the boxes are consumed lazily, in
 // score order, and each candidate "pulls" against the boxes kept so far:
-//   round    : the next 1024 best keys are radix-selected out of the LDS-resident key list and
-//              sorted (bitonic, 1 key per thread) -- a full sort of all candidates never happens
-//              unless the greedy scan really needs them all.
-//   chunk    : 64 candidates (lane <-> candidate).  (1) all 16 waves test the SAME 64 candidates,
-//              each against its own 1/16 slice of the kept list (a candidate's <= ndetections IoU
-//              tests run on 16 threads); (2) wave 0 ANDs the 16 verdict words and resolves the
-//              survivors sequentially with ballot / v_readlane -- registers only, no barrier inside.
-// Typical inputs (100 detections found among the first few hundred candidates) finish in one round
-// and one or two chunks; the worst case (all one class, heavy suppression) is bounded by
-// count/64 chunks x (<= ndetections/16 IoU tests per thread + 2 barriers).
+//   round    : the next (up to) 1024 best candidates, in order.
+//              generic input : radix-selected out of the LDS-resident key list and sorted (bitonic);
+//              sorted runs   : (odtk_detect) the input is decode_levels' output, per level a list already in NMS
+//                              order: the round is a prefix of every run, found by probing 1024 / n_runs slots per
+//                              run, and its order comes from RANKS -- a key's rank is its own slot plus, per other
+//                              run, a binary search -- not from a sort (round 3; the sort was 7 of the kernel's 29 us).
+//   chunk    : 64 candidates (lane <-> candidate).
+//              axis-aligned  : (1) all 16 waves test the SAME 64 candidates, each against its own 1/16 slice of the
+//                              kept list, and compute the chunk's pairwise suppression rows; (2) wave 0 resolves the
+//                              64 in rank order with scalar bit arithmetic.
+//              rotated       : the polygon clip costs ~1000 wave instructions, so pairs are never evaluated where a
+//                              lane happens to sit: every (kept box | earlier candidate, candidate) pair that shares
+//                              a class and survives the cheap distance reject is APPENDED to a work queue in LDS, and
+//                              the queue is drained densely, one pair per thread -- one clip call site in the kernel,
+//                              no idle lanes beside a busy one, pull first and suppression rows only among the
+//                              candidates the pull left alive.
+//   filter   : when a round's yield says that every remaining candidate will have to be examined anyway (heavy
+//              suppression: 2236 candidates for 9 kept boxes took eleven rounds), all of them are tested against the
+//              whole kept list at once (1024 at a time, in parallel) and only the survivors stay listed.
 #pragma once
 
 #include "common.hpp"
 #include "rotated_iou.hpp"
-#include "select_decode.hpp"   // radix_threshold, sort_keys_desc
+#include "select_decode.hpp"   // range_threshold, sort_keys_desc
 #include "../../include/odtk_hip.h"
 
 namespace odtk {
 
 constexpr int kNmsThreads = 1024;
-constexpr int kNmsRound = 1024;        // keys selected + sorted per round (one per thread)
+constexpr int kNmsRound = 1024;        // keys selected + ordered per round (one per thread)
 constexpr int kNmsChunk = 64;          // candidates resolved per chunk: one wave-width
+constexpr int kPairQueue = kRadixBins; // rotated: (box, box) pairs per queue slab -- the queue lives in the histogram's 8 KiB
+constexpr int kNmsMisc = 160;          // words of s_misc
 
 struct NmsArgs {
   uint64_t *key_scratch;   // [batch, count] keys in the workspace when count > ODTK_MAX_NMS_COUNT (else unused)
@@ -49,34 +61,43 @@ struct NmsArgs {
   uint32_t count;
   uint32_t run_len;        // != 0: the `count` candidates of an image are count / run_len runs, each sorted by (score desc,
                            // position asc) with its non-positive scores at the end -- what decode_levels writes.  odtk_detect
-                           // sets it; the stand-alone nms entry points (arbitrary input) leave it 0.
+                           // sets it (together with run_valid); the stand-alone nms entry points (arbitrary input) leave it 0.
+  const uint32_t *run_valid;   // [batch, count / run_len]: entries with a positive score at the head of every run (select_decode)
   int ndet;
   float thresh;
   uint32_t flags;
   unsigned long long *trace;   // debug (odtk_debug_set_trace): 8 timestamps per workgroup, or null
 };
 
-// LDS carve-up shared by host (size) and device (pointers); every offset is 16-byte aligned.
+// LDS carve-up shared by host (size) and device (pointers); every offset is 16-byte aligned.  The regions of fixed size
+// come first, at compile-time offsets (no scalar register per pointer -- the kernel is short of them); the ones that
+// depend on detections_per_im / count follow.
+template <int NB>
+struct NmsFixedLds {
+  static constexpr size_t sel = 0;                                             // the round's keys, in order
+  static constexpr size_t box = sel + kNmsRound * 8;                           // ... their boxes
+  static constexpr size_t cls = box + static_cast<size_t>(kNmsRound) * NB * 4;   // ... and classes
+  static constexpr size_t hist = cls + kNmsRound * 4;                          // range_threshold's histogram | sorted-run windows | pair queue
+  static constexpr size_t misc = hist + kRadixBins * 4;
+  static constexpr size_t sup = misc + kNmsMisc * 4;                           // suppression words of the current chunk
+  static constexpr size_t end = sup + kNmsChunk * 8;
+  static_assert(end % 16 == 0, "16-byte aligned regions");
+};
+
 struct NmsLds {
   static constexpr size_t kLdsBudget = 160 * 1024;
-  size_t keys, sel, box, cls, kbox, kcls, kscore, ksrc, hist, misc, sup, clip, total;
-  int ways;     // waves that take part in the pull phase
+  size_t kbox, kcls, kscore, ksrc, keys, clip, total;
+  int ways;     // waves that evaluate box pairs
   __host__ __device__ NmsLds(uint32_t count, int ndet, int nb, bool global_keys = false) {
     auto up = [](size_t v) { return (v + 15) & ~static_cast<size_t>(15); };
-    size_t o = 0;
-    keys = o;   o += global_keys ? 0 : up(static_cast<size_t>(count) * 8);
-    sel = o;    o += up(kNmsRound * 8);
-    box = o;    o += up(static_cast<size_t>(kNmsRound) * nb * 4);
-    cls = o;    o += up(kNmsRound * 4);
+    size_t o = nb == 6 ? NmsFixedLds<6>::end : NmsFixedLds<4>::end;
     kbox = o;   o += up(static_cast<size_t>(ndet) * nb * 4);
     kcls = o;   o += up(static_cast<size_t>(ndet) * 4);
     kscore = o; o += up(static_cast<size_t>(ndet) * 4);
     ksrc = o;   o += up(static_cast<size_t>(ndet) * 4);
-    hist = o;   o += up(kRadixBins * 4);
-    misc = o;   o += up(112 * 4);
-    sup = o;    o += up(kNmsChunk * 8);                     // suppression words of the current chunk
-    // rotated IoU: one lane-private polygon region (4 KiB, rotated_iou.hpp) per wave that takes part
-    // in the pull phase: as many of the 16 waves as the 160 KiB budget allows
+    keys = o;   o += global_keys ? 0 : up(static_cast<size_t>(count) * 8);
+    // rotated IoU: one lane-private polygon region (4 KiB, rotated_iou.hpp) per wave that evaluates pairs: as many of
+    // the 16 waves as the 160 KiB budget allows
     clip = o;
     ways = 16;
     if (nb == 6) {
@@ -111,20 +132,12 @@ __device__ __forceinline__ bool axis_suppresses(const float *m, const float *j, 
   return !(iou <= thr);
 }
 
-template <int NB, bool kReject = true>
-__device__ __forceinline__ bool box_suppresses(const float *m, const float *j, float thr, bool own_angle, float2 *q) {
-  if constexpr (NB == 4) return axis_suppresses(m, j, thr);
-  else return rotated_suppresses<kReject>(m, j, thr, own_angle, q);
-}
-
-// Does any box kept at ranks q0, q0 + step, ... (< q1) suppress candidate (jb, jc)?  Class words are
+// Axis-aligned: does any box kept at ranks q0, q0 + step, ... (< q1) suppress candidate (jb, jc)?  Class words are
 // fetched eight at a time (independent LDS reads) -- the common case is "no kept box of this class",
 // and a one-read-per-trip loop would pay the LDS latency once per kept box.
-template <int NB>
 __device__ __forceinline__ bool pull_against_kept(const float *s_kcls, const float *s_kbox, int q0, int q1, int step,
-                                                  const float *jb, float jc, bool alive, float thr, bool own_angle,
-                                                  float2 *clip) {
-  constexpr int kBatch = NB == 6 ? 2 : 8;        // rotated: the IoU + its reject need the registers (8 spills, 2 does not)
+                                                  const float *jb, float jc, bool alive, float thr) {
+  constexpr int kBatch = 8;
   for (int q = q0; q < q1 && alive; q += kBatch * step) {
     float kc[kBatch];
 #pragma unroll
@@ -132,10 +145,10 @@ __device__ __forceinline__ bool pull_against_kept(const float *s_kcls, const flo
 #pragma unroll
     for (int u = 0; u < kBatch; ++u) {
       if (alive && kc[u] == jc) {                               // box.py:351: a different class keeps
-        float mb[NB];
+        float mb[4];
 #pragma unroll
-        for (int k = 0; k < NB; ++k) mb[k] = s_kbox[(q + u * step) * NB + k];
-        if (box_suppresses<NB>(mb, jb, thr, own_angle, clip)) alive = false;
+        for (int k = 0; k < 4; ++k) mb[k] = s_kbox[(q + u * step) * 4 + k];
+        if (axis_suppresses(mb, jb, thr)) alive = false;
       }
     }
   }
@@ -155,6 +168,21 @@ struct LdsKeySource {   // keys of this image that rank below `upper` (exclusive
   }
 };
 
+// #{i < n : A[i] > x} (kStrict) or #{A[i] >= x} for a descending-sorted A, by binary lifting with a block-uniform trip
+// count (p2 = a power of two >= n): every lane runs the same log2(p2) + 1 steps whatever its n.
+template <bool kStrict>
+__device__ __forceinline__ uint32_t count_above(const uint64_t *A, uint32_t n, uint64_t x, uint32_t p2) {
+  uint32_t lo = 0;
+  for (uint32_t s = p2; s > 0; s >>= 1) {
+    const uint32_t at = lo + s;
+    if (at <= n) {
+      const uint64_t v = A[at - 1];
+      if (kStrict ? v > x : v >= x) lo = at;
+    }
+  }
+  return lo;
+}
+
 // kGlobalKeys: more candidates than the LDS holds (count > ODTK_MAX_NMS_COUNT): the key list of an image lives in the
 // caller's workspace instead; rounds then walk it out of L2 -- slower, same result.
 template <int NB, bool kGlobalKeys = false>
@@ -163,21 +191,28 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsArgs a) {
   const NmsLds lay(a.count, a.ndet, NB, kGlobalKeys);
   uint64_t *s_keys = kGlobalKeys ? a.key_scratch + static_cast<size_t>(blockIdx.x) * a.count
                                  : reinterpret_cast<uint64_t *>(smem + lay.keys);
-  uint64_t *s_sel = reinterpret_cast<uint64_t *>(smem + lay.sel);
-  float *s_box = reinterpret_cast<float *>(smem + lay.box);
-  float *s_cls = reinterpret_cast<float *>(smem + lay.cls);
+  using Fixed = NmsFixedLds<NB>;
+  uint64_t *s_sel = reinterpret_cast<uint64_t *>(smem + Fixed::sel);
+  float *s_box = reinterpret_cast<float *>(smem + Fixed::box);
+  float *s_cls = reinterpret_cast<float *>(smem + Fixed::cls);
   float *s_kbox = reinterpret_cast<float *>(smem + lay.kbox);
   float *s_kcls = reinterpret_cast<float *>(smem + lay.kcls);
   float *s_kscore = reinterpret_cast<float *>(smem + lay.kscore);
   int32_t *s_ksrc = reinterpret_cast<int32_t *>(smem + lay.ksrc);
-  uint32_t *s_hist = reinterpret_cast<uint32_t *>(smem + lay.hist);
-  uint32_t *s_misc = reinterpret_cast<uint32_t *>(smem + lay.misc);
-  // s_misc: [0..31] radix_select scratch, [32] key count, [33] gather cursor, [34] kept count,
-  //         [40..71] verdict words of the pull phase (16 x 64 bits); [40..103] min / max keys per wave before the first round
-  //         (generic mode); [72..111] per-run valid counts, cursors, member counts, probe keys (sorted-run mode)
+  uint32_t *s_hist = reinterpret_cast<uint32_t *>(smem + Fixed::hist);
+  uint32_t *s_misc = reinterpret_cast<uint32_t *>(smem + Fixed::misc);
+  // s_misc: [0..31] range_threshold scratch, [32] length of the key list, [33] gather cursor, [34] kept count,
+  //         [35..36] pair-queue lengths (two, used alternately), [37] survivors of a filter pass,
+  //         [40..71] verdict words of the axis-aligned pull (16 x 64 bits); [40..103] min / max keys per wave (generic mode,
+  //         between rounds), [72..111] per-run valid counts, cursors, member counts, probe keys (sorted-run mode),
+  //         [112..143] dead bits of the round's 1024 candidates (rotated), [144..147] smallest / largest key of the list,
+  //         [148..155] output pointers
   uint64_t *s_alive = reinterpret_cast<uint64_t *>(s_misc + 40);
-  uint64_t *s_sup = reinterpret_cast<uint64_t *>(smem + lay.sup);
+  uint32_t *s_dead = s_misc + 112;
+  uint64_t *s_sup = reinterpret_cast<uint64_t *>(smem + Fixed::sup);
   float2 *s_clip = reinterpret_cast<float2 *>(smem + lay.clip);     // rotated only
+  uint64_t *s_win = reinterpret_cast<uint64_t *>(s_hist);           // sorted-run mode: the runs' probed slots
+  uint32_t *s_queue = s_hist;                                       // rotated: pair queue (chunk phase; never while a round is selected)
   const int ways = lay.ways;
 
   const int tid = threadIdx.x;
@@ -190,45 +225,68 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsArgs a) {
   const int ndet = a.ndet;
   const float thr = a.thresh;
   const bool own_angle = (a.flags & ODTK_FLAG_ROTATED_NMS_FIXED_ANGLE) != 0;
-  const float *in_s = a.scores + static_cast<size_t>(img) * count;
-  const float *in_b = a.boxes + static_cast<size_t>(img) * count * NB;
-  const float *in_c = a.classes + static_cast<size_t>(img) * count;
+  const float *in_s = uniform_ptr(a.scores + static_cast<size_t>(img) * count);
+  const float *in_b = uniform_ptr(a.boxes + static_cast<size_t>(img) * count * NB);
+  const float *in_c = uniform_ptr(a.classes + static_cast<size_t>(img) * count);
+  auto stamp = [&](int k) { if (a.trace && tid == 0) a.trace[(gridDim.x + blockIdx.x) * 8 + k] = wall_clock64(); };
 
-  // ---- compact positive-score candidates into 64-bit (score, ~position) keys ----
-  if (tid == 0) { s_misc[32] = 0; s_misc[34] = 0; }
-  __syncthreads();
+  if (tid == 0) { s_misc[32] = 0; s_misc[34] = 0; s_misc[35] = 0; s_misc[36] = 0; }
+  // the output pointers are needed once, at the very end: parked in LDS (s_misc[148..155]) they do not occupy scalar
+  // registers -- which this kernel is short of -- for its whole run
+  uint64_t *s_out = reinterpret_cast<uint64_t *>(s_misc + 148);
+  if (tid == 0) {
+    s_out[0] = reinterpret_cast<uint64_t>(a.out_scores); s_out[1] = reinterpret_cast<uint64_t>(a.out_boxes);
+    s_out[2] = reinterpret_cast<uint64_t>(a.out_classes); s_out[3] = reinterpret_cast<uint64_t>(a.out_indices);
+  }
   // Sorted-run mode (odtk_detect): the input is what decode_levels wrote -- n_runs lists of run_len candidates, each already
-  // in NMS order.  The k best candidates overall are then prefixes of the runs: a round is found by looking at `step` slots
-  // per run (below) and neither the key list, nor the min / max pass, nor the radix selection are needed (measured before:
-  // compaction 1.8 + selection 10.8 us of the kernel's 36).
-  const uint32_t n_runs = a.run_len ? count / a.run_len : 0;
+  // in NMS order, `run_valid` of them with a positive score.  The best candidates overall are then prefixes of the runs: no
+  // key list, no min / max pass, no radix selection, no sort (until a filter pass turns what is left into a key list).
   static_assert(ODTK_MAX_LEVELS <= 8, "the sorted-run state (s_misc[72..111]) holds 8 runs; run_len is set by odtk_detect only");
-  const bool runs = a.run_len >= 64 && n_runs * a.run_len == count && n_runs >= 1 && n_runs <= 8;   // block-uniform
+  const uint32_t n_runs = a.run_len ? count / a.run_len : 0;
+  bool runs = a.run_valid && a.run_len >= 64 && n_runs * a.run_len == count && n_runs >= 1 && n_runs <= 8;   // block-uniform
   uint32_t *s_valid = s_misc + 72, *s_cursor = s_misc + 80, *s_members = s_misc + 88;   // per run (s_misc[72..95])
   uint64_t *s_probe = reinterpret_cast<uint64_t *>(s_misc + 96);                       // per run (s_misc[96..111])
-  // adds `n` to counter[run] for the lanes with pred, one LDS atomic per (wave, run): a wave's 64 consecutive slots touch
-  // at most two runs (run_len, step >= 64)
-  auto count_per_run = [&](uint32_t *counter, bool pred, uint32_t run) {
-    const uint64_t m = __ballot(pred);
-    if (!m) return;
-    const uint32_t r0 = __shfl(run, __ffsll(static_cast<unsigned long long>(m)) - 1, kWave);
-    const uint64_t m0 = __ballot(pred && run == r0), m1 = m & ~m0;
-    if (lane == 0) {
-      atomicAdd(&counter[r0], static_cast<uint32_t>(__popcll(m0)));
-      if (m1) atomicAdd(&counter[r0 + 1], static_cast<uint32_t>(__popcll(m1)));
+  uint32_t list_n = 0;               // generic mode: keys in s_keys; their range [k_lo, k_hi] is parked in s_misc[144..147]
+  uint64_t *s_range = reinterpret_cast<uint64_t *>(s_misc + 144);
+  // smallest / largest key of the list: the round selection cuts THAT range (fp32 scores of one image share their exponent
+  // bits; an MSD digit needed two passes, 9.9 us, to isolate the first 256..1024 keys)
+  auto key_range = [&]() {
+    uint64_t k_lo = ~0ull, k_hi = 0;
+    for (uint32_t i = tid; i < list_n; i += kNmsThreads) {
+      const uint64_t k = s_keys[i];
+      k_lo = k < k_lo ? k : k_lo;
+      k_hi = k > k_hi ? k : k_hi;
     }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+      const uint64_t o1 = shfl_xor_u64(k_lo, d), o2 = shfl_xor_u64(k_hi, d);
+      k_lo = o1 < k_lo ? o1 : k_lo;
+      k_hi = o2 > k_hi ? o2 : k_hi;
+    }
+    __syncthreads();                                         // (s_misc[40..103] may still be read as verdict words)
+    if (lane == 0) { s_alive[wave] = k_lo; s_alive[16 + wave] = k_hi; }
+    __syncthreads();
+    for (int w = 0; w < kNmsThreads / kWave; ++w) {
+      k_lo = s_alive[w] < k_lo ? s_alive[w] : k_lo;
+      k_hi = s_alive[16 + w] > k_hi ? s_alive[16 + w] : k_hi;
+    }
+    if (tid == 0) { s_range[0] = k_lo; s_range[1] = k_hi; }
+    __syncthreads();
   };
+
+  uint32_t left = 0;                 // candidates not yet handed to a round (block-uniform)
   if (runs) {
-    if (tid < 8) { s_valid[tid] = 0; s_cursor[tid] = 0; }
-    __syncthreads();
-    for (uint32_t i0 = 0; i0 < count; i0 += kNmsThreads) {
-      const uint32_t i = i0 + tid;
-      const float sc = i < count ? in_s[i] : 0.0f;
-      count_per_run(s_valid, sc > 0.0f, i < count ? i / a.run_len : 0);   // box.py:328  score > 0 (NaN fails)
+    if (tid < 8) {
+      const uint32_t v = static_cast<uint32_t>(tid) < n_runs ? a.run_valid[static_cast<size_t>(img) * n_runs + tid] : 0u;
+      s_valid[tid] = v < a.run_len ? v : a.run_len;
+      s_cursor[tid] = 0;
     }
     __syncthreads();
-    if (tid == 0) { uint32_t k = 0; for (uint32_t l = 0; l < n_runs; ++l) k += s_valid[l]; s_misc[32] = k; }
+    for (uint32_t l = 0; l < n_runs; ++l) left += s_valid[l];
+    left = __builtin_amdgcn_readfirstlane(left);
   } else {
+    __syncthreads();
+    // ---- compact positive-score candidates into 64-bit (score, ~position) keys ----
     auto compact = [&](float sc, uint32_t i) {                // wave-uniform call sites
       const bool pos = sc > 0.0f;                             // box.py:328  score > 0 (NaN fails)
       const uint64_t m = __ballot(pos);
@@ -254,101 +312,178 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsArgs a) {
       }
   #pragma unroll
       for (int u = 0; u < kScoreLoads; ++u) {
-        if (u * kNmsThreads >= count) break;                    // block-uniform
-        compact(my_scores[u], u * kNmsThreads + tid);
+        if (static_cast<uint32_t>(u) * kNmsThreads < count) compact(my_scores[u], u * kNmsThreads + tid);   // block-uniform
       }
     }
+    __syncthreads();
+    list_n = __builtin_amdgcn_readfirstlane(s_misc[32]);   // (LDS values are VGPRs to the compiler: pin loop-control scalars to SGPRs)
+    left = list_n;
   }
-  __syncthreads();
-  const uint32_t K = __builtin_amdgcn_readfirstlane(s_misc[32]);   // (LDS values are VGPRs to the compiler: pin loop-control scalars to SGPRs)
-  auto stamp = [&](int k) { if (a.trace && tid == 0) a.trace[(gridDim.x + blockIdx.x) * 8 + k] = wall_clock64(); };
+  const uint32_t K = left;
   stamp(1);
+  if (!runs) key_range();
 
-  // smallest / largest key of the image: the round selection below cuts THAT range (fp32 scores of one image share their
-  // exponent bits; an MSD digit needed two passes, 9.9 us, to isolate the first 256..1024 keys)
-  uint64_t k_lo = ~0ull, k_hi = 0;
-  if (!runs) {                       // (block-uniform; the sorted-run mode needs neither and keeps its state in s_misc[72..])
-  for (uint32_t i = tid; i < K; i += kNmsThreads) {
-    const uint64_t k = s_keys[i];
-    k_lo = k < k_lo ? k : k_lo;
-    k_hi = k > k_hi ? k : k_hi;
-  }
-#pragma unroll
-  for (int d = 32; d > 0; d >>= 1) {
-    const uint64_t o1 = shfl_xor_u64(k_lo, d), o2 = shfl_xor_u64(k_hi, d);
-    k_lo = o1 < k_lo ? o1 : k_lo;
-    k_hi = o2 > k_hi ? o2 : k_hi;
-  }
-  if (lane == 0) { s_alive[wave] = k_lo; s_alive[16 + wave] = k_hi; }   // (s_misc[40..103]: the verdict words are not in use yet)
-  __syncthreads();
-  for (int w = 0; w < kNmsThreads / kWave; ++w) {
-    k_lo = s_alive[w] < k_lo ? s_alive[w] : k_lo;
-    k_hi = s_alive[16 + w] > k_hi ? s_alive[16 + w] : k_hi;
-  }
-  __syncthreads();
-  }
-
-  uint32_t consumed = 0;             // candidates handed to earlier rounds
-  uint64_t upper = ~0ull;            // keys >= upper were consumed
+  uint32_t examined = 0;             // candidates handed to rounds so far (debug trace)
+  uint64_t upper = ~0ull;            // generic mode: keys >= upper were consumed
   int kept = 0;                      // block-uniform copy of s_misc[34]
+  int pulled = 0;                    // every candidate still listed is known to survive the boxes kept at ranks < pulled
+  bool first_round = true;
 
-  while (consumed < K && kept < ndet) {
-    // ---- round: select + sort the next (up to) 1024 best keys ----
-    const uint32_t left = K - consumed;
-    uint32_t n_round = left;
-    uint64_t lower = 0;
+  // ---- rotated: box pairs through the queue (the ONE place of the kernel that clips polygons) ----
+  // Candidates are the round's ranks r0 .. r0 + n - 1 (boxes / classes staged in s_box / s_cls); `rows` = false: against
+  // the kept boxes at ranks ka .. kb - 1, a suppressed candidate gets its dead bit; `rows` = true (n <= 64): candidate
+  // pairs (i < j) inside the chunk, both alive, the verdict is bit j of suppression row i.  Slabs of kPairQueue (box, box)
+  // combinations are filtered (class, dead bit, distance reject) into the queue, then drained one pair per thread.
+  uint32_t q_parity = 0;
+  auto pair_phase = [&](bool rows, uint32_t r0, uint32_t n, int ka, int kb) {
+    if constexpr (NB == 6) {
+      const uint32_t n_a = rows ? n : static_cast<uint32_t>(kb - ka);
+      const uint32_t combos = n_a * n;
+      float2 *clip = s_clip + static_cast<size_t>(wave) * kClipSlotsPerWave + lane;
+      for (uint32_t e0 = 0; e0 < combos; e0 += kPairQueue, q_parity ^= 1u) {
+        const uint32_t parity = q_parity;
+        // two queue counters, used by consecutive slabs in turn -- across calls too: a slab clears the one its successor will
+        // use (last read before the previous slab's closing barrier, next touched after this slab's barriers)
+        if (tid == 0) s_misc[35 + (parity ^ 1u)] = 0;
+#pragma unroll
+        for (int u = 0; u < kPairQueue / kNmsThreads; ++u) {
+          const uint32_t e = e0 + static_cast<uint32_t>(u) * kNmsThreads + tid;
+          const uint32_t ai = e / n, ji = e - ai * n;          // (n = 64 or 1024 on the hot paths: `ai` is wave-uniform there)
+          const uint32_t r = r0 + ji;
+          bool want = e < combos && !((s_dead[r >> 5] >> (r & 31u)) & 1u);
+          uint32_t entry = 0;
+          if (want) {
+            const float *jb = s_box + static_cast<size_t>(r) * 6;
+            if (rows) {
+              const uint32_t ri = r0 + ai;
+              want = ai < ji && !((s_dead[ri >> 5] >> (ri & 31u)) & 1u) && s_cls[ri] == s_cls[r] &&
+                     !rotated_far_apart(s_box + static_cast<size_t>(ri) * 6, jb, thr, own_angle);
+              entry = 0x80000000u | (ri << 10) | r;
+            } else {
+              const uint32_t k = static_cast<uint32_t>(ka) + ai;
+              want = s_kcls[k] == s_cls[r] && !rotated_far_apart(s_kbox + static_cast<size_t>(k) * 6, jb, thr, own_angle);
+              entry = (k << 10) | r;
+            }
+          }
+          const uint32_t slot = wave_append_slot(&s_misc[35 + parity], want);
+          if (want) s_queue[slot] = entry;
+        }
+        __syncthreads();
+        const uint32_t n_q = s_misc[35 + parity];
+        if (wave < ways) {
+          for (uint32_t q = static_cast<uint32_t>(tid); q < n_q; q += static_cast<uint32_t>(ways) * kWave) {
+            const uint32_t entry = s_queue[q];
+            const uint32_t r = entry & 1023u, ai = (entry >> 10) & 2047u;
+            const bool is_row = (entry >> 31) != 0;
+            const float *mp = (is_row ? s_box : s_kbox) + static_cast<size_t>(ai) * 6;
+            float mb[6], jb[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) { mb[k] = mp[k]; jb[k] = s_box[static_cast<size_t>(r) * 6 + k]; }
+            if (rotated_suppresses(mb, jb, thr, own_angle, clip)) {
+              if (is_row) {
+                const uint32_t bit = r - r0;                 // row ai - r0 (< 64), column r - r0
+                atomicOr(reinterpret_cast<uint32_t *>(s_sup + (ai - r0)) + (bit >> 5), 1u << (bit & 31u));
+              } else {
+                atomicOr(&s_dead[r >> 5], 1u << (r & 31u));
+              }
+            }
+          }
+        }
+        __syncthreads();
+      }
+    }
+  };
+
+  while (left > 0 && kept < ndet) {
+    const int kept_at_round_start = kept;
+    // ---- round: the next (up to) 1024 best candidates, in order, into s_sel ----
+    uint32_t n_round = left < kNmsRound ? left : kNmsRound;
     if (runs) {
-      // slot t = (run l, offset j): the next `step` candidates of every run.  T = the largest of the runs' LAST examined keys;
-      // the members of the round are the slots with key >= T: no run can hold an unexamined key >= T (its last examined
-      // key is <= T and the run is sorted), so they are exactly the best unconsumed candidates, 1 .. n_runs * step of them.
+      // slot t = (run l, offset j): the next `step` candidates of every run.  T = the largest of the runs' LAST examined
+      // keys; the members of the round are the slots with key >= T: no run can hold an unexamined key >= T (its last
+      // examined key is <= T and the run is sorted), so they are exactly the best unconsumed candidates, 1 .. n_runs * step of
+      // them.  Keys are unique: a member's position in the round is the number of member keys above it = its own offset
+      // (the run is sorted) + per other run the count of examined keys above it (all of those are >= T, i.e. members).
       const uint32_t step = kNmsRound / n_runs;
+      uint32_t p2 = 1;
+      while (p2 < step) p2 <<= 1;
       const uint32_t l = static_cast<uint32_t>(tid) / step, j = static_cast<uint32_t>(tid) - l * step;
-      uint64_t key = 0;
-      if (tid < 8) { s_members[tid] = 0; s_probe[tid] = 0; }
-      if (tid == 0) s_misc[33] = 0;
+      if (tid < 8) s_probe[tid] = 0;
       __syncthreads();
-      uint32_t avail = 0;
+      uint64_t key = 0;
       if (l < n_runs) {
-        avail = s_valid[l] - s_cursor[l];
-        if (j < avail) {
+        const uint32_t avail = s_valid[l] - s_cursor[l];
+        const uint32_t n_l = avail < step ? avail : step;
+        if (j < n_l) {
           const uint32_t p = l * a.run_len + s_cursor[l] + j;
           key = make_key(in_s[p], p);
-          if (j == (avail < step ? avail : step) - 1) s_probe[l] = key;
+          if (j == n_l - 1) s_probe[l] = key;
         }
       }
+      s_win[tid] = key;                                      // run l's window = s_win[l * step .. + step)
       __syncthreads();
       uint64_t T = 0;
       for (uint32_t q = 0; q < n_runs; ++q) T = s_probe[q] > T ? s_probe[q] : T;
-      const bool take = key != 0 && key >= T;
-      const uint32_t slot = wave_append_slot(&s_misc[33], take);
-      if (take) s_sel[slot] = key;
-      count_per_run(s_members, take, l < n_runs ? l : 0);
+      if (key != 0 && key >= T) {
+        // the binary searches of the other runs advance together, one step of each per trip: independent LDS reads in
+        // flight instead of (n_runs - 1) x log2(step) dependent ones (measured: 6.5 us for the round with one search after
+        // the other)
+        uint32_t n_q[8], lo[8];
+#pragma unroll
+        for (uint32_t q = 0; q < 8; ++q) {
+          const uint32_t avail = q < n_runs && q != l ? s_valid[q] - s_cursor[q] : 0u;
+          n_q[q] = avail < step ? avail : step;
+          lo[q] = 0;
+        }
+        for (uint32_t s2 = p2; s2 > 0; s2 >>= 1) {
+#pragma unroll
+          for (uint32_t q = 0; q < 8; ++q) {
+            const uint32_t at = lo[q] + s2;
+            if (at <= n_q[q] && s_win[q * step + at - 1] > key) lo[q] = at;
+          }
+        }
+        uint32_t rank = j;
+#pragma unroll
+        for (uint32_t q = 0; q < 8; ++q) rank += lo[q];
+        s_sel[rank] = key;
+      }
+      if (static_cast<uint32_t>(tid) < n_runs) {
+        const uint32_t avail = s_valid[tid] - s_cursor[tid];
+        s_members[tid] = count_above<false>(s_win + static_cast<uint32_t>(tid) * step, avail < step ? avail : step, T, p2);
+      }
+      __syncthreads();
+      n_round = 0;
+      for (uint32_t q = 0; q < n_runs; ++q) n_round += s_members[q];
       __syncthreads();
       if (static_cast<uint32_t>(tid) < n_runs) s_cursor[tid] += s_members[tid];
-      n_round = s_misc[33];
-      __syncthreads();
+      n_round = __builtin_amdgcn_readfirstlane(n_round);
+      if (first_round) { stamp(2); stamp(3); }
     } else {
-      const LdsKeySource src{s_keys, K, upper};
+      const LdsKeySource src{s_keys, list_n, upper};
+      uint64_t lower = 0;
       // any top-prefix of 256..1024 keys will do for a round: stop the radix descent early
-      if (left > kNmsRound)
-        lower = range_threshold(src, 256, kNmsRound, k_lo, upper == ~0ull ? k_hi : upper - 1, s_hist, s_misc, &n_round);
+      if (left > kNmsRound) {
+        const uint64_t k_lo = uniform_u64(s_range[0]), k_hi = uniform_u64(s_range[1]);
+        lower = uniform_u64(range_threshold(src, 256, kNmsRound, k_lo, upper == ~0ull ? k_hi : upper - 1, s_hist, s_misc, &n_round));
+      }
       if (tid == 0) s_misc[33] = 0;
       __syncthreads();
-      for (uint32_t i0 = 0; i0 < K; i0 += kNmsThreads) {     // (block-uniform trip count: the append ballots)
+      for (uint32_t i0 = 0; i0 < list_n; i0 += kNmsThreads) {     // (block-uniform trip count: the append ballots)
         const uint32_t i = i0 + tid;
-        const uint64_t key = i < K ? s_keys[i] : 0;
+        const uint64_t key = i < list_n ? s_keys[i] : 0;
         const bool take = key != 0 && key < upper && key >= lower;
         const uint32_t slot = wave_append_slot(&s_misc[33], take);
         if (take) s_sel[slot] = key;
       }
       __syncthreads();
+      if (first_round) stamp(2);
+      n_round = __builtin_amdgcn_readfirstlane(n_round);
+      sort_keys_desc(s_sel, n_round);                        // pads to 1024 with zeros (sort last)
+      if (first_round) stamp(3);
+      upper = lower;
     }
-    if (consumed == 0) stamp(2);
-    n_round = __builtin_amdgcn_readfirstlane(n_round);
-    sort_keys_desc(s_sel, n_round);                        // pads to 1024 with zeros (sort last)
-    if (consumed == 0) stamp(3);
-    upper = lower;
-    consumed += n_round;
+    left -= n_round;
+    examined += n_round;
 
     // thread t <-> rank `t` of this round: stage its box + class in LDS
     if (static_cast<uint32_t>(tid) < n_round) {
@@ -357,50 +492,61 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsArgs a) {
       for (int k = 0; k < NB; ++k) s_box[tid * NB + k] = in_b[static_cast<size_t>(p) * NB + k];
       s_cls[tid] = in_c[p];
     }
+    if constexpr (NB == 6) {
+      if (tid < 32) {                                          // dead bits: the slots behind the round's last candidate
+        const uint32_t lo = static_cast<uint32_t>(tid) * 32u;
+        s_dead[tid] = lo >= n_round ? ~0u : (lo + 32u <= n_round ? 0u : ~0u << (n_round - lo));
+      }
+    }
     __syncthreads();
 
-    // ---- chunks of 64 candidates: 16-way parallel pull, then one wave resolves the 64 in order ----
+    // ---- chunks of 64 candidates ----
     for (uint32_t c0 = 0; c0 < n_round && kept < ndet; c0 += kNmsChunk) {
       const int kept_before = kept;
-      // debug: per-chunk timeline of image 0's first round (3 stamps per chunk: start, after the pull phase, after the resolve)
+      // debug: per-chunk timeline of image 0's first round (3 stamps per chunk: start, after the pair work, after the resolve)
       auto cstamp = [&](int k) {
-        if (a.trace && tid == 0 && blockIdx.x == 0 && consumed == n_round && c0 / kNmsChunk < 20)
-          a.trace[2048 - 8 * 64 + (c0 / kNmsChunk) * 4 + k] = k == 3 ? static_cast<unsigned long long>(kept) : wall_clock64();
+        if (a.trace && tid == 0 && blockIdx.x == 0 && first_round && c0 / kNmsChunk < 20)
+          a.trace[4096 - 8 * 64 + (c0 / kNmsChunk) * 4 + k] = k == 3 ? static_cast<unsigned long long>(kept) : wall_clock64();
       };
       cstamp(0);
-      // (1) EVERY wave looks at the same 64 candidates (lane <-> candidate).
-      //   pull: against its own slice of the kept list (ranks wave, wave + ways, ...): a candidate's <= ndet tests are
-      //         spread over `ways` threads.  Wave w publishes its verdict word; the AND is the set still alive.
-      //   suppression rows: row i of the chunk = the lanes j > i of the same class that candidate i WOULD suppress if it is
-      //         kept.  Wave w computes rows w, w + ways, ...: all of the chunk's pairwise IoUs happen here, in parallel on
-      //         every wave, and not on the serial chain of (2) -- measured before: 0.28 us per kept box in (2), 28 of the
-      //         kernel's 50 us (one wave, ~10 dependent branches per box).
       const uint32_t r = c0 + lane;                           // rank inside the round (< 1024)
-      float jb[NB];
-#pragma unroll
-      for (int k = 0; k < NB; ++k) jb[k] = s_box[r * NB + k];
-      const float jc = s_cls[r];
-      float2 *clip = s_clip + static_cast<size_t>(wave) * kClipSlotsPerWave + lane;   // rotated: wave-private
       const uint32_t n_chunk = n_round - c0 < kNmsChunk ? n_round - c0 : kNmsChunk;
-      if (wave < ways) {
+      if constexpr (NB == 4) {
+        float jb[NB];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) jb[k] = s_box[r * NB + k];
+        const float jc = s_cls[r];
+        // (1) EVERY wave looks at the same 64 candidates (lane <-> candidate).
+        //   pull: against its own slice of the kept list (ranks pulled + wave, + 16, ...): a candidate's tests are spread over
+        //         16 threads.  Wave w publishes its verdict word; the AND is the set still alive.
+        //   suppression rows: row i of the chunk = the lanes j > i of the same class that candidate i WOULD suppress if it is
+        //         kept.  Wave w computes rows w, w + 16, ...: all of the chunk's pairwise IoUs happen here, in parallel on
+        //         every wave, and not on the serial chain of (2) -- measured before: 0.28 us per kept box in (2), 28 of the
+        //         kernel's 50 us (one wave, ~10 dependent branches per box).
         bool alive = r < n_round;
-        if (alive) alive = pull_against_kept<NB>(s_kcls, s_kbox, wave, kept_before, ways, jb, jc, true, thr, own_angle, clip);
+        if (alive) alive = pull_against_kept(s_kcls, s_kbox, pulled + wave, kept_before, 16, jb, jc, true, thr);
         const uint64_t word = __ballot(alive);
         if (lane == 0) s_alive[wave] = word;
-        for (uint32_t i = wave; i < n_chunk; i += ways) {
+        for (uint32_t i = wave; i < n_chunk; i += 16) {
           const float ic = s_cls[c0 + i];                      // same address in every lane: LDS broadcast
           const bool rival = static_cast<uint32_t>(lane) > i && r < n_round && jc == ic;
           uint64_t row = 0;
           if (__ballot(rival)) {                               // wave-uniform: most rows have no same-class follower
-            float ib[NB];
+            float ib[4];
 #pragma unroll
-            for (int k = 0; k < NB; ++k) ib[k] = s_box[(c0 + i) * NB + k];
-            row = __ballot(rival && box_suppresses<NB>(ib, jb, thr, own_angle, clip));
+            for (int k = 0; k < 4; ++k) ib[k] = s_box[(c0 + i) * 4 + k];
+            row = __ballot(rival && axis_suppresses(ib, jb, thr));
           }
           if (lane == 0) s_sup[i] = row;
         }
+        __syncthreads();
+      } else {
+        // rotated: pull first (dead bits), then rows among the survivors only -- both through the pair queue
+        if (tid < kNmsChunk) s_sup[tid] = 0;
+        if (kept_before > pulled) pair_phase(false, c0, n_chunk, pulled, kept_before);
+        else __syncthreads();
+        pair_phase(true, c0, n_chunk, 0, 0);
       }
-      __syncthreads();
       cstamp(1);
 
       // (2) wave 0 resolves the chunk in rank order with scalar bit operations only: lane i holds row i, the first alive
@@ -408,7 +554,12 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsArgs a) {
       //     branch per kept box.
       if (wave == 0) {
         uint64_t word = ~0ull;
-        for (int w = 0; w < ways; ++w) word &= s_alive[w];
+        if constexpr (NB == 4) {
+          for (int w = 0; w < 16; ++w) word &= s_alive[w];
+        } else {
+          const uint64_t dead = static_cast<uint64_t>(s_dead[c0 >> 5]) | (static_cast<uint64_t>(s_dead[(c0 >> 5) + 1]) << 32);
+          word = ~dead;
+        }
         const uint64_t my_row = static_cast<uint32_t>(lane) < n_chunk ? s_sup[lane] : 0;
         const uint32_t row_lo = static_cast<uint32_t>(my_row), row_hi = static_cast<uint32_t>(my_row >> 32);
         // (LDS values are VGPRs, "divergent" to the compiler: pin the loop state to SGPRs so the loop is scalar control flow)
@@ -428,8 +579,8 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsArgs a) {
           const int my_rank = kept_before + __popcll(kept_mask & ((1ull << lane) - 1ull));
           const uint64_t key = s_sel[r];
 #pragma unroll
-          for (int k = 0; k < NB; ++k) s_kbox[my_rank * NB + k] = jb[k];
-          s_kcls[my_rank] = jc;
+          for (int k = 0; k < NB; ++k) s_kbox[my_rank * NB + k] = s_box[r * NB + k];
+          s_kcls[my_rank] = s_cls[r];
           s_kscore[my_rank] = key_score(key);
           s_ksrc[my_rank] = static_cast<int32_t>(key_index(key));
         }
@@ -440,23 +591,96 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsArgs a) {
       cstamp(2);
       cstamp(3);
     }
+    first_round = false;
+
+    // ---- heavy suppression: drop everything the kept list already suppresses, in one parallel pass ----
+    // Worth it only when everything that is left would be examined anyway: at this round's yield (kept per examined) the
+    // boxes still missing need more candidates than remain.  Then the pass does no pair test the lazy rounds would not do
+    // too, and saves their selection / sort / barrier overhead; otherwise it would test candidates nobody ever looks at.
+    if (kept < ndet && left > 0 &&
+        static_cast<unsigned long long>(ndet - kept) * n_round >= static_cast<unsigned long long>(left) * static_cast<uint32_t>(kept - kept_at_round_start)) {
+      // source = the candidates no round has taken yet (sorted-run mode: the tails of the runs; generic: keys < upper);
+      // survivors are appended to the key list (its front, in place) and the kernel continues in generic mode on them
+      const uint32_t n_src = runs ? left : list_n;
+      if (tid == 0) s_misc[37] = 0;
+      __syncthreads();
+      for (uint32_t f0 = 0; f0 < n_src; f0 += kNmsThreads) {   // block-uniform trip count
+        const uint32_t f = f0 + tid;
+        uint64_t key = 0;
+        if (f < n_src) {
+          if (runs) {
+            uint32_t q = 0, base = 0, acc = 0;                   // flat index f -> (run q, offset f - base) over the runs' tails
+#pragma unroll
+            for (uint32_t t = 0; t < 8; ++t) {                   // (selects only: a dynamically indexed private array would live in scratch)
+              const uint32_t n_t = t < n_runs ? s_valid[t] - s_cursor[t] : 0u;
+              const bool here = f >= acc && f - acc < n_t;
+              q = here ? t : q;
+              base = here ? acc : base;
+              acc += n_t;
+            }
+            const uint32_t p = q * a.run_len + s_cursor[q] + (f - base);
+            key = make_key(in_s[p], p);
+          } else {
+            key = s_keys[f];
+            key = key < upper ? key : 0;                       // already handed to a round
+          }
+        }
+        bool alive = key != 0;
+        float cb[NB];
+        float cc = 0.0f;
+        if (alive) {
+          const uint32_t p = key_index(key);
+#pragma unroll
+          for (int k = 0; k < NB; ++k) cb[k] = in_b[static_cast<size_t>(p) * NB + k];
+          cc = in_c[p];
+        }
+        if constexpr (NB == 4) {
+          __syncthreads();                                     // (generic mode: this slab's keys are read before any is overwritten)
+          if (alive) alive = pull_against_kept(s_kcls, s_kbox, 0, kept, 1, cb, cc, true, thr);
+        } else {
+          // stage the slab like a round and run the pull through the pair queue
+          if (alive) {
+#pragma unroll
+            for (int k = 0; k < NB; ++k) s_box[tid * NB + k] = cb[k];
+            s_cls[tid] = cc;
+          }
+          const uint64_t present = __ballot(alive);
+          if (lane == 0) { s_dead[2 * wave] = ~static_cast<uint32_t>(present); s_dead[2 * wave + 1] = ~static_cast<uint32_t>(present >> 32); }
+          __syncthreads();
+          pair_phase(false, 0, kNmsThreads, 0, kept);
+          alive = alive && !((s_dead[tid >> 5] >> (tid & 31)) & 1u);
+        }
+        const uint32_t slot = wave_append_slot(&s_misc[37], alive);
+        if (alive) s_keys[slot] = key;
+        __syncthreads();
+      }
+      list_n = __builtin_amdgcn_readfirstlane(s_misc[37]);
+      left = list_n;
+      upper = ~0ull;
+      runs = false;
+      pulled = kept;
+      if (left > 0) key_range();
+    }
   }
 
   stamp(4);
   if (a.trace && tid == 0) {
-    a.trace[(gridDim.x + blockIdx.x) * 8 + 5] = consumed;
+    a.trace[(gridDim.x + blockIdx.x) * 8 + 5] = examined;
     a.trace[(gridDim.x + blockIdx.x) * 8 + 6] = K;
     a.trace[(gridDim.x + blockIdx.x) * 8 + 7] = static_cast<unsigned long long>(clock64() - shader_clock0);
   }
   // ---- outputs: kept boxes, then the zero-padded tail (box.py:322-324) ----
+  float *out_scores = reinterpret_cast<float *>(uniform_u64(s_out[0])), *out_boxes = reinterpret_cast<float *>(uniform_u64(s_out[1]));
+  float *out_classes = reinterpret_cast<float *>(uniform_u64(s_out[2]));
+  int32_t *out_indices = reinterpret_cast<int32_t *>(uniform_u64(s_out[3]));
   for (int t = tid; t < ndet; t += kNmsThreads) {
     const size_t o = static_cast<size_t>(img) * ndet + t;
     const bool v = t < kept;
-    a.out_scores[o] = v ? s_kscore[t] : 0.0f;
-    a.out_classes[o] = v ? s_kcls[t] : 0.0f;
+    out_scores[o] = v ? s_kscore[t] : 0.0f;
+    out_classes[o] = v ? s_kcls[t] : 0.0f;
 #pragma unroll
-    for (int k = 0; k < NB; ++k) a.out_boxes[o * NB + k] = v ? s_kbox[t * NB + k] : 0.0f;
-    if (a.out_indices) a.out_indices[o] = v ? s_ksrc[t] : -1;
+    for (int k = 0; k < NB; ++k) out_boxes[o * NB + k] = v ? s_kbox[t * NB + k] : 0.0f;
+    if (out_indices) out_indices[o] = v ? s_ksrc[t] : -1;
   }
 }
 

@@ -227,7 +227,7 @@ int launch_decode(bool rotated, uint32_t tiles, int n_seg, size_t scan_lds, cons
 
 int decode_levels_impl(int batch, int n_levels, const odtk_level_t *levels, int A, int C, int dtype,
                        uint32_t flags, float thresh, int top_n, void *const *outputs, int n_outputs,
-                       void *workspace, size_t workspace_size, hipStream_t stream) {
+                       void *workspace, size_t workspace_size, hipStream_t stream, uint32_t *run_valid = nullptr) {
   if (batch <= 0 || n_levels <= 0 || n_levels > ODTK_MAX_LEVELS || !levels) return ODTK_ERR_INVALID;
   if (A <= 0 || A > ODTK_MAX_ANCHORS || C <= 0 || top_n <= 0 || top_n > ODTK_MAX_TOP_N) return ODTK_ERR_INVALID;
   for (int l = 0; l < n_levels; ++l)
@@ -328,6 +328,7 @@ int decode_levels_impl(int batch, int n_levels, const odtk_level_t *levels, int 
   da.out_boxes = static_cast<float *>(outputs[1]);
   da.out_classes = static_cast<float *>(outputs[2]);
   da.out_indices = n_outputs > 3 ? static_cast<int32_t *>(outputs[3]) : nullptr;
+  da.run_valid = run_valid;
   da.n_levels = n_levels;
   da.batch = batch;
   da.num_anchors = A;
@@ -371,13 +372,17 @@ int nms_launch(const odtk::NmsArgs &na, int batch, size_t lds, hipStream_t strea
 
 int nms_impl(int batch, const void *const *inputs, void *const *outputs, int n_outputs, size_t count,
              int ndet, float thresh, uint32_t flags, void *workspace, size_t workspace_size, hipStream_t stream,
-             uint32_t sorted_run_len = 0) {
+             uint32_t sorted_run_len = 0, const uint32_t *run_valid = nullptr) {
   if (batch <= 0 || count == 0 || count > ODTK_MAX_NMS_COUNT_SCRATCH || ndet <= 0 || ndet > ODTK_MAX_NMS_DETECTIONS)
     return ODTK_ERR_INVALID;
   // up to ODTK_MAX_NMS_COUNT candidates per image everything is LDS-resident and the kernel needs no global scratch
   // (a token size keeps the reference's two-phase calling convention working unchanged); beyond that the key list
   // of every image lives in the workspace
-  const bool global_keys = count > ODTK_MAX_NMS_COUNT;
+  const int nb = (flags & ODTK_FLAG_ROTATED) ? 6 : 4;
+  // ... or when the LDS-resident form does not fit next to a long kept list (detections_per_im in the thousands), or -- rotated
+  // -- would leave fewer than 8 of the 16 waves a polygon-clip column (they are what evaluates box pairs)
+  const odtk::NmsLds local(static_cast<uint32_t>(count > ODTK_MAX_NMS_COUNT ? 1 : count), ndet, nb, false);
+  const bool global_keys = count > ODTK_MAX_NMS_COUNT || local.total > odtk::NmsLds::kLdsBudget || (nb == 6 && local.ways < 8);
   const size_t need = global_keys ? align_up(sizeof(uint64_t) * static_cast<size_t>(batch) * count) : kAlign;
   if (need > 0x7fffffffull) return ODTK_ERR_INVALID;
   if (!workspace || !workspace_size) return static_cast<int>(need);
@@ -385,7 +390,6 @@ int nms_impl(int batch, const void *const *inputs, void *const *outputs, int n_o
   if (!inputs || !outputs || n_outputs < 3) return ODTK_ERR_INVALID;
   for (int i = 0; i < 3; ++i)
     if (!inputs[i] || !outputs[i]) return ODTK_ERR_INVALID;
-  const int nb = (flags & ODTK_FLAG_ROTATED) ? 6 : 4;
   odtk::NmsArgs na;
   std::memset(&na, 0, sizeof na);
   na.scores = static_cast<const float *>(inputs[0]);
@@ -397,6 +401,7 @@ int nms_impl(int batch, const void *const *inputs, void *const *outputs, int n_o
   na.out_indices = n_outputs > 3 ? static_cast<int32_t *>(outputs[3]) : nullptr;
   na.count = static_cast<uint32_t>(count);
   na.run_len = sorted_run_len;
+  na.run_valid = run_valid;
   na.ndet = ndet;
   na.thresh = thresh;
   na.flags = flags;
@@ -807,18 +812,20 @@ int odtk_detect(int batch_size, int n_levels, const odtk_level_t *levels, int nu
   const size_t off_b = off_s + align_up(sizeof(float) * batch_size * count);
   const size_t off_c = off_b + align_up(sizeof(float) * batch_size * count * nb);
   const size_t off_n = off_c + align_up(sizeof(float) * batch_size * count);
-  const size_t total = off_n + align_up(static_cast<size_t>(nms_ws));
+  const size_t off_v = off_n + align_up(static_cast<size_t>(nms_ws));                // positive scores per (image, level) list
+  const size_t total = off_v + align_up(sizeof(uint32_t) * batch_size * n_levels);
   if (!workspace || !workspace_size) return total > 0x7fffffffull ? ODTK_ERR_INVALID : static_cast<int>(total);
   if (workspace_size < total) return ODTK_ERR_WORKSPACE;
   if (!outputs) return ODTK_ERR_INVALID;
   char *ws = static_cast<char *>(workspace);
   void *cat[3] = {ws + off_s, ws + off_b, ws + off_c};
+  uint32_t *run_valid = reinterpret_cast<uint32_t *>(ws + off_v);
   int rc = decode_levels_impl(batch_size, n_levels, levels, num_anchors, num_classes, dtype, flags, score_thresh,
-                              top_n, cat, 3, workspace, static_cast<size_t>(dec), static_cast<hipStream_t>(stream));
+                              top_n, cat, 3, workspace, static_cast<size_t>(dec), static_cast<hipStream_t>(stream), run_valid);
   if (rc != ODTK_OK) return rc;
-  // the candidates are decode_levels' own output: n_levels runs of top_n, each already in NMS order
+  // the candidates are decode_levels' own output: n_levels runs of top_n, each already in NMS order, run_valid of them positive
   return nms_impl(batch_size, cat, outputs, 3, count, detections_per_im, nms_thresh, flags, ws + off_n,
-                  static_cast<size_t>(nms_ws), static_cast<hipStream_t>(stream), static_cast<uint32_t>(top_n));
+                  static_cast<size_t>(nms_ws), static_cast<hipStream_t>(stream), static_cast<uint32_t>(top_n), run_valid);
 }
 
 }  // extern "C"

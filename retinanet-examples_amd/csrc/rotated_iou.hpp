@@ -35,9 +35,14 @@ struct Pt { float x, y; };
 // returns |area|.  q = this lane's column in a kClipSlotsPerWave-sized LDS region of its wave.
 __device__ __forceinline__ float clip_area(const Pt *R, Pt *P, float2 *q) {
   int count = 4;
-#pragma unroll
+  // the four clip edges run through ONE copy of the code: the quad's corners rotate through four registers pairs (static
+  // indices, so they stay registers) instead of the loop being unrolled four times -- a quarter of the code, and the
+  // scheduler cannot overlap two edges' temporaries (the unrolled form needed 74 VGPRs alone and spilled inside the NMS)
+  Pt Q0 = R[0], Q1 = R[1], Q2 = R[2], Q3 = R[3];
+#pragma unroll 1
   for (int e = 0; e < 4; ++e) {
-    const Pt r1 = R[e], r2 = R[(e + 1) & 3];
+    const Pt r1 = Q0, r2 = Q1;
+    { const Pt t = Q0; Q0 = Q1; Q1 = Q2; Q2 = Q3; Q3 = t; }
     // Line(r1, r2): a = r2.y - r1.y, b = r1.x - r2.x, c = r2 x r1      (nms_iou.cu:86)
     const float la = r2.y - r1.y, lb = r1.x - r2.x, lc = r2.x * r1.y - r2.y * r1.x;
     float lv[kPolyMax];
@@ -113,37 +118,37 @@ __device__ __forceinline__ float overlap_from(const Pt *I, const Pt *M, float2 *
   }
 #pragma unroll
   for (int k = 4; k < kPolyMax; ++k) { P[k].x = 0.0f; P[k].y = 0.0f; }
+  const float uni = (fabsf(quad_shoelace(I)) + fabsf(quad_shoelace(M))) / 2.0f;   // (before the clip: I need not stay in registers)
   const float inter = clip_area(M, P, q);
-  const float uni = (fabsf(quad_shoelace(I)) + fabsf(quad_shoelace(M))) / 2.0f;
   if (inter != inter && uni != uni) return 1.0f;
   if (inter != inter) return 0.0f;
   return inter / (uni - inter);
 }
 
+// Cheap reject in front of the polygon clip: true = the kept box m CANNOT suppress the lower-scored box j.
+// Every corner of a quad lies within its half diagonal (scaled by |(sin, cos)|, which the network does not normalise) of
+// the box centre, so two quads whose centres are further apart -- along x or along y -- than an upper bound of the two
+// radii cannot intersect: the clip would return an empty polygon, overlap 0, and `0 > thr` is false for thr >= 0.  The
+// margin (0.1 % + 2 px + 4e-6 * coordinate^2) is far above the fp32 error of the clip's line equations as long as the
+// kept quad is properly oriented with edges of at least one pixel (otherwise, and for any NaN / inf, the answer is "cannot
+// tell" = false and the full path decides).  In an NMS almost all same-class pairs are far apart.
+__device__ __forceinline__ bool rotated_far_apart(const float *m, const float *j, float thr, bool own_angle) {
+  if (!(thr >= 0.0f)) return false;
+  const float sm = own_angle ? m[4] : j[4], cm = own_angle ? m[5] : j[5];
+  const float wm = m[2] - m[0], hm = m[3] - m[1];
+  const float kj = fabsf(j[4]) + fabsf(j[5]), km = fabsf(sm) + fabsf(cm);           // >= |(sin, cos)|: no sqrt needed
+  const float rr = 0.5f * ((fabsf(j[2] - j[0]) + fabsf(j[3] - j[1])) * kj + (fabsf(wm) + fabsf(hm)) * km);   // >= r_j + r_m
+  const float sxm = m[0] + m[2], sym = m[1] + m[3];                                 // twice the kept centre
+  const float far = 0.5f * fmaxf(fabsf((j[0] + j[2]) - sxm), fabsf((j[1] + j[3]) - sym));
+  const float reach = 0.5f * (fabsf(sxm) + fabsf(sym)) + far + rr;                  // >= |any coordinate| of both quads
+  // |(sin, cos)| >= (|sin| + |cos|) / sqrt 2: edges of the kept quad are at least one pixel long
+  const bool proper = wm * km >= 1.5f && hm * km >= 1.5f;                          // implies wm, hm > 0 (km >= 0)
+  return proper && far > rr * 1.001f + 2.0f + 4e-6f * reach * reach;
+}
+
 // Does the kept box m suppress the lower-scored box j?  boxes are [x1,y1,x2,y2,sin,cos].
 // Reference default (nms_iou.cu:186-193): BOTH quads are rotated by j's (sin, cos).
-template <bool kReject = true>
-__device__ __forceinline__ bool rotated_suppresses(const float *m, const float *j, float thr, bool own_angle,
-                                                   float2 *q) {
-  // Cheap reject before the polygon clip: every corner of a quad lies within its half diagonal (scaled by
-  // |(sin, cos)|, which the network does not normalise) of the box centre, so two quads whose centres are
-  // further apart -- along x or along y -- than an upper bound of the two radii cannot intersect: the clip would return an empty polygon, overlap 0,
-  // and `0 > thr` is false for thr >= 0.  The margin (0.1 % + 2 px + 4e-6 * coordinate^2) is far above
-  // the fp32 error of the clip's line equations as long as the kept quad is properly oriented with edges
-  // of at least one pixel (otherwise, and for any NaN / inf, the full path decides).  In an NMS almost
-  // all same-class pairs are far apart, and a wave only pays for the clip if one of its lanes needs it.
-  if (kReject && thr >= 0.0f) {
-    const float sm = own_angle ? m[4] : j[4], cm = own_angle ? m[5] : j[5];
-    const float wm = m[2] - m[0], hm = m[3] - m[1];
-    const float kj = fabsf(j[4]) + fabsf(j[5]), km = fabsf(sm) + fabsf(cm);           // >= |(sin, cos)|: no sqrt needed
-    const float rr = 0.5f * ((fabsf(j[2] - j[0]) + fabsf(j[3] - j[1])) * kj + (fabsf(wm) + fabsf(hm)) * km);   // >= r_j + r_m
-    const float sxm = m[0] + m[2], sym = m[1] + m[3];                                 // twice the kept centre
-    const float far = 0.5f * fmaxf(fabsf((j[0] + j[2]) - sxm), fabsf((j[1] + j[3]) - sym));
-    const float reach = 0.5f * (fabsf(sxm) + fabsf(sym)) + far + rr;                  // >= |any coordinate| of both quads
-    // |(sin, cos)| >= (|sin| + |cos|) / sqrt 2: edges of the kept quad are at least one pixel long
-    const bool proper = wm * km >= 1.5f && hm * km >= 1.5f;                          // implies wm, hm > 0 (km >= 0)
-    if (proper && far > rr * 1.001f + 2.0f + 4e-6f * reach * reach) return false;
-  }
+__device__ __forceinline__ bool rotated_suppresses(const float *m, const float *j, float thr, bool own_angle, float2 *q) {
   Pt I[4], M[4];
   rotated_corners(j, j[4], j[5], I);
   rotated_corners(m, own_angle ? m[4] : j[4], own_angle ? m[5] : j[5], M);

@@ -84,6 +84,7 @@ struct DecodeArgs {
   float *out_boxes;      // [batch, n_levels*top_n, NB]
   float *out_classes;    // [batch, n_levels*top_n]
   int32_t *out_indices;  // optional
+  uint32_t *run_valid;   // optional [batch, n_levels]: emitted entries with score > 0 of every (image, level) list (nms sorted-run mode)
   int n_levels, batch, num_anchors, num_classes, top_n;
   float thresh;
   unsigned long long *trace;   // debug (odtk_debug_set_trace): 8 timestamps per workgroup, or null
@@ -700,6 +701,7 @@ __global__ __launch_bounds__(kSelThreads) void select_decode_kernel(const Decode
 
   auto stamp = [&](int k) { if (a.trace && threadIdx.x == 0) a.trace[blockIdx.x * 8 + k] = wall_clock64(); };
   stamp(0);
+  if (threadIdx.x == 0) s_misc[22] = 0;                                  // positive scores emitted (run_valid)
   const ListSource lists(a.cand + L.cand_off + static_cast<uint64_t>(b) * kSubLists * L.cap, sub_counts, L.cap);
   uint32_t n_sort;   // number of valid keys placed in s_keys
 
@@ -869,11 +871,19 @@ __global__ __launch_bounds__(kSelThreads) void select_decode_kernel(const Decode
       bx[3] = clamp_like_torch(pcy + 0.5f * ph - 1.0f, lim_y);
       if constexpr (NB == 6) { bx[4] = d[4]; bx[5] = d[5]; }   // sin, cos pass through (decode_rotate.cu:152-162)
     }
+    if (a.run_valid) {                                                   // (block-uniform; the list is sorted: positives are a prefix)
+      const uint64_t positive = __ballot(score > 0.0f);
+      if (positive && lane_id() == 0) atomicAdd(&s_misc[22], static_cast<uint32_t>(__popcll(positive)));
+    }
     a.out_scores[out_row + t] = score;
     a.out_classes[out_row + t] = cls;
 #pragma unroll
     for (int k = 0; k < NB; ++k) a.out_boxes[(out_row + t) * NB + k] = bx[k];
     if (a.out_indices) a.out_indices[out_row + t] = index;
+  }
+  if (a.run_valid) {
+    __syncthreads();
+    if (threadIdx.x == 0) a.run_valid[static_cast<size_t>(b) * a.n_levels + l] = s_misc[22];
   }
   stamp(4);
 }

@@ -64,7 +64,7 @@ _C.library().odtk_debug_set_trace(trace.data_ptr())
 step(); torch.cuda.synchronize()
 _C.library().odtk_debug_set_trace(None)
 t = trace.cpu()
-rows = t[2048:2048 + 80].view(-1, 4)
+rows = t[4096:4096 + 80].view(-1, 4)
 img0 = t.view(-1, 8)[64 + 8]
 print('nms image 0: compact %.2f | select %.2f | sort %.2f | chunks %.2f us; consumed %d of %d' % (
     (img0[1] - img0[0]) / 100.0, (img0[2] - img0[1]) / 100.0, (img0[3] - img0[2]) / 100.0, (img0[4] - img0[3]) / 100.0, img0[5], img0[6]))

@@ -80,7 +80,7 @@ for name, fn in (('in Model.forward', step), ('back to back', alone)):
               % (i, (int(r[0]) - t0) / 100.0, (int(r[1]) - int(r[0])) / 100.0, (int(r[2]) - int(r[1])) / 100.0,
                  (int(r[3]) - int(r[2])) / 100.0, (int(r[4]) - int(r[3])) / 100.0, wall, int(r[5]), int(r[6]),
                  int((out[0][i] > 0).sum()), int(r[7]) / max(wall * 1e3, 1e-9)))
-    ch = t[2048:2048 + 80].view(-1, 4)
+    ch = t[4096:4096 + 80].view(-1, 4)
     prev = None
     for c, r in enumerate(ch):
         if int(r[0]) == 0:
