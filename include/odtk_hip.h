@@ -239,6 +239,18 @@ int odtk_snap_to_anchors(int batch_size, const float *targets, int n_max, const 
                          float iou_background, float iou_foreground,
                          float *cls_target, float *box_target, float *depth, void *stream);
 
+/* ... and all pyramid levels in ONE launch (a level table in the kernel arguments; n_levels <= ODTK_MAX_LEVELS). */
+typedef struct odtk_snap_level {
+  const float *anchors;       /* HOST float[4*num_anchors] of this level's stride */
+  float *cls_target;          /* [batch, A, C, H, W] or NULL */
+  float *box_target;          /* [batch, A, 4, H, W] */
+  float *depth;               /* [batch, A, 1, H, W] */
+  int32_t height, width, stride, pad_;
+} odtk_snap_level_t;
+int odtk_snap_to_anchors_levels(int batch_size, const float *targets, int n_max, int n_levels,
+                                const odtk_snap_level_t *levels, int num_anchors, int num_classes,
+                                float iou_background, float iou_foreground, void *stream);
+
 /*
  * odtk_retina_loss_forward / odtk_retina_loss_backward -- fused, masked FocalLoss + SmoothL1 reduction of ONE
  * pyramid level for the whole batch (the step after target assignment in training).
@@ -309,7 +321,9 @@ int odtk_retina_loss_levels_backward(int n_levels, const odtk_loss_level_t *leve
 #define ODTK_KERNEL_LOSS      7   /* retina_loss_kernel (forward and backward)      */
 #define ODTK_KERNEL_SELHIST   8   /* select_hist_kernel (both histogram passes)     */
 #define ODTK_KERNEL_SELFILTER 9   /* select_filter_kernel                           */
-#define ODTK_KERNEL_COUNT     10
+#define ODTK_KERNEL_NMS_ORDER 10  /* nms_kernel, stage 1 (rotated: the first round in order)   */
+#define ODTK_KERNEL_NMS_MATRIX 11 /* rotated_sup_matrix_kernel (rotated: pairwise suppression) */
+#define ODTK_KERNEL_COUNT     12
 /* on: 0 = off, otherwise a bit mask of kernel ids (1 << ODTK_KERNEL_*), -1 = all.  An event pair
  * is a queue marker before and after the kernel: cheap for the 3 post-processing launches of a step,
  * measurably NOT free for the ~110 epilogue launches (about 10 % of an 8.7 ms step), so time those

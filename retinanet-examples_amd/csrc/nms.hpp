@@ -67,7 +67,105 @@ struct NmsArgs {
   float thresh;
   uint32_t flags;
   unsigned long long *trace;   // debug (odtk_debug_set_trace): 8 timestamps per workgroup, or null
+  // rotated boxes, three launches (below): the first round in order, its pairwise suppression matrix, the resolve
+  float *first_box;            // [batch, m_max, 6]  boxes of the first round's candidates, in NMS order
+  float *first_cls;            // [batch, m_max]
+  uint32_t *first_n;           // [batch]            how many of them the matrix covers
+  unsigned long long *first_keys;   // [batch, kNmsRound] the whole first round's keys, in order (stage 1 -> stage 2)
+  uint32_t *first_state;       // [batch, 16]        its size, and where the selection stood after it (run cursors | lower key bound)
+  unsigned long long *sup;     // [batch, m_max, m_max / 64]  bit (j % 64) of word j / 64 of row i: candidate i suppresses candidate j (i < j)
+  uint32_t m_max;              // multiple of 64, <= kNmsRound
 };
+
+// Rotated boxes: the polygon clip is ~1000 wave instructions, and ONE workgroup per image -- one CU out of 256 -- cannot
+// evaluate the thousands of pairs an image needs in less than ~100 us (measured: 3.5 us per 1024 clips, VALU-bound).  The
+// pairs of the FIRST round are therefore evaluated by the whole chip:
+//   stage 1  nms_kernel<6, ., 1>         one workgroup per image: the first round (up to m_max candidates) in NMS order
+//                                        -> first_box / first_cls / first_n
+//   matrix   rotated_sup_matrix_kernel   one workgroup per 64 x 64 tile of (i < j) pairs and image: class test, distance
+//                                        reject, clip -> one 64-bit suppression word per (row, column block)
+//   stage 2  nms_kernel<6, ., 2>         one workgroup per image: the same first round again (deterministic), resolved
+//                                        from the matrix with bit arithmetic only -- a kept candidate ORs its row into the
+//                                        dead bits of the columns behind it; anything beyond the matrix (more than m_max
+//                                        candidates examined) continues with the in-workgroup pair queue.
+// The matrix is speculative -- all pairs of the first m candidates, not only those a lazy pull would test -- which is what
+// makes it parallel; m_max = 8 x detections_per_im bounds the waste.
+struct SupArgs {
+  const float *first_box;
+  const float *first_cls;
+  const uint32_t *first_n;
+  unsigned long long *sup;
+  uint32_t m_max;
+  float thresh;
+  uint32_t flags;
+};
+
+constexpr int kSupThreads = 256;
+
+// One workgroup per 16 x 64 slice of a 64 x 64 tile of (i < j) candidate pairs and image (four clips per thread at most: a
+// lone wave needs ~3..5 us per clip, so the work has to be wide, not deep).  A wave that clipped a whole row whenever ONE of its
+// 64 columns needed it paid ~46 000 wave-clips at m = 800 (44 us, VALU-bound) for pairs of which a quarter needed the clip;
+// so, as in the NMS kernel itself: enumerate the tile's pairs (class, distance reject), append the ones that need the
+// polygon clip to a queue in LDS, drain the queue one pair per thread, OR the verdicts into the tile's 64 row words.
+__global__ __launch_bounds__(kSupThreads) void rotated_sup_matrix_kernel(const SupArgs a) {
+  __shared__ float2 s_clip[(kSupThreads / kWave) * kClipSlotsPerWave];
+  constexpr uint32_t kRows = 16, kSlices = 64 / kRows;         // rows of the tile this workgroup takes
+  __shared__ float s_rows[kRows * 6], s_cols[64 * 6], s_rcls[kRows];
+  __shared__ uint32_t s_words[kRows * 2];
+  __shared__ uint16_t s_queue[kRows * 64];
+  __shared__ uint32_t s_count;
+  const uint32_t nblk = a.m_max / 64;
+  const uint32_t row0 = (blockIdx.x % kSlices) * kRows;      // first row of the slice inside its tile
+  uint32_t t = blockIdx.x / kSlices, bi = 0;
+  while (t >= nblk - bi) { t -= nblk - bi; ++bi; }           // upper-triangular tile index -> (row block, column block)
+  const uint32_t bj = bi + t;
+  const uint32_t img = blockIdx.y;
+  const uint32_t n = a.first_n[img];
+  if (bj * 64 >= n || bi * 64 + row0 >= n) return;           // (bi <= bj) nothing of this slice exists
+  const int tid = static_cast<int>(threadIdx.x);
+  const int lane = lane_id();
+  const int wave = tid >> 6;
+  const bool own_angle = (a.flags & ODTK_FLAG_ROTATED_NMS_FIXED_ANGLE) != 0;
+  const float *boxes = a.first_box + static_cast<size_t>(img) * a.m_max * 6;
+  const float *classes = a.first_cls + static_cast<size_t>(img) * a.m_max;
+  // stage the tile's 64 row boxes and 64 column boxes (6 floats each: 384 + 384 values, coalesced)
+  for (int e = tid; e < 64 * 6; e += kSupThreads) {
+    const uint32_t ri = (bi * 64 + row0) * 6 + e, ci = bj * 64 * 6 + e;
+    if (e < static_cast<int>(kRows) * 6) s_rows[e] = ri < n * 6 ? boxes[ri] : 0.0f;
+    s_cols[e] = ci < n * 6 ? boxes[ci] : 0.0f;
+  }
+  if (tid < static_cast<int>(kRows)) s_rcls[tid] = bi * 64 + row0 + tid < n ? classes[bi * 64 + row0 + tid] : __builtin_nanf("");
+  if (tid < static_cast<int>(kRows) * 2) s_words[tid] = 0;
+  if (tid == 0) s_count = 0;
+  const uint32_t j = bj * 64 + static_cast<uint32_t>(lane);
+  const float jc = j < n ? classes[j] : __builtin_nanf("");   // NaN equals nothing
+  __syncthreads();
+  float jb[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) jb[k] = s_cols[lane * 6 + k];
+  constexpr uint32_t kRowsPerWave = kRows / (kSupThreads / kWave);
+  for (uint32_t r = 0; r < kRowsPerWave; ++r) {
+    const uint32_t il = static_cast<uint32_t>(wave) * kRowsPerWave + r, i = bi * 64 + row0 + il;
+    bool need = j > i && jc == s_rcls[il];                   // (i >= n: its class is NaN)
+    if (need) need = !rotated_far_apart(s_rows + il * 6, jb, a.thresh, own_angle);
+    const uint32_t slot = wave_append_slot(&s_count, need);
+    if (need) s_queue[slot] = static_cast<uint16_t>((il << 6) | static_cast<uint32_t>(lane));
+  }
+  __syncthreads();
+  const uint32_t n_q = s_count;
+  float2 *clip = s_clip + static_cast<size_t>(wave) * kClipSlotsPerWave + lane;
+  for (uint32_t q = static_cast<uint32_t>(tid); q < n_q; q += kSupThreads) {
+    const uint32_t entry = s_queue[q], il = entry >> 6, jl = entry & 63u;
+    float ib[6], cb[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { ib[k] = s_rows[il * 6 + k]; cb[k] = s_cols[jl * 6 + k]; }
+    if (rotated_suppresses(ib, cb, a.thresh, own_angle, clip)) atomicOr(&s_words[2 * il + (jl >> 5)], 1u << (jl & 31u));
+  }
+  __syncthreads();
+  if (tid < static_cast<int>(kRows) && bi * 64 + row0 + tid < n)
+    a.sup[(static_cast<size_t>(img) * a.m_max + bi * 64 + row0 + tid) * nblk + bj] =
+        static_cast<unsigned long long>(s_words[2 * tid]) | (static_cast<unsigned long long>(s_words[2 * tid + 1]) << 32);
+}
 
 // LDS carve-up shared by host (size) and device (pointers); every offset is 16-byte aligned.  The regions of fixed size
 // come first, at compile-time offsets (no scalar register per pointer -- the kernel is short of them); the ones that
@@ -185,8 +283,11 @@ __device__ __forceinline__ uint32_t count_above(const uint64_t *A, uint32_t n, u
 
 // kGlobalKeys: more candidates than the LDS holds (count > ODTK_MAX_NMS_COUNT): the key list of an image lives in the
 // caller's workspace instead; rounds then walk it out of L2 -- slower, same result.
-template <int NB, bool kGlobalKeys = false>
+// kStage (rotated only): 0 = the whole NMS in this launch; 1 = export the first round and stop; 2 = resolve the first round
+// from the suppression matrix, then go on as stage 0 would.
+template <int NB, bool kGlobalKeys = false, int kStage = 0>
 __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsArgs a) {
+  static_assert(kStage == 0 || NB == 6, "the staged form exists for rotated boxes only");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const NmsLds lay(a.count, a.ndet, NB, kGlobalKeys);
   uint64_t *s_keys = kGlobalKeys ? a.key_scratch + static_cast<size_t>(blockIdx.x) * a.count
@@ -202,7 +303,7 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsArgs a) {
   uint32_t *s_hist = reinterpret_cast<uint32_t *>(smem + Fixed::hist);
   uint32_t *s_misc = reinterpret_cast<uint32_t *>(smem + Fixed::misc);
   // s_misc: [0..31] range_threshold scratch, [32] length of the key list, [33] gather cursor, [34] kept count,
-  //         [35..36] pair-queue lengths (two, used alternately), [37] survivors of a filter pass,
+  //         [35..36] pair-queue lengths (two, used alternately), [37] survivors of a filter pass, [38..39] boxes kept in the chunk,
   //         [40..71] verdict words of the axis-aligned pull (16 x 64 bits); [40..103] min / max keys per wave (generic mode,
   //         between rounds), [72..111] per-run valid counts, cursors, member counts, probe keys (sorted-run mode),
   //         [112..143] dead bits of the round's 1024 candidates (rotated), [144..147] smallest / largest key of the list,
@@ -229,6 +330,17 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsArgs a) {
   const float *in_b = uniform_ptr(a.boxes + static_cast<size_t>(img) * count * NB);
   const float *in_c = uniform_ptr(a.classes + static_cast<size_t>(img) * count);
   auto stamp = [&](int k) { if (a.trace && tid == 0) a.trace[(gridDim.x + blockIdx.x) * 8 + k] = wall_clock64(); };
+  // debug: image 0's phases beyond the first round (id, time) pairs: 1 round selected, 2 boxes staged, 3 chunks / push done,
+  // 4 filter done
+  uint32_t n_phase = 0;
+  auto phase = [&](unsigned long long id) {
+    if constexpr (NB == 4)                                   // (the rotated kernels have no register to spare for it)
+    if (a.trace && tid == 0 && blockIdx.x == 0 && n_phase < 48) {
+      a.trace[4096 - 8 * 64 + 96 + 2 * n_phase] = id;
+      a.trace[4096 - 8 * 64 + 97 + 2 * n_phase] = wall_clock64();
+      ++n_phase;
+    }
+  };
 
   if (tid == 0) { s_misc[32] = 0; s_misc[34] = 0; s_misc[35] = 0; s_misc[36] = 0; }
   // the output pointers are needed once, at the very end: parked in LDS (s_misc[148..155]) they do not occupy scalar
@@ -321,6 +433,12 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsArgs a) {
   }
   const uint32_t K = left;
   stamp(1);
+  if constexpr (kStage == 1) {
+    if (left == 0) {                                       // no candidate: an empty first round
+      if (tid == 0) a.first_n[img] = 0;
+      return;
+    }
+  }
   if (!runs) key_range();
 
   uint32_t examined = 0;             // candidates handed to rounds so far (debug trace)
@@ -328,6 +446,8 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsArgs a) {
   int kept = 0;                      // block-uniform copy of s_misc[34]
   int pulled = 0;                    // every candidate still listed is known to survive the boxes kept at ranks < pulled
   bool first_round = true;
+  int last_round_kept = 0;           // yield of the previous round (push / pull choice)
+  uint32_t last_round_size = 0;
 
   // ---- rotated: box pairs through the queue (the ONE place of the kernel that clips polygons) ----
   // Candidates are the round's ranks r0 .. r0 + n - 1 (boxes / classes staged in s_box / s_cls); `rows` = false: against
@@ -398,13 +518,93 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsArgs a) {
     const int kept_at_round_start = kept;
     // ---- round: the next (up to) 1024 best candidates, in order, into s_sel ----
     uint32_t n_round = left < kNmsRound ? left : kNmsRound;
-    if (runs) {
+    if (kStage == 2 && first_round) {
+      // stage 1 selected and ordered this round already: take its keys and the state of the selection after it
+      const uint32_t *state = a.first_state + static_cast<size_t>(img) * 16;
+      n_round = __builtin_amdgcn_readfirstlane(state[0]);
+      if (static_cast<uint32_t>(tid) < n_round) s_sel[tid] = a.first_keys[static_cast<size_t>(img) * kNmsRound + tid];
+      if (runs) { if (tid < 8) s_cursor[tid] = state[1 + tid]; }
+      else upper = uniform_u64(static_cast<uint64_t>(state[1]) | (static_cast<uint64_t>(state[2]) << 32));
+      __syncthreads();
+    } else if (runs && kStage != 0) {
+      // Rotated, staged: the first round should be as long as the suppression matrix (m_max, several hundred candidates), and
+      // the probe below returns as few as 1024 / n_runs when one level dominates.  Exact top-min(left, 1024) instead: every
+      // run's next min(avail, 1024) keys are laid out window after window in the key list's space, and a key's position in the
+      // round is its offset in its own run + the number of larger keys in every other window (binary searches, advanced
+      // together); keys with a position below the target are the round, already in order.
+      const uint32_t target = n_round;
+      uint32_t w_n[8], w_base[9];
+      w_base[0] = 0;
+#pragma unroll
+      for (uint32_t q = 0; q < 8; ++q) {
+        const uint32_t avail = q < n_runs ? s_valid[q] - s_cursor[q] : 0u;
+        w_n[q] = __builtin_amdgcn_readfirstlane(avail < kNmsRound ? avail : kNmsRound);
+        w_base[q + 1] = w_base[q] + w_n[q];
+      }
+      const uint32_t total = w_base[8];
+      uint32_t p2 = 1;
+      while (p2 < kNmsRound && p2 < total) p2 <<= 1;
+      auto slot_of = [&](uint32_t f, uint32_t *q_out, uint32_t *j_out) {
+        uint32_t q = 0, base = 0;
+#pragma unroll
+        for (uint32_t t = 1; t < 8; ++t) {
+          const bool past = f >= w_base[t];
+          q = past ? t : q;
+          base = past ? w_base[t] : base;
+        }
+        *q_out = q;
+        *j_out = f - base;
+      };
+      for (uint32_t f = tid; f < total; f += kNmsThreads) {
+        uint32_t q, j;
+        slot_of(f, &q, &j);
+        const uint32_t p = q * a.run_len + s_cursor[q] + j;
+        s_keys[f] = make_key(in_s[p], p);
+      }
+      __syncthreads();
+      for (uint32_t f = tid; f < total; f += kNmsThreads) {
+        uint32_t q, j;
+        slot_of(f, &q, &j);
+        if (j >= target) continue;                             // its own run alone puts `target` keys above it
+        const uint64_t key = s_keys[f];
+        uint32_t lo[8];
+#pragma unroll
+        for (uint32_t t = 0; t < 8; ++t) lo[t] = 0;
+        for (uint32_t s2 = p2; s2 > 0; s2 >>= 1) {
+#pragma unroll
+          for (uint32_t t = 0; t < 8; ++t) {
+            if (t < n_runs) {                                  // (block-uniform; the key's own window is searched like the others:
+              const uint32_t at = lo[t] + s2;                  //  the count there is its own offset -- no per-thread exception,
+              const bool in_range = at <= w_n[t];              //  every load of a trip is unconditional and in flight together)
+              const uint64_t v = s_keys[w_base[t] + (in_range ? at - 1 : 0u)];
+              lo[t] = in_range && v > key ? at : lo[t];
+            }
+          }
+        }
+        uint32_t rank = 0;
+#pragma unroll
+        for (uint32_t t = 0; t < 8; ++t) rank += lo[t];
+        if (rank < target) s_sel[rank] = key;
+      }
+      __syncthreads();
+      if (static_cast<uint32_t>(tid) < n_runs) {               // how far every run was consumed: its keys >= the round's last key
+        uint32_t q = static_cast<uint32_t>(tid), n_w = 0, base = 0;
+#pragma unroll
+        for (uint32_t t = 0; t < 8; ++t) { n_w = t == q ? w_n[t] : n_w; base = t == q ? w_base[t] : base; }
+        s_cursor[q] += count_above<false>(s_keys + base, n_w, s_sel[target - 1], p2);
+      }
+      __syncthreads();
+    } else if (runs) {
       // slot t = (run l, offset j): the next `step` candidates of every run.  T = the largest of the runs' LAST examined
       // keys; the members of the round are the slots with key >= T: no run can hold an unexamined key >= T (its last
       // examined key is <= T and the run is sorted), so they are exactly the best unconsumed candidates, 1 .. n_runs * step of
       // them.  Keys are unique: a member's position in the round is the number of member keys above it = its own offset
       // (the run is sorted) + per other run the count of examined keys above it (all of those are >= T, i.e. members).
-      const uint32_t step = kNmsRound / n_runs;
+      uint32_t step = kNmsRound / n_runs;
+      // (opaque to the optimiser: everything derived from `step` -- each thread's run, offset and addresses -- is then
+      // recomputed per round instead of being hoisted out of the round loop and kept alive, in VGPRs the polygon clip
+      // needs, for the whole kernel)
+      asm volatile("" : "+s"(step));
       uint32_t p2 = 1;
       while (p2 < step) p2 <<= 1;
       const uint32_t l = static_cast<uint32_t>(tid) / step, j = static_cast<uint32_t>(tid) - l * step;
@@ -422,27 +622,32 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsArgs a) {
       }
       s_win[tid] = key;                                      // run l's window = s_win[l * step .. + step)
       __syncthreads();
+      if (first_round) stamp(2);
       uint64_t T = 0;
       for (uint32_t q = 0; q < n_runs; ++q) T = s_probe[q] > T ? s_probe[q] : T;
       if (key != 0 && key >= T) {
-        // the binary searches of the other runs advance together, one step of each per trip: independent LDS reads in
-        // flight instead of (n_runs - 1) x log2(step) dependent ones (measured: 6.5 us for the round with one search after
-        // the other)
+        // the binary searches of all runs advance together, one step of each per trip: independent LDS reads in flight
+        // instead of n_runs x log2(step) dependent ones.  The key's own run is searched like the others (the count there is
+        // its own offset j): no per-thread exception, so every load of a trip is unconditional for the runs that exist.
         uint32_t n_q[8], lo[8];
 #pragma unroll
         for (uint32_t q = 0; q < 8; ++q) {
-          const uint32_t avail = q < n_runs && q != l ? s_valid[q] - s_cursor[q] : 0u;
+          const uint32_t avail = q < n_runs ? s_valid[q] - s_cursor[q] : 0u;
           n_q[q] = avail < step ? avail : step;
           lo[q] = 0;
         }
         for (uint32_t s2 = p2; s2 > 0; s2 >>= 1) {
 #pragma unroll
           for (uint32_t q = 0; q < 8; ++q) {
-            const uint32_t at = lo[q] + s2;
-            if (at <= n_q[q] && s_win[q * step + at - 1] > key) lo[q] = at;
+            if (q < n_runs) {                                  // (block-uniform)
+              const uint32_t at = lo[q] + s2;
+              const bool in_range = at <= n_q[q];
+              const uint64_t v = s_win[q * step + (in_range ? at - 1 : 0u)];
+              lo[q] = in_range && v > key ? at : lo[q];
+            }
           }
         }
-        uint32_t rank = j;
+        uint32_t rank = 0;
 #pragma unroll
         for (uint32_t q = 0; q < 8; ++q) rank += lo[q];
         s_sel[rank] = key;
@@ -457,7 +662,7 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsArgs a) {
       __syncthreads();
       if (static_cast<uint32_t>(tid) < n_runs) s_cursor[tid] += s_members[tid];
       n_round = __builtin_amdgcn_readfirstlane(n_round);
-      if (first_round) { stamp(2); stamp(3); }
+      if (first_round) stamp(3);
     } else {
       const LdsKeySource src{s_keys, list_n, upper};
       uint64_t lower = 0;
@@ -484,6 +689,7 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsArgs a) {
     }
     left -= n_round;
     examined += n_round;
+    phase(1);
 
     // thread t <-> rank `t` of this round: stage its box + class in LDS
     if (static_cast<uint32_t>(tid) < n_round) {
@@ -491,6 +697,24 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsArgs a) {
 #pragma unroll
       for (int k = 0; k < NB; ++k) s_box[tid * NB + k] = in_b[static_cast<size_t>(p) * NB + k];
       s_cls[tid] = in_c[p];
+    }
+    // candidates of the first round the suppression matrix covers: all of them, or the first m_max (whole chunks)
+    const uint32_t m_cov = kStage != 0 && first_round ? (n_round <= a.m_max ? n_round : a.m_max) : 0u;
+    if constexpr (kStage == 1) {
+      if (static_cast<uint32_t>(tid) < m_cov) {
+#pragma unroll
+        for (int k = 0; k < NB; ++k) a.first_box[(static_cast<size_t>(img) * a.m_max + tid) * NB + k] = s_box[tid * NB + k];
+        a.first_cls[static_cast<size_t>(img) * a.m_max + tid] = s_cls[tid];
+      }
+      if (static_cast<uint32_t>(tid) < n_round) a.first_keys[static_cast<size_t>(img) * kNmsRound + tid] = s_sel[tid];
+      uint32_t *state = a.first_state + static_cast<size_t>(img) * 16;
+      if (tid == 0) {
+        a.first_n[img] = m_cov;
+        state[0] = n_round;
+        if (!runs) { state[1] = static_cast<uint32_t>(upper); state[2] = static_cast<uint32_t>(upper >> 32); }
+      }
+      if (runs && tid < 8) state[1 + tid] = s_cursor[tid];
+      return;
     }
     if constexpr (NB == 6) {
       if (tid < 32) {                                          // dead bits: the slots behind the round's last candidate
@@ -500,8 +724,58 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsArgs a) {
     }
     __syncthreads();
 
+    phase(2);
+    // ---- heavy suppression (axis-aligned): push instead of pull ----
+    // When the last round kept fewer than 1 in 20 of its candidates, resolving 64 candidates per chunk (pairwise rows +
+    // two barriers, ~2.7 us) spends most of its time on candidates that die anyway.  Then: thread <-> candidate for the WHOLE
+    // round, and per KEPT box one parallel pass -- the first candidate still alive is kept and every alive candidate behind
+    // it of its class tests itself against it (~0.6 us per kept box: one LDS-broadcast box, one IoU, one ballot).
+    bool pushed = false;
+    if constexpr (NB == 4) {
+      if (!first_round && static_cast<uint32_t>(last_round_kept) * 20u < last_round_size) {
+        pushed = true;
+        const uint32_t r = static_cast<uint32_t>(tid);
+        float jb[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) jb[k] = r < n_round ? s_box[r * 4 + k] : 0.0f;
+        const float jc = r < n_round ? s_cls[r] : 0.0f;
+        bool alive = r < n_round;
+        if (alive && kept > pulled) alive = pull_against_kept(s_kcls, s_kbox, pulled, kept, 1, jb, jc, true, thr);
+        while (kept < ndet) {                                  // block-uniform trip count
+          const uint64_t word = __ballot(alive);
+          if (lane == 0) s_alive[wave] = word;
+          __syncthreads();
+          uint32_t first = kNmsRound;                          // lowest alive rank of the round
+          for (int w = kNmsThreads / kWave - 1; w >= 0; --w) {
+            const uint64_t m = s_alive[w];
+            if (m) first = static_cast<uint32_t>(w) * kWave + static_cast<uint32_t>(__ffsll(static_cast<unsigned long long>(m)) - 1);
+          }
+          first = __builtin_amdgcn_readfirstlane(first);
+          if (first >= n_round) { __syncthreads(); break; }
+          if (r == first) {                                    // keep it
+            const uint64_t key = s_sel[r];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s_kbox[kept * 4 + k] = jb[k];
+            s_kcls[kept] = jc;
+            s_kscore[kept] = key_score(key);
+            s_ksrc[kept] = static_cast<int32_t>(key_index(key));
+            alive = false;
+          } else if (alive && r > first && jc == s_cls[first]) {
+            float mb[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) mb[k] = s_box[first * 4 + k];
+            if (axis_suppresses(mb, jb, thr)) alive = false;
+          }
+          ++kept;
+          __syncthreads();                                     // (s_alive is rewritten next trip)
+        }
+        if (tid == 0) s_misc[34] = static_cast<uint32_t>(kept);
+        __syncthreads();
+      }
+    }
+
     // ---- chunks of 64 candidates ----
-    for (uint32_t c0 = 0; c0 < n_round && kept < ndet; c0 += kNmsChunk) {
+    for (uint32_t c0 = 0; c0 < n_round && kept < ndet && !pushed; c0 += kNmsChunk) {
       const int kept_before = kept;
       // debug: per-chunk timeline of image 0's first round (3 stamps per chunk: start, after the pair work, after the resolve)
       auto cstamp = [&](int k) {
@@ -538,6 +812,14 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsArgs a) {
             row = __ballot(rival && axis_suppresses(ib, jb, thr));
           }
           if (lane == 0) s_sup[i] = row;
+        }
+        __syncthreads();
+      } else if (kStage == 2 && c0 < m_cov) {
+        // rotated, first round, inside the matrix: the dead bits already hold the rows of every box kept so far; the chunk's
+        // own rows are one word per candidate
+        if (tid < kNmsChunk) {
+          const uint32_t i = c0 + static_cast<uint32_t>(tid);
+          s_sup[tid] = i < m_cov ? a.sup[(static_cast<size_t>(img) * a.m_max + i) * (a.m_max / 64) + (c0 >> 6)] : 0ull;
         }
         __syncthreads();
       } else {
@@ -584,14 +866,36 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsArgs a) {
           s_kscore[my_rank] = key_score(key);
           s_ksrc[my_rank] = static_cast<int32_t>(key_index(key));
         }
-        if (lane == 0) s_misc[34] = static_cast<uint32_t>(k_cnt);
+        if (lane == 0) {
+          s_misc[34] = static_cast<uint32_t>(k_cnt);
+          s_misc[38] = static_cast<uint32_t>(kept_mask);
+          s_misc[39] = static_cast<uint32_t>(kept_mask >> 32);
+        }
       }
       __syncthreads();
       kept = __builtin_amdgcn_readfirstlane(static_cast<int>(s_misc[34]));
+      if constexpr (kStage == 2) {
+        if (c0 < m_cov) {
+          // every box kept in this chunk ORs its row into the dead bits of the column blocks behind the chunk: thread
+          // (candidate i, block w), one word each
+          const uint32_t nblk = a.m_max / 64, cov_blocks = (m_cov + 63) / 64;
+          const uint32_t i = static_cast<uint32_t>(tid) >> 4, w = static_cast<uint32_t>(tid) & 15u;
+          const uint64_t kept_mask = static_cast<uint64_t>(s_misc[38]) | (static_cast<uint64_t>(s_misc[39]) << 32);
+          if (((kept_mask >> i) & 1ull) && w > (c0 >> 6) && w < cov_blocks) {
+            const uint64_t word = a.sup[(static_cast<size_t>(img) * a.m_max + c0 + i) * nblk + w];
+            if (static_cast<uint32_t>(word)) atomicOr(&s_dead[2 * w], static_cast<uint32_t>(word));
+            if (static_cast<uint32_t>(word >> 32)) atomicOr(&s_dead[2 * w + 1], static_cast<uint32_t>(word >> 32));
+          }
+          __syncthreads();
+        }
+      }
       cstamp(2);
       cstamp(3);
     }
     first_round = false;
+    phase(3);
+    last_round_kept = kept - kept_at_round_start;
+    last_round_size = n_round;
 
     // ---- heavy suppression: drop everything the kept list already suppresses, in one parallel pass ----
     // Worth it only when everything that is left would be examined anyway: at this round's yield (kept per examined) the
@@ -660,6 +964,7 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsArgs a) {
       runs = false;
       pulled = kept;
       if (left > 0) key_range();
+      phase(4);
     }
   }
 

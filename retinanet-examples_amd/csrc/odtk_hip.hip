@@ -197,12 +197,12 @@ int launch_decode(bool rotated, uint32_t tiles, int n_seg, size_t scan_lds, cons
   timed_launch(ODTK_KERNEL_PREFILTER, odtk::prefilter_scan_kernel<T, kLogits>, dim3(tiles), dim3(odtk::kScanThreads), scan_lds, stream, sa);
   ODTK_HIP_TRY(hipGetLastError());
   // multi-workgroup narrowing of the segments that hold more candidates than one LDS sort (select_decode.hpp):
-  // histogram, histogram, filter.  Segments below that size leave at the first instruction.
+  // histogram, then filter (with a second histogram digit inside the same launch where saturated scores need one).
+  // Segments below that size leave at the first instruction.
   const uint32_t pass_blocks = da.part_begin[da.n_levels];
   if (pass_blocks && da.sel) {
     timed_launch(ODTK_KERNEL_SELHIST, odtk::select_pass_kernel<T, kLogits, 0>, dim3(pass_blocks), dim3(odtk::kPassThreads), 0, stream, da);
-    timed_launch(ODTK_KERNEL_SELHIST, odtk::select_pass_kernel<T, kLogits, 1>, dim3(pass_blocks), dim3(odtk::kPassThreads), 0, stream, da);
-    timed_launch(ODTK_KERNEL_SELFILTER, odtk::select_pass_kernel<T, kLogits, 2>, dim3(pass_blocks), dim3(odtk::kPassThreads), 0, stream, da);
+    timed_launch(ODTK_KERNEL_SELFILTER, odtk::select_pass_kernel<T, kLogits, 1>, dim3(pass_blocks), dim3(odtk::kPassThreads), 0, stream, da);
     ODTK_HIP_TRY(hipGetLastError());
   }
   if (da.sort_cap > static_cast<uint32_t>(odtk::kSortCap)) {
@@ -359,15 +359,40 @@ int decode_levels_impl(int batch, int n_levels, const odtk_level_t *levels, int 
                 : launch_decode<odtk::F16, false>(rotated, tiles, n_seg, scan_lds, sa, da, stream);
 }
 
-template <int NB, bool kGlobalKeys>
+template <int NB, bool kGlobalKeys, int kStage = 0>
 int nms_launch(const odtk::NmsArgs &na, int batch, size_t lds, hipStream_t stream) {
   // opt this kernel in to the full 160 KiB of LDS (once per device)
-  const int rc = allow_dynamic_lds(reinterpret_cast<const void *>(&odtk::nms_kernel<NB, kGlobalKeys>), 160 * 1024,
+  const int rc = allow_dynamic_lds(reinterpret_cast<const void *>(&odtk::nms_kernel<NB, kGlobalKeys, kStage>), 160 * 1024,
                                    "hipFuncSetAttribute(nms_kernel)");
   if (rc != ODTK_OK) return rc;
-  timed_launch(ODTK_KERNEL_NMS, odtk::nms_kernel<NB, kGlobalKeys>, dim3(batch), dim3(odtk::kNmsThreads), lds, stream, na);
+  timed_launch(kStage == 1 ? ODTK_KERNEL_NMS_ORDER : ODTK_KERNEL_NMS, odtk::nms_kernel<NB, kGlobalKeys, kStage>, dim3(batch),
+               dim3(odtk::kNmsThreads), lds, stream, na);
   ODTK_HIP_TRY(hipGetLastError());
   return ODTK_OK;
+}
+
+// rotated boxes: first round in order -> pairwise suppression matrix on the whole chip -> resolve (csrc/nms.hpp)
+template <bool kGlobalKeys>
+int nms_rotated_staged(const odtk::NmsArgs &na, int batch, size_t lds, hipStream_t stream) {
+  int rc = nms_launch<6, kGlobalKeys, 1>(na, batch, lds, stream);
+  if (rc != ODTK_OK) return rc;
+  odtk::SupArgs sa;
+  sa.first_box = na.first_box; sa.first_cls = na.first_cls; sa.first_n = na.first_n; sa.sup = na.sup;
+  sa.m_max = na.m_max; sa.thresh = na.thresh; sa.flags = na.flags;
+  const unsigned nblk = na.m_max / 64;
+  timed_launch(ODTK_KERNEL_NMS_MATRIX, odtk::rotated_sup_matrix_kernel, dim3(nblk * (nblk + 1) / 2 * 4, batch), dim3(odtk::kSupThreads), 0,
+               stream, sa);
+  ODTK_HIP_TRY(hipGetLastError());
+  return nms_launch<6, kGlobalKeys, 2>(na, batch, lds, stream);
+}
+
+// candidates of the first round the rotated suppression matrix covers: 8 x detections_per_im (the lazy pull of a typical
+// image examines 1.5 .. 7 x as many candidates as it keeps), whole 64-candidate chunks, at most one round
+uint32_t rotated_matrix_rows(size_t count, int ndet) {
+  size_t m = static_cast<size_t>(ndet) * 8;
+  if (m > count) m = count;
+  if (m > static_cast<size_t>(odtk::kNmsRound)) m = odtk::kNmsRound;
+  return static_cast<uint32_t>((m + 63) / 64 * 64);
 }
 
 int nms_impl(int batch, const void *const *inputs, void *const *outputs, int n_outputs, size_t count,
@@ -383,7 +408,16 @@ int nms_impl(int batch, const void *const *inputs, void *const *outputs, int n_o
   // -- would leave fewer than 8 of the 16 waves a polygon-clip column (they are what evaluates box pairs)
   const odtk::NmsLds local(static_cast<uint32_t>(count > ODTK_MAX_NMS_COUNT ? 1 : count), ndet, nb, false);
   const bool global_keys = count > ODTK_MAX_NMS_COUNT || local.total > odtk::NmsLds::kLdsBudget || (nb == 6 && local.ways < 8);
-  const size_t need = global_keys ? align_up(sizeof(uint64_t) * static_cast<size_t>(batch) * count) : kAlign;
+  const size_t keys_bytes = global_keys ? align_up(sizeof(uint64_t) * static_cast<size_t>(batch) * count) : kAlign;
+  // rotated: [first-round boxes | classes | counts | suppression matrix] behind the keys
+  const uint32_t m_max = nb == 6 ? rotated_matrix_rows(count, ndet) : 0u;
+  const size_t off_fb = keys_bytes;
+  const size_t off_fc = off_fb + (nb == 6 ? align_up(sizeof(float) * 6 * batch * m_max) : 0);
+  const size_t off_fn = off_fc + (nb == 6 ? align_up(sizeof(float) * batch * m_max) : 0);
+  const size_t off_fk = off_fn + (nb == 6 ? align_up(sizeof(uint32_t) * batch) : 0);
+  const size_t off_fs = off_fk + (nb == 6 ? align_up(sizeof(uint64_t) * batch * odtk::kNmsRound) : 0);
+  const size_t off_sup = off_fs + (nb == 6 ? align_up(sizeof(uint32_t) * 16 * batch) : 0);
+  const size_t need = off_sup + (nb == 6 ? align_up(sizeof(uint64_t) * batch * m_max * (m_max / 64)) : 0);
   if (need > 0x7fffffffull) return ODTK_ERR_INVALID;
   if (!workspace || !workspace_size) return static_cast<int>(need);
   if (workspace_size < need) return ODTK_ERR_WORKSPACE;
@@ -409,8 +443,18 @@ int nms_impl(int batch, const void *const *inputs, void *const *outputs, int n_o
   na.key_scratch = global_keys ? static_cast<uint64_t *>(workspace) : nullptr;
   const size_t lds = odtk::NmsLds(na.count, ndet, nb, global_keys).total;   // same carve-up the kernel computes
   if (lds > 160 * 1024) return ODTK_ERR_INVALID;
-  if (global_keys) return nb == 6 ? nms_launch<6, true>(na, batch, lds, stream) : nms_launch<4, true>(na, batch, lds, stream);
-  return nb == 6 ? nms_launch<6, false>(na, batch, lds, stream) : nms_launch<4, false>(na, batch, lds, stream);
+  if (nb == 6) {
+    char *ws = static_cast<char *>(workspace);
+    na.first_box = reinterpret_cast<float *>(ws + off_fb);
+    na.first_cls = reinterpret_cast<float *>(ws + off_fc);
+    na.first_n = reinterpret_cast<uint32_t *>(ws + off_fn);
+    na.first_keys = reinterpret_cast<unsigned long long *>(ws + off_fk);
+    na.first_state = reinterpret_cast<uint32_t *>(ws + off_fs);
+    na.sup = reinterpret_cast<unsigned long long *>(ws + off_sup);
+    na.m_max = m_max;
+    return global_keys ? nms_rotated_staged<true>(na, batch, lds, stream) : nms_rotated_staged<false>(na, batch, lds, stream);
+  }
+  return global_keys ? nms_launch<4, true>(na, batch, lds, stream) : nms_launch<4, false>(na, batch, lds, stream);
 }
 
 template <typename T, bool kRes, bool kRelu>
@@ -692,6 +736,44 @@ int odtk_snap_to_anchors(int batch_size, const float *targets, int n_max, const 
     hipLaunchKernelGGL(odtk::snap_to_anchors_kernel, dim3(blocks, batch_size), dim3(odtk::kSnapThreads), 0,
                        static_cast<hipStream_t>(stream), sa);
   }
+  ODTK_HIP_TRY(hipGetLastError());
+  return ODTK_OK;
+}
+
+int odtk_snap_to_anchors_levels(int batch_size, const float *targets, int n_max, int n_levels,
+                                const odtk_snap_level_t *levels, int num_anchors, int num_classes,
+                                float iou_background, float iou_foreground, void *stream) {
+  if (batch_size <= 0 || n_max < 0 || n_levels <= 0 || n_levels > ODTK_MAX_LEVELS || !levels || num_anchors <= 0 ||
+      num_anchors > ODTK_MAX_ANCHORS || num_classes <= 0 || (n_max > 0 && !targets))
+    return ODTK_ERR_INVALID;
+  odtk::SnapLevelsArgs la;
+  std::memset(&la, 0, sizeof la);
+  la.n_levels = n_levels;
+  unsigned total = 0;
+  for (int l = 0; l < n_levels; ++l) {
+    const odtk_snap_level_t &lv = levels[l];
+    if (!lv.anchors || !lv.box_target || !lv.depth || lv.height <= 0 || lv.width <= 0) return ODTK_ERR_INVALID;
+    odtk::SnapArgs &sa = la.lv[l];
+    sa.targets = targets;
+    sa.cls_target = lv.cls_target;
+    sa.box_target = lv.box_target;
+    sa.depth = lv.depth;
+    sa.n_max = n_max;
+    sa.num_anchors = num_anchors;
+    sa.num_classes = num_classes;
+    sa.height = lv.height;
+    sa.width = lv.width;
+    sa.stride = static_cast<float>(lv.stride);
+    sa.iou_bg = iou_background;
+    sa.iou_fg = iou_foreground;
+    std::memcpy(sa.anchors, lv.anchors, sizeof(float) * 4 * num_anchors);
+    la.block_begin[l] = total;
+    const long long cells = 1ll * num_anchors * lv.height * lv.width;
+    total += static_cast<unsigned>((cells + odtk::kSnapThreads - 1) / odtk::kSnapThreads);
+  }
+  for (int l = n_levels; l <= ODTK_MAX_LEVELS; ++l) la.block_begin[l] = total;
+  timed_launch(ODTK_KERNEL_TARGETS, odtk::snap_to_anchors_levels_kernel, dim3(total, batch_size), dim3(odtk::kSnapThreads), 0,
+               static_cast<hipStream_t>(stream), la);
   ODTK_HIP_TRY(hipGetLastError());
   return ODTK_OK;
 }

@@ -8,11 +8,12 @@
 // normative: two-sided clamp).
 //
 // Selection is exact for ANY input:
-//   K > sort size           : MULTI-WORKGROUP narrowing first (select_pass_kernel, three launches in front of this
-//                             kernel): two histogram passes over 11-bit digits of the 64-bit keys and one filter pass,
-//                             each walked by up to kSelParts workgroups per segment, leave the <= ~top_n keys at or
-//                             above the boundary bin in a small survivor list; this kernel then only sorts.  (One
-//                             workgroup walking 1e5..1e7 keys three times was the whole cost of this kernel.)
+//   K > sort size           : MULTI-WORKGROUP narrowing first (select_pass_kernel, two launches in front of this
+//                             kernel): a histogram pass over 2048 equal bins of the key range, then a filter pass (with a
+//                             second histogram digit inside the same launch when saturated scores need one), each walked
+//                             by up to kSelParts workgroups per segment, leave the <= ~top_n keys at or above the
+//                             boundary bin in a small survivor list; this kernel then only sorts.  (One workgroup
+//                             walking 1e5..1e7 keys three times was the whole cost of this kernel.)
 //   K <= kSortCap           : all candidates are sorted (bitonic network in LDS).
 //   kSortCap < K <= cap     : MSD radix descent (11-bit digits, LDS histograms) on the 64-bit
 //                             keys of the candidate lists narrows down the bin of the top_n-th
@@ -62,13 +63,12 @@ struct SelSeg {
   uint32_t hist[2][1 << 11];               // histograms of pass 0 / pass 1, bins reversed (largest keys first)
   unsigned long long kmax;                 // pass 0: largest key, and ...
   unsigned long long kmin_inv;             // ... largest ~key (= ~smallest key)
-  unsigned long long lo, hi;               // pass 1 (part 0) publishes the state it derived from pass 0: boundary bin [lo, hi]
-  uint32_t remaining, taken, in_bin, done;
   // filter pass (part 0): keys >= T survive, `expected` of them; those > bin_hi (exactly `taken` keys) are wanted
   // outright, of the `in_bin` keys inside [T, bin_hi] the `need` largest are wanted
   unsigned long long T, bin_hi;
   uint32_t expected, need, n_above, n_bin;   // expected = n_above + n_bin
   uint32_t filtered, surv_count;
+  uint32_t arrived, pad_;                  // second digit: workgroups of the segment that have added their histogram (ticket)
 };
 
 struct DecodeArgs {
@@ -344,18 +344,19 @@ __device__ uint64_t radix_threshold(const Source &src, uint32_t want, uint32_t m
   return prefix;                                    // undecided low bits are 0 = start of the boundary bin
 }
 
-// ---- multi-workgroup narrowing (three launches in front of select_decode_kernel) --------------------------
-// A pass cuts the current key range [lo, hi] into 2048 equal bins (digit = (key - lo) >> sh) and histograms the keys
+// ---- multi-workgroup narrowing (two launches in front of select_decode_kernel) ----------------------------
+// A digit cuts the current key range [lo, hi] into 2048 equal bins (digit = (key - lo) >> sh) and histograms the keys
 // inside it; the bin in which the running count, from the top, crosses top_n becomes the next range.
-//   pass 0: range = [key(thresh, last index), key(1.0 | +inf, index 0)] -- every candidate lies in it; also records the
-//           smallest and the largest key.
-//   pass 1: the boundary bin of pass 0, clipped to [min key, max key] (saturated scores: all keys share their score
-//           bits and differ only in the index bits; the clip makes the 2048 bins land on the bits that differ).
-//           Skipped when pass 0 already left a boundary bin that select_decode can rank (<= kRankCap keys).
-//   pass 2: every key >= the boundary bin's lower end goes to the segment's survivor list: the `taken` keys above the
-//           bin, all wanted, and the bin's own `in_bin` keys of which select_decode keeps the `need` largest.
+//   launch 0: first digit over [key(thresh, last index), key(1.0 | +inf, index 0)] -- every candidate lies in it; also
+//             records the smallest and the largest key.
+//   launch 1: FILTER -- every key >= the boundary bin's lower end goes to the segment's survivor list: the `taken` keys
+//             above the bin, all wanted, and the bin's own `in_bin` keys of which select_decode keeps the `need` largest.
+//             Where more keys than the survivor list holds share the boundary bin (saturated scores: all keys share
+//             their score bits and differ only in the index bits) a SECOND DIGIT comes first, inside the same launch:
+//             over the bin clipped to [min key, max key] (the clip makes the 2048 bins land on the bits that differ); the
+//             workgroup that adds its histogram last finishes the segment (select_pass_kernel).
 // Up to kSelParts workgroups of 256 threads per segment walk disjoint slices of the candidate lists (or of the raw
-// scores when a sub-list overflowed); segments with <= sort-size candidates leave all three passes at once.
+// scores when a sub-list overflowed); segments with <= sort-size candidates leave both launches at once.
 struct SelState {
   uint64_t lo, hi;                      // current range, both ends inclusive
   uint32_t remaining, taken, in_bin, done;
@@ -401,10 +402,13 @@ __device__ __forceinline__ void scan_boundary_256(const uint32_t *s_hist, uint32
 }
 
 // Folds one histogram pass into the state (block-wide, uniform result).  [kmin, kmax]: all keys of the segment.
+// kFresh: the histogram was completed by OTHER workgroups of this launch (ticket): read it past this CU's vector cache.
+template <bool kFresh = false>
 __device__ __forceinline__ void advance_state(SelState &st, const uint32_t *g_hist, uint64_t kmin, uint64_t kmax, uint32_t sort_cap,
                                               uint32_t *s_hist, uint32_t *s_misc) {
   const int sh = range_shift(st.lo, st.hi);
-  for (uint32_t i = threadIdx.x; i < kRadixBins; i += kPassThreads) s_hist[i] = g_hist[i];
+  for (uint32_t i = threadIdx.x; i < kRadixBins; i += kPassThreads)
+    s_hist[i] = kFresh ? __hip_atomic_load(g_hist + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : g_hist[i];
   __syncthreads();
   uint32_t rbin, above, in_bin;
   scan_boundary_256(s_hist, st.remaining, s_misc, &rbin, &above, &in_bin);
@@ -501,6 +505,16 @@ struct RawSlice {
   }
 };
 
+// PASS 0: the first histogram (+ smallest / largest key).
+// PASS 1: what follows it, in ONE launch (round 3; there were two, the first of them launched and skipped in the normal case):
+//   * every workgroup derives the state after pass 0 from the segment's histogram (8 KiB out of L2);
+//   * boundary bin rankable, or everything at or above it fits the survivor list  -> FILTER now: this workgroup's slice of
+//     the keys >= the bin's lower end goes to the survivor list (select_decode ranks a bin of <= kRankCap keys by brute
+//     force and radix-selects a larger one in LDS);
+//   * otherwise (saturated scores, plateaus: > surv_cap keys share the boundary bin)  -> SECOND DIGIT: histogram of the
+//     slice over the bin, clipped to [min key, max key]; the workgroup that arrives LAST at the segment's ticket counter
+//     (no grid barrier, nobody waits) folds that histogram into the state and filters the WHOLE segment alone -- slower
+//     than 64 workgroups, but it is the rare route and costs the common one no launch.
 template <typename T, bool kLogits, int PASS>
 __global__ __launch_bounds__(kPassThreads) void select_pass_kernel(const DecodeArgs a) {
   __shared__ __attribute__((aligned(8))) uint32_t s_hist[kRadixBins];
@@ -533,34 +547,6 @@ __global__ __launch_bounds__(kPassThreads) void select_pass_kernel(const DecodeA
   };
   stamp(0);
 
-  // pass 0 range: every candidate has score >= thresh; sigmoid outputs never exceed 1
-  SelState st;
-  st.lo = make_key(a.thresh, 0xffffffffu);
-  st.hi = kLogits ? make_key(1.0f, 0u) : ~0ull;
-  st.remaining = static_cast<uint32_t>(a.top_n);
-  st.taken = st.in_bin = st.done = 0;
-  if (PASS == 1) {
-    advance_state(st, S.hist[0], ~S.kmin_inv, S.kmax, a.sort_cap, s_hist, s_misc);
-    if (part == 0 && threadIdx.x == 0) {
-      S.lo = st.lo; S.hi = st.hi; S.remaining = st.remaining; S.taken = st.taken; S.in_bin = st.in_bin; S.done = st.done;
-    }
-    if (st.done) return;                                    // pass 0 already isolated a rankable boundary bin
-  }
-  uint64_t T64 = 0;
-  if (PASS == 2) {
-    st.lo = S.lo; st.hi = S.hi; st.remaining = S.remaining; st.taken = S.taken; st.in_bin = S.in_bin; st.done = S.done;
-    if (!st.done) advance_state(st, S.hist[1], st.lo, st.hi, a.sort_cap, s_hist, s_misc);
-    T64 = st.lo;
-    const uint32_t expected = st.taken + st.in_bin;
-    const bool fits = expected <= a.surv_cap;
-    if (part == 0 && threadIdx.x == 0) {
-      S.T = T64; S.bin_hi = st.hi; S.expected = expected; S.need = st.remaining; S.filtered = fits ? 1u : 0u;
-      S.n_above = st.taken; S.n_bin = st.in_bin;          // (own fields: the other workgroups of this pass still read S.taken / S.in_bin)
-    }
-    if (!fits) return;                                      // (adversarial key sets only) select_decode walks the source itself
-  }
-  stamp(1);
-
   // ---- this workgroup's slice of the segment ----
   const uint32_t hw = static_cast<uint32_t>(L.height) * L.width;
   const uint32_t channels = static_cast<uint32_t>(a.num_anchors) * a.num_classes;
@@ -568,30 +554,28 @@ __global__ __launch_bounds__(kPassThreads) void select_pass_kernel(const DecodeA
   const uint32_t total = complete ? lists.start[kSubLists] : L.n;
   uint32_t active = complete ? (total + kSelSlice - 1) / kSelSlice : P;
   if (active > P) active = P;
-  if (part >= active) return;
   const uint32_t chunk = ((total + active - 1) / active + kPassThreads - 1) / kPassThreads * kPassThreads;
+  const uint32_t n_live = (total + chunk - 1) / chunk;       // workgroups of this segment that own a non-empty slice
   const uint32_t lo = part * chunk;
   const uint32_t hi = lo + chunk < total ? lo + chunk : total;
-  if (lo >= hi) return;
-
+  if (part >= active || lo >= hi) return;
+  const typename T::storage *cls_image = static_cast<const typename T::storage *>(L.cls) + static_cast<uint64_t>(b) * L.n;
+  const RawSlice<T, kLogits> raw{cls_image, L.n, channels, hw, L.channels_last, a.thresh, L.cls_bias};
+  auto walk = [&](uint32_t w_lo, uint32_t w_hi, auto &&fn) {
+    if (complete) lists.template for_range<kPassThreads>(w_lo, w_hi, fn);
+    else raw.template for_range<kPassThreads>(w_lo, w_hi, fn);
+  };
   const int lane = lane_id();
-  constexpr uint32_t kStageKeys = kRadixBins / 2;           // s_hist reinterpreted as 64-bit keys
-  uint64_t *s_stage = reinterpret_cast<uint64_t *>(s_hist);
-  if (PASS < 2) {
+
+  // histogram of the keys inside [r_lo, r_hi] (2048 equal bins, reversed) into g_hist; pass 0 also records min / max
+  auto histogram = [&](uint64_t r_lo, uint64_t r_hi, bool clip, uint32_t *g_hist) {
     for (uint32_t i = threadIdx.x; i < kRadixBins; i += kPassThreads) s_hist[i] = 0;
     if (threadIdx.x < 2) s_range[threadIdx.x] = 0;
-  } else if (threadIdx.x == 0) {
-    s_misc[24] = 0;
-  }
-  __syncthreads();
-  const int sh = range_shift(st.lo, st.hi);
-  const uint64_t r_lo = st.lo, r_hi = st.hi;
-  uint64_t my_max = 0, my_min_inv = 0;
-  uint64_t *surv = a.surv + static_cast<uint64_t>(seg) * a.surv_cap;
-
-  auto visit = [&](uint64_t key, bool valid) {
-    if (PASS < 2) {
-      if (PASS == 1) valid = valid && key >= r_lo && key <= r_hi;
+    __syncthreads();
+    const int sh = range_shift(r_lo, r_hi);
+    uint64_t my_max = 0, my_min_inv = 0;
+    walk(lo, hi, [&](uint64_t key, bool valid) {
+      if (clip) valid = valid && key >= r_lo && key <= r_hi;
       const uint64_t m = __ballot(valid);
       if (!m) return;                                       // wave-uniform
       uint32_t digit = static_cast<uint32_t>((key - r_lo) >> sh);
@@ -608,33 +592,7 @@ __global__ __launch_bounds__(kPassThreads) void select_pass_kernel(const DecodeA
         my_max = key > my_max ? key : my_max;
         my_min_inv = ~key > my_min_inv ? ~key : my_min_inv;
       }
-    } else {
-      // survivors are staged in LDS (the histogram's 8 KiB = 1024 keys, idle in this pass) and leave with ONE returning
-      // global atomic per workgroup; a returning atomic per wave and round cost 1-2 us each on the critical path
-      const bool take = valid && key >= T64;
-      const uint64_t m = __ballot(take);
-      if (!m) return;
-      const int leader = __ffsll(static_cast<unsigned long long>(m)) - 1;
-      uint32_t base = 0;
-      if (lane == leader) base = atomicAdd(&s_misc[24], static_cast<uint32_t>(__popcll(m)));
-      base = __shfl(base, leader, kWave);
-      if (take) {
-        const uint32_t pos = base + __popcll(m & ((1ull << lane) - 1ull));
-        if (pos < kStageKeys) s_stage[pos] = key;
-        else { const uint32_t g = atomicAdd(&S.surv_count, 1u); if (g < a.surv_cap) surv[g] = key; }   // stage full (rare)
-      }
-    }
-  };
-  stamp(2);
-  if (complete) {
-    lists.template for_range<kPassThreads>(lo, hi, visit);
-  } else {
-    const typename T::storage *cls_image = static_cast<const typename T::storage *>(L.cls) + static_cast<uint64_t>(b) * L.n;
-    const RawSlice<T, kLogits> raw{cls_image, L.n, channels, hw, L.channels_last, a.thresh, L.cls_bias};
-    raw.template for_range<kPassThreads>(lo, hi, visit);
-  }
-  stamp(3);
-  if (PASS < 2) {
+    });
     if (PASS == 0) {
 #pragma unroll
       for (int d = 32; d > 0; d >>= 1) {
@@ -645,23 +603,96 @@ __global__ __launch_bounds__(kPassThreads) void select_pass_kernel(const DecodeA
       if (lane == 0) { atomicMax(&s_range[0], my_max); atomicMax(&s_range[1], my_min_inv); }
     }
     __syncthreads();
-    uint32_t *g_hist = S.hist[PASS == 0 ? 0 : 1];
     for (uint32_t i = threadIdx.x; i < kRadixBins; i += kPassThreads) {
       const uint32_t h = s_hist[i];
       if (h) atomicAdd(&g_hist[i], h);
     }
     if (PASS == 0 && threadIdx.x == 0) { atomicMax(&S.kmax, s_range[0]); atomicMax(&S.kmin_inv, s_range[1]); }
-  } else {
-    __syncthreads();
-    const uint32_t staged = s_misc[24] < kStageKeys ? s_misc[24] : kStageKeys;
-    if (staged) {
-      if (threadIdx.x == 0) s_misc[25] = atomicAdd(&S.surv_count, staged);
-      __syncthreads();
-      const uint32_t g0 = s_misc[25];
-      for (uint32_t i = threadIdx.x; i < staged; i += kPassThreads)
-        if (g0 + i < a.surv_cap) surv[g0 + i] = s_stage[i];
-    }
+  };
+
+  // pass 0 range: every candidate has score >= thresh; sigmoid outputs never exceed 1
+  SelState st;
+  st.lo = make_key(a.thresh, 0xffffffffu);
+  st.hi = kLogits ? make_key(1.0f, 0u) : ~0ull;
+  st.remaining = static_cast<uint32_t>(a.top_n);
+  st.taken = st.in_bin = st.done = 0;
+  if (PASS == 0) {
+    stamp(1);
+    histogram(st.lo, st.hi, false, S.hist[0]);
+    stamp(4);
+    return;
   }
+
+  // ---- PASS 1 ----
+  advance_state(st, S.hist[0], ~S.kmin_inv, S.kmax, a.sort_cap, s_hist, s_misc);
+  uint64_t *surv = a.surv + static_cast<uint64_t>(seg) * a.surv_cap;
+  constexpr uint32_t kStageKeys = kRadixBins / 2;           // s_hist reinterpreted as 64-bit keys
+  uint64_t *s_stage = reinterpret_cast<uint64_t *>(s_hist);
+  // every key >= T64 of [w_lo, w_hi) goes to the survivor list: staged in LDS (the histogram's 8 KiB = 1024 keys, idle now),
+  // ONE returning global atomic per workgroup and stage-full; a returning atomic per wave and round cost 1-2 us each
+  auto filter = [&](uint64_t T64, uint32_t w_lo, uint32_t w_hi) {
+    if (threadIdx.x == 0) s_misc[24] = 0;
+    __syncthreads();
+    auto flush = [&]() {                                     // block-uniform call sites
+      __syncthreads();
+      const uint32_t staged = s_misc[24] < kStageKeys ? s_misc[24] : kStageKeys;
+      if (staged) {
+        if (threadIdx.x == 0) s_misc[25] = atomicAdd(&S.surv_count, staged);
+        __syncthreads();
+        const uint32_t g0 = s_misc[25];
+        for (uint32_t i = threadIdx.x; i < staged; i += kPassThreads)
+          if (g0 + i < a.surv_cap) surv[g0 + i] = s_stage[i];
+      }
+      __syncthreads();
+      if (threadIdx.x == 0) s_misc[24] = 0;
+      __syncthreads();
+    };
+    // slabs of one load round (8 keys per lane): the stage (1024 keys) cannot overflow inside a slab of 2048 keys twice
+    for (uint32_t s_lo = w_lo; s_lo < w_hi; s_lo += kSelSlice) {
+      const uint32_t s_hi = s_lo + kSelSlice < w_hi ? s_lo + kSelSlice : w_hi;
+      walk(s_lo, s_hi, [&](uint64_t key, bool valid) {
+        const bool take = valid && key >= T64;
+        const uint64_t m = __ballot(take);
+        if (!m) return;
+        const int leader = __ffsll(static_cast<unsigned long long>(m)) - 1;
+        uint32_t base = 0;
+        if (lane == leader) base = atomicAdd(&s_misc[24], static_cast<uint32_t>(__popcll(m)));
+        base = __shfl(base, leader, kWave);
+        if (take) {
+          const uint32_t pos = base + __popcll(m & ((1ull << lane) - 1ull));
+          if (pos < kStageKeys) s_stage[pos] = key;
+          else { const uint32_t g = atomicAdd(&S.surv_count, 1u); if (g < a.surv_cap) surv[g] = key; }   // stage full (rare)
+        }
+      });
+      if (s_hi < w_hi) flush();                              // (only the last workgroup of a second digit walks more than one slab)
+    }
+    flush();
+  };
+  auto publish = [&](const SelState &f, bool fits) {
+    S.T = f.lo; S.bin_hi = f.hi; S.expected = f.taken + f.in_bin; S.need = f.remaining; S.filtered = fits ? 1u : 0u;
+    S.n_above = f.taken; S.n_bin = f.in_bin;
+  };
+  stamp(1);
+  if (st.done || st.taken + st.in_bin <= a.surv_cap) {
+    // the common routes: filter this slice now
+    if (part == 0 && threadIdx.x == 0) publish(st, true);
+    stamp(2);
+    filter(st.lo, lo, hi);
+    stamp(4);
+    return;
+  }
+  // second digit: this slice's histogram over the boundary bin, then the ticket
+  histogram(st.lo, st.hi, true, S.hist[1]);
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) s_misc[26] = atomicAdd(&S.arrived, 1u);
+  __syncthreads();
+  if (s_misc[26] != n_live - 1) return;                      // (block-uniform) somebody else is last
+  __threadfence();
+  advance_state<true>(st, S.hist[1], st.lo, st.hi, a.sort_cap, s_hist, s_misc);
+  const bool fits = st.taken + st.in_bin <= a.surv_cap;
+  if (threadIdx.x == 0) publish(st, fits);
+  if (fits) filter(st.lo, 0, total);                         // (adversarial key sets that two digits cannot split: select_decode walks the source itself)
   stamp(4);
 }
 

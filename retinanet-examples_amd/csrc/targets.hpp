@@ -1,4 +1,4 @@
-// targets.hpp -- fused training-target assignment for one pyramid level of the whole batch
+// targets.hpp -- fused training-target assignment for the pyramid levels of the whole batch
 // (SURVEY.md 8f rank 2).  One thread per anchor (image, a, y, x): IoU against every ground-truth box
 // of its image (LDS-resident), arg-max, regression deltas, depth and the one-hot class map, written
 // straight in the [A, *, H, W] layout the loss consumes.
@@ -13,6 +13,7 @@
 #pragma once
 
 #include "common.hpp"
+#include "../../include/odtk_hip.h"
 
 namespace odtk {
 
@@ -29,14 +30,15 @@ struct SnapArgs {
   float anchors[ODTK_MAX_ANCHORS * 4];
 };
 
-__global__ __launch_bounds__(kSnapThreads) void snap_to_anchors_kernel(const SnapArgs a) {
+// One workgroup: 256 consecutive (anchor, y, x) cells of level `a`, image blockIdx.y.
+__device__ __forceinline__ void snap_to_anchors_block(const SnapArgs &a, int block_in_level) {
   __shared__ float s_box[kSnapMaxBoxes * 6];   // x1, y1, x2, y2, area, class of the VALID boxes of this round, in order
   __shared__ int s_n;
 
   const int b = blockIdx.y;
   const float *tg = a.targets + static_cast<size_t>(b) * a.n_max * 5;
   const int hw = a.height * a.width;
-  const int cell = blockIdx.x * kSnapThreads + threadIdx.x;     // (anchor, y, x) flattened
+  const int cell = block_in_level * kSnapThreads + threadIdx.x;     // (anchor, y, x) flattened
   const bool live = cell < a.num_anchors * hw;
   const int an = live ? cell / hw : 0, pix = live ? cell - an * hw : 0;
   const int y = pix / a.width, x = pix - y * a.width;
@@ -119,6 +121,27 @@ __global__ __launch_bounds__(kSnapThreads) void snap_to_anchors_kernel(const Sna
     float *cls = a.cls_target + (img + an) * a.num_classes * hw + pix;
     for (int c = 0; c < a.num_classes; ++c) cls[static_cast<size_t>(c) * hw] = (c == hot) ? 1.0f : 0.0f;
   }
+}
+
+__global__ __launch_bounds__(kSnapThreads) void snap_to_anchors_kernel(const SnapArgs a) {
+  snap_to_anchors_block(a, static_cast<int>(blockIdx.x));
+}
+
+// All pyramid levels of the batch in ONE launch (a level table in the kernel arguments, like the loss): five launches of
+// 2 .. 170 workgroups each cost 44 us per training step, mostly launch boundaries.
+struct SnapLevelsArgs {
+  SnapArgs lv[ODTK_MAX_LEVELS];
+  uint32_t block_begin[ODTK_MAX_LEVELS + 1];
+  int n_levels;
+};
+static_assert(sizeof(SnapLevelsArgs) <= 4096, "kernel arguments travel by value");
+
+__global__ __launch_bounds__(kSnapThreads) void snap_to_anchors_levels_kernel(const SnapLevelsArgs a) {
+  int l = 0;
+#pragma unroll
+  for (int i = 1; i < ODTK_MAX_LEVELS; ++i)
+    if (i < a.n_levels && blockIdx.x >= a.block_begin[i]) l = i;
+  snap_to_anchors_block(a.lv[l], static_cast<int>(blockIdx.x - a.block_begin[l]));
 }
 
 }  // namespace odtk

@@ -42,6 +42,13 @@ class LossLevel(ctypes.Structure):
                 ('channels_last', ctypes.c_int32), ('pad_', ctypes.c_int32)]
 
 
+class SnapLevel(ctypes.Structure):
+    """odtk_snap_level_t"""
+    _fields_ = [('anchors', ctypes.POINTER(ctypes.c_float)), ('cls_target', ctypes.c_void_p), ('box_target', ctypes.c_void_p),
+                ('depth', ctypes.c_void_p), ('height', ctypes.c_int32), ('width', ctypes.c_int32), ('stride', ctypes.c_int32),
+                ('pad_', ctypes.c_int32)]
+
+
 class Level(ctypes.Structure):
     """odtk_level_t"""
     _fields_ = [('cls', _vp), ('box', _vp), ('height', ctypes.c_int32), ('width', ctypes.c_int32),
@@ -70,6 +77,8 @@ _SIGNATURES = {
     'odtk_snap_to_anchors': (ctypes.c_int, [ctypes.c_int, _vp, ctypes.c_int, _fp, ctypes.c_int, ctypes.c_int,
                                             ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float,
                                             _vp, _vp, _vp, _vp]),
+    'odtk_snap_to_anchors_levels': (ctypes.c_int, [ctypes.c_int, _vp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(SnapLevel),
+                                                   ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float, _vp]),
     'odtk_retina_loss_forward': (ctypes.c_int, [_vp, _vp, _vp, _vp] + [ctypes.c_int] * 8 + [ctypes.c_float] * 3 + [_vp, _vp]),
     'odtk_retina_loss_backward': (ctypes.c_int, [_vp, _vp, _vp, _vp] + [ctypes.c_int] * 8 + [ctypes.c_float] * 3 +
                                   [_vp, _vp, _vp, _vp, _vp]),
@@ -90,7 +99,8 @@ _SIGNATURES = {
 }
 
 KERNEL_NAMES = ('prefilter_scan_kernel', 'select_decode_kernel', 'nms_kernel', 'iou_pairs_kernel', 'bias_act_kernel',
-                'snap_to_anchors_kernel', 'gemm_bias_act', 'retina_loss_kernel', 'select_hist_kernel', 'select_filter_kernel')
+                'snap_to_anchors_kernel', 'gemm_bias_act', 'retina_loss_kernel', 'select_hist_kernel', 'select_filter_kernel',
+                'nms_first_round_kernel', 'rotated_sup_matrix_kernel')
 
 _lib = None
 
@@ -378,6 +388,43 @@ def snap_to_anchors(targets, anchors, num_classes, height, width, stride, iou_ba
                                               depth.data_ptr(), stream),
                'snap_to_anchors')
     return cls, box_t, depth
+
+
+def snap_to_anchors_levels(targets, anchors_list, num_classes, sizes, strides, iou_background, iou_foreground,
+                           want_cls_target=True):
+    """`snap_to_anchors` for every pyramid level in ONE launch.  anchors_list: per level [A, 4]; sizes: per level (H, W).
+    -> lists (cls_targets or Nones, box_targets, depths)."""
+    _check_input(targets, 'targets')
+    if targets.dim() != 3 or targets.shape[2] != 5:
+        raise RuntimeError('targets must be [B, N, 5]')
+    n = len(anchors_list)
+    if not (n == len(sizes) == len(strides)) or n == 0 or n > MAX_LEVELS:
+        raise RuntimeError('snap_to_anchors_levels: need 1..%d levels with matching lists' % MAX_LEVELS)
+    b, n_max = targets.shape[0], targets.shape[1]
+    dev = targets.device
+    arr = (SnapLevel * n)()
+    keep, cls_t, box_t, depth_t = [], [], [], []
+    a = None
+    with torch.cuda.device(dev):
+        for i, (anchors, (h, w), s) in enumerate(zip(anchors_list, sizes, strides)):
+            carr, ln = _anchor_array(anchors.reshape(-1).tolist() if isinstance(anchors, torch.Tensor) else anchors)
+            if a is None:
+                a = ln // 4
+            if ln != 4 * a:
+                raise RuntimeError('snap_to_anchors_levels: every level needs the same number of anchors')
+            keep.append(carr)
+            cls_t.append(torch.empty((b, a, num_classes, h, w), dtype=torch.float32, device=dev) if want_cls_target else None)
+            box_t.append(torch.empty((b, a, 4, h, w), dtype=torch.float32, device=dev))
+            depth_t.append(torch.empty((b, a, 1, h, w), dtype=torch.float32, device=dev))
+            arr[i].anchors = ctypes.cast(carr, _fp)
+            arr[i].cls_target = cls_t[-1].data_ptr() if want_cls_target else None
+            arr[i].box_target, arr[i].depth = box_t[-1].data_ptr(), depth_t[-1].data_ptr()
+            arr[i].height, arr[i].width, arr[i].stride = int(h), int(w), int(s)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _check(library().odtk_snap_to_anchors_levels(b, targets.data_ptr(), n_max, n, arr, a, int(num_classes),
+                                                     float(iou_background), float(iou_foreground), stream),
+               'snap_to_anchors_levels')
+    return cls_t, box_t, depth_t
 
 
 def _loss_geometry(cls_head, box_head, depth, box_target):

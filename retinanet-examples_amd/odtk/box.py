@@ -186,6 +186,17 @@ def snap_to_anchors_batched(targets, width, height, stride, anchors, num_classes
                               int(stride), anchor_ious[0], anchor_ious[1], want_cls_target)
 
 
+MAX_LEVELS_PER_CALL = _C.MAX_LEVELS
+
+
+def snap_to_anchors_levels(targets, sizes, strides, anchors_list, num_classes, anchor_ious, want_cls_target=True):
+    """snap_to_anchors_batched for every pyramid level in ONE fused HIP launch (GPU only; csrc/targets.hpp).
+    sizes: per level (H, W) of the head tensors; -> lists (cls_targets | Nones, box_targets, depths)."""
+    _require_gpu(targets, 'snap_to_anchors_levels')
+    return _C.snap_to_anchors_levels(targets.float().contiguous(), anchors_list, num_classes, [(int(h), int(w)) for h, w in sizes],
+                                     [int(s) for s in strides], anchor_ious[0], anchor_ious[1], want_cls_target)
+
+
 def rotate_boxes(boxes, points=False):
     """(x, y, w, h, theta) targets -> ([x1, y1, x2, y2, sin, cos], ordered corner quads [N, 8])
     (reference utils.py:33-82; `points=True` takes (x1, y1, x2, y2, theta))."""

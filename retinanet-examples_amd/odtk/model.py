@@ -276,14 +276,20 @@ class Model(nn.Module):
         anchors (reference model.py:186-210); `depth` is -1 ignore / 0 background / class+1."""
         cls_total, box_total, foreground = 0.0, 0.0, 0.0
         if self.fused_loss and cls_heads[0].is_cuda:
-            # targets of every level (one HIP launch each; the class map is implied by depth and not even built), then focal
+            # targets of every level (ONE HIP launch for all of them; the class map is implied by depth and not even built), then focal
             # + smooth-L1 + masks + sums of ALL levels in one HIP pass -- and one more in backward (csrc/loss.hpp)
-            depths, box_targets = [], []
-            for cls_head in cls_heads:
-                stride = x.shape[-1] / cls_head.shape[-1]
-                _, box_target, depth = self._extract_targets(targets, stride, cls_head.shape[-2:], False)
-                depths.append(depth)
-                box_targets.append(box_target)
+            if not self.rotated_bbox and len(cls_heads) <= box_ops.MAX_LEVELS_PER_CALL:
+                strides = [x.shape[-1] / c.shape[-1] for c in cls_heads]
+                _, box_targets, depths = box_ops.snap_to_anchors_levels(
+                    targets, [tuple(c.shape[-2:]) for c in cls_heads], strides, [self.level_anchors(s) for s in strides],
+                    self.classes, self.anchor_ious, want_cls_target=False)
+            else:
+                depths, box_targets = [], []
+                for cls_head in cls_heads:
+                    stride = x.shape[-1] / cls_head.shape[-1]
+                    _, box_target, depth = self._extract_targets(targets, stride, cls_head.shape[-2:], False)
+                    depths.append(depth)
+                    box_targets.append(box_target)
             cls_sums, box_sums, fg = fused_pyramid_loss(cls_heads, box_heads, depths, box_targets, self.cls_criterion.alpha,
                                                         self.cls_criterion.gamma, self.box_criterion.beta)
             foreground = fg.clamp(min=1).sum()              # per level, as the reference clamps (model.py:196)

@@ -157,3 +157,60 @@ def test_short_runs_take_the_generic_path(top_n):
     out = box.detect([c.cuda() for c in cls], [d.cuda() for d in dl], strides, anchors, 0.05, top_n, 0.5, 100)
     _, ref = _oracle_detect(cls, dl, strides, anchors, 0.05, top_n, 0.5, 100, False)
     same_bits(out, ref, 'detect, top_n %d' % top_n)
+
+
+@pytest.mark.parametrize('rotated', [False, True], ids=['axis', 'rotated'])
+@pytest.mark.parametrize('count,ndet,spread', [(4000, 100, 10.0), (4000, 300, 25.0), (9000, 100, 10.0)],
+                         ids=['crowd-4000-d100', 'crowd-4000-d300', 'crowd-9000-scratch-keys'])
+def test_heavy_suppression_standalone(rotated, count, ndet, spread):
+    """A crowd: thousands of same-class boxes on a few pixels, a handful survive.  Exercises the filter pass (everything
+    left is tested against the kept list at once when a round's yield says it will all be examined anyway) and, axis-aligned,
+    the push form of a round (one parallel pass per kept box when fewer than 1 in 20 candidates survive)."""
+    if rotated and count == 9000:
+        count = 8000
+    scores, boxes, classes = random_candidates(7000 + count + ndet + rotated, 2, count, 1, rotated, spread)
+    g = torch.Generator().manual_seed(count + ndet)
+    ctr = (boxes[..., :2] + boxes[..., 2:4]) / 2
+    wh = 40 + torch.rand(2, count, 2, generator=g) * 4                # nearly equal sizes: neighbours overlap by more than half
+    boxes[..., :2], boxes[..., 2:4] = ctr - wh / 2, ctr + wh / 2
+    if rotated:
+        th = (torch.rand(2, count, generator=g) - 0.5) * 0.2
+        boxes[..., 4], boxes[..., 5] = th.sin(), th.cos()
+    out = _C.nms(scores.cuda(), boxes.cuda(), classes.cuda(), 0.5, ndet, rotated, return_indices=True)
+    ref = c_oracle.nms(scores.numpy(), boxes.numpy(), classes.numpy(), 0.5, ndet, rotated=rotated)
+    assert np.array_equal(out[3].cpu().numpy().astype(np.int64), ref[3]), 'kept positions'
+    same_bits(out, ref, 'nms')
+    kept = int((out[0] > 0).sum(1).max())
+    assert 1 <= kept < count // 20, kept                              # heavy suppression indeed
+
+
+@pytest.mark.parametrize('rotated', [False, True], ids=['axis', 'rotated'])
+def test_heavy_suppression_through_detect(rotated):
+    """The same through `detect` (sorted-run mode -> filter -> key list): every level's candidates sit on one small patch."""
+    strides = [8, 16, 32]
+    A, nb = (27, 6) if rotated else (9, 4)
+    g = torch.Generator().manual_seed(31 + rotated)
+    cls, dl = [], []
+    for s in strides:
+        h, w = 256 // s, 320 // s
+        c = torch.zeros(2, A * 2, h, w)
+        ph, pw = max(2, (3 * h) // 4), max(2, (3 * w) // 4)             # a patch of 3/4 x 3/4 of the level ...
+        for a_idx in ((12, 13, 14) if rotated else (3, 4, 5)):          # ... three anchors of one scale (one angle), class 0 only:
+            c[:, 2 * a_idx, 1:1 + ph, 1:1 + pw] = torch.rand(2, ph, pw, generator=g) * 0.9 + 0.06   # neighbours overlap by > 1/2
+        cls.append(c)
+        d = torch.randn(2, A * nb, h, w, generator=g) * 0.05
+        if rotated:
+            d.view(2, A, nb, h, w)[:, :, 4] = 0.0                    # sin
+            d.view(2, A, nb, h, w)[:, :, 5] = 1.0                    # cos: well-formed quads
+        dl.append(d)
+    sizes = [c[0].numel() for c in cls]
+    joint = synthetic.make_unique_scores(torch.cat([c.reshape(2, -1) for c in cls], 1), 0.05)
+    cls = [j.reshape(c.shape) for j, c in zip(joint.split(sizes, 1), cls)]
+    anchors = {s: (box.generate_anchors_rotated(s, RATIOS, SCALES, ANGLES) if rotated else box.generate_anchors(s, RATIOS, SCALES))
+               for s in strides}
+    out = box.detect([c.cuda() for c in cls], [d.cuda() for d in dl], strides, anchors, 0.05, 1000, 0.5, 100, rotated)
+    cat, ref = _oracle_detect(cls, dl, strides, anchors, 0.05, 1000, 0.5, 100, rotated)
+    same_bits(out, ref, 'detect, crowd')
+    n_cand = int((cat[0][0] > 0).sum())
+    kept = int((out[0][0] > 0).sum())
+    assert n_cand > 1500 and 3 <= kept < n_cand // 10, (n_cand, kept)   # (the oracle comparison above is what matters)

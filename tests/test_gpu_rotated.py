@@ -74,9 +74,13 @@ def test_rotated_nms_vs_c_oracle(count, ndet, thr, own):
     if own:
         out = [torch.empty(2, ndet, device='cuda'), torch.empty(2, ndet, 6, device='cuda'),
                torch.empty(2, ndet, device='cuda'), torch.empty(2, ndet, dtype=torch.int32, device='cuda')]
-        ws = torch.empty(256, dtype=torch.uint8, device='cuda')
-        rc = lib.odtk_nms_ex(2, _C._ptrs([s, b, c]), _C._ptrs(out), 4, count, ndet, thr,
-                             _C.FLAG_ROTATED | _C.FLAG_ROTATED_NMS_FIXED_ANGLE, ws.data_ptr(), 256,
+        flags = _C.FLAG_ROTATED | _C.FLAG_ROTATED_NMS_FIXED_ANGLE
+        size = lib.odtk_nms_ex(2, None, None, 4, count, ndet, thr, flags, None, 0, None)     # two-phase: query, then call
+        assert size > 256                              # rotated: first-round boxes + suppression matrix live in the workspace
+        ws = torch.empty(size, dtype=torch.uint8, device='cuda')
+        assert lib.odtk_nms_ex(2, _C._ptrs([s, b, c]), _C._ptrs(out), 4, count, ndet, thr, flags, ws.data_ptr(), 256,
+                               torch.cuda.current_stream().cuda_stream) == _C.ERR_WORKSPACE   # "Workspace is too small!"
+        rc = lib.odtk_nms_ex(2, _C._ptrs([s, b, c]), _C._ptrs(out), 4, count, ndet, thr, flags, ws.data_ptr(), size,
                              torch.cuda.current_stream().cuda_stream)
         assert rc == 0
         torch.cuda.synchronize()

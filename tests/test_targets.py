@@ -32,8 +32,15 @@ def test_snap_to_anchors_matches_reference_fixture(path):
     prod = box.snap_to_anchors(boxes, size, stride, anchors, classes, 'cpu', ious)
     for o, p, k in zip(ora, prod, ('cls_target', 'box_target', 'depth')):
         assert o.shape == tuple(g[k].shape)
-        assert np.array_equal(_bits(o.numpy()), _bits(g[k])), k          # oracle == reference, bit for bit
-        assert np.array_equal(_bits(p.numpy()), _bits(g[k])), k          # product == reference, bit for bit
+        assert np.array_equal(_bits(o.numpy()), _bits(p.numpy())), k     # oracle == product on this machine, bit for bit
+        if k == 'box_target':
+            # the deltas go through torch.log, whose vectorised CPU routine differs by an ulp between CPU generations (the
+            # fixture was made in the build container; the GPU box's host is another CPU): values within 2 ulp, the decisions
+            # (which anchors got a box, i.e. exact zeros) bit for bit
+            assert np.array_equal(o.numpy() == 0, g[k] == 0), k
+            assert np.allclose(o.numpy(), g[k], rtol=3e-7, atol=1e-7), k
+        else:
+            assert np.array_equal(_bits(o.numpy()), _bits(g[k])), k      # == reference, bit for bit
 
 
 @pytest.mark.skipif(not ref_loader.available() or torch.cuda.is_available(), reason='reference tree only in the build container')
@@ -180,6 +187,34 @@ def test_fused_kernel_more_than_1024_rows():
         assert np.array_equal(_bits(out[0][i].cpu().numpy()), _bits(ora[0].numpy()))
         assert np.array_equal(_bits(out[2][i].cpu().numpy()), _bits(ora[2].numpy()))
         assert np.allclose(out[1][i].cpu().numpy(), ora[1].numpy(), rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('want_cls', [True, False])
+def test_all_levels_in_one_launch_equal_the_per_level_launches(want_cls):
+    """odtk_snap_to_anchors_levels (one launch over a level table, what the fused training loss uses) writes the same bits
+    as five odtk_snap_to_anchors launches -- which are pinned to the reference's fixtures above; 6 levels = ODTK_MAX_LEVELS,
+    one of them a single cell, padding rows, an image without any box."""
+    from odtk import _C
+    g = torch.Generator().manual_seed(8)
+    strides, wpx, hpx = [4, 8, 16, 32, 64, 128], 320, 256
+    sizes = [(max(1, hpx // s), max(1, wpx // s)) for s in strides]
+    anchors = [box.generate_anchors(s, RATIOS, SCALES) for s in strides]
+    per_image = []
+    for n in (7, 0, 31):
+        xy = torch.rand(n, 2, generator=g) * torch.tensor([wpx * 0.8, hpx * 0.8])
+        wh = torch.rand(n, 2, generator=g) * 120 + 6
+        per_image.append(torch.cat([xy, wh, torch.randint(0, 12, (n, 1), generator=g).float()], 1))
+    targets = _pad(per_image, 40).cuda()
+    cls_all, box_all, depth_all = _C.snap_to_anchors_levels(targets, anchors, 12, sizes, strides, 0.4, 0.5, want_cls_target=want_cls)
+    for l, (s, (h, w)) in enumerate(zip(strides, sizes)):
+        one = _C.snap_to_anchors(targets, anchors[l], 12, h, w, s, 0.4, 0.5, want_cls_target=want_cls)
+        assert (cls_all[l] is None) == (not want_cls)
+        if want_cls:
+            assert torch.equal(cls_all[l], one[0]), 'level %d class map' % l
+        assert torch.equal(box_all[l].view(torch.int32), one[1].view(torch.int32)), 'level %d deltas' % l
+        assert torch.equal(depth_all[l], one[2]), 'level %d depth' % l
+    assert float(depth_all[1][0].max()) > 0 and float(depth_all[1][1].max()) == 0       # image 1 has no box: all background
 
 
 # ---- rotated target assignment against the reference's OWN snap_to_anchors_rotated (odtk/box.py:192-252), run on the

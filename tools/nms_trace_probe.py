@@ -76,10 +76,19 @@ for name, fn in (('in Model.forward', step), ('back to back', alone)):
     print('== %s (%s): nms workgroups, us relative to the first start' % (tag, name))
     for i, r in enumerate(rows):
         wall = (int(r[4]) - int(r[0])) / 100.0
-        print('  img %2d: start %6.2f | compact %5.2f | round1 select %5.2f | sort %5.2f | chunks %7.2f | total %7.2f us | consumed %5d of K %5d | kept %3d | %.2f GHz'
+        print('  img %2d: start %6.2f | setup %5.2f | round1 load/select %5.2f | order %5.2f | chunks %7.2f | total %7.2f us | consumed %5d of K %5d | kept %3d | %.2f GHz'
               % (i, (int(r[0]) - t0) / 100.0, (int(r[1]) - int(r[0])) / 100.0, (int(r[2]) - int(r[1])) / 100.0,
                  (int(r[3]) - int(r[2])) / 100.0, (int(r[4]) - int(r[3])) / 100.0, wall, int(r[5]), int(r[6]),
                  int((out[0][i] > 0).sum()), int(r[7]) / max(wall * 1e3, 1e-9)))
+    ph = t[4096 + 96:4096 + 96 + 96].view(-1, 2)
+    names = {1: 'round selected', 2: 'boxes staged', 3: 'chunks / push done', 4: 'filter done'}
+    line, prev_t = [], int(rows[0][0])
+    for pid, pt in ph.tolist():
+        if pid == 0:
+            break
+        line.append('%s +%.2f' % (names.get(pid, str(pid)), (pt - prev_t) / 100.0))
+        prev_t = pt
+    print('    img 0 phases (us since the previous one; first since kernel start): ' + ' | '.join(line))
     ch = t[4096:4096 + 80].view(-1, 4)
     prev = None
     for c, r in enumerate(ch):
@@ -91,7 +100,8 @@ for name, fn in (('in Model.forward', step), ('back to back', alone)):
         prev = int(r[2])
 
 # kernel time of the launch itself, back to back
-_C.profile_enable(True, ('nms_kernel', 'select_decode_kernel', 'prefilter_scan_kernel', 'select_hist_kernel', 'select_filter_kernel'))
+_C.profile_enable(True, ('nms_kernel', 'select_decode_kernel', 'prefilter_scan_kernel', 'select_hist_kernel', 'select_filter_kernel',
+                         'nms_first_round_kernel', 'rotated_sup_matrix_kernel'))
 _C.profile_collect()
 for _ in range(20):
     alone()

@@ -5,14 +5,14 @@
 #      (its average prefilter duration must agree with the hipEvent figure in the bench line)
 #   2. rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, as MI355X_MICROARCH.md prescribes) on the
 #      post-processing alone, bf16 fused (what the step runs) and fp32 (the reference boundary) -> traffic JSON
-#   3. bench lines of the other BASELINE configs
+#   3. rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE on a short bench run -> MFMA utilisation of the convolutions
 R=${1:-r02}
 OUT=gpurun_out/prof_$R
 mkdir -p $OUT
 export TMPDIR=/tmp
 STEPS=${STEPS:-50}
 
-rocprofv3 --kernel-trace --stats -d $OUT/bench -o bench -- python bench.py --steps $STEPS --warmup 10 --cpu-seconds 0 --no-eager-leg \
+rocprofv3 --kernel-trace --stats -d $OUT/bench -o bench -- python bench.py --steps $STEPS --warmup 10 --cpu-seconds 0 --no-eager-leg --no-other-configs \
     > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err
 DB=$(find $OUT/bench -name "*_results.db" | head -1)
 python tools/rocpd_stats.py "$DB" --steady prefilter_scan:$STEPS --csv $OUT/${R}_bench_steady_kernel_stats.csv --top 25 > $OUT/${R}_bench_steady_kernel_stats.txt 2>&1
@@ -30,11 +30,11 @@ pmc() {   # name key bytes-per-score args...
 pmc bf16_fused_sparse bf16_logits_channels_last 2 --kind sparse --dtype bf16 --logits --channels-last --bias
 pmc fp32_sparse fp32_scores_nchw 4 --kind sparse
 
-python bench.py --backbone ResNet101FPN --batch 16 --cpu-seconds 0 --no-eager-leg > $OUT/bench_${R}_rn101_bs16.json 2> $OUT/bench_rn101.err
-python bench.py --rotated-bbox --cpu-seconds 0 --no-eager-leg > $OUT/bench_${R}_rn50_rotated_bs8.json 2> $OUT/bench_rot.err
-python bench.py --mode train > $OUT/bench_${R}_train_rn50_fp32_bs2.json 2> $OUT/bench_train.err
-python bench.py --mode train --no-fused-loss > $OUT/bench_${R}_train_rn50_fp32_bs2_torch_loss.json 2>> $OUT/bench_train.err
-python bench.py --mode train --dtype fp16 > $OUT/bench_${R}_train_rn50_amp_bs2.json 2>> $OUT/bench_train.err
+# 3. MFMA utilisation of the convolution kernels (SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE, one pass, short run)
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $OUT/pmc_mfma -o pmc -- python bench.py --steps 6 --warmup 4 \
+    --cpu-seconds 0 --no-eager-leg --no-other-configs > $OUT/pmc_mfma.log 2>&1
+python tools/pmc_mfma.py "$(find $OUT/pmc_mfma -name '*_results.db' | head -1)" --steps 3 --csv $OUT/${R}_pmc_mfma_bench.csv > $OUT/${R}_pmc_mfma_bench.txt 2>&1
+# (the other BASELINE configurations are legs of the default bench.py run since round 3: `other_configs` on its line)
 rm -rf $OUT/bench/*/*.db.tmp 2>/dev/null
 # the raw rocpd databases are large: keep only the summaries
 find $OUT -name "*.db" -size +8M -delete
