@@ -456,9 +456,9 @@ def run_infer(args, rank, world, dev):
     ms, n = prof['prefilter_scan_kernel']
     roofline = None
     # HBM traffic per launch comes from PMC passes (cannot be collected live next to the timing):
-    # profiles/r02_pmc_traffic.json, quoted only when the workload matches the profiled one
+    # profiles/r03_pmc_traffic.json (tools/profile_round.sh), quoted only when the workload matches the profiled one
     traffic, traffic_src = None, None
-    for name in ('r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
+    for name in ('r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
         try:
             pmc = json.load(open(os.path.join(ROOT, 'profiles', name)))
             key = 'bf16_logits_channels_last' if (model.fused_postprocess and bytes_per_score == 2) else 'fp32_scores_nchw'
