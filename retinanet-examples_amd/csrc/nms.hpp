@@ -331,7 +331,7 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsArgs a) {
   const float *in_c = uniform_ptr(a.classes + static_cast<size_t>(img) * count);
   auto stamp = [&](int k) { if (a.trace && tid == 0) a.trace[(gridDim.x + blockIdx.x) * 8 + k] = wall_clock64(); };
   // debug: image 0's phases beyond the first round (id, time) pairs: 1 round selected, 2 boxes staged, 3 chunks / push done,
-  // 4 filter done
+  // 4 filter done, 5 push over everything done
   uint32_t n_phase = 0;
   auto phase = [&](unsigned long long id) {
     if constexpr (NB == 4)                                   // (the rotated kernels have no register to spare for it)
@@ -515,6 +515,84 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsArgs a) {
   };
 
   while (left > 0 && kept < ndet) {
+    // ---- heavy suppression, everything that is left fits four candidates per thread (axis-aligned): push over ALL of it ----
+    // After a filter pass the survivors are a key list, and when the last round kept fewer than 1 in 20 of its candidates
+    // most of them will die too.  No round, no sort, no further filter then: every thread owns up to four candidates (key,
+    // box, class in registers), and per KEPT box there is one block-wide maximum over the alive keys (the greedy order IS
+    // "best alive candidate next") and one parallel test of every alive candidate against it -- ~0.7 us per kept box, where a
+    // round costs ~10 us of selection and sorting before its first box.
+    if constexpr (NB == 4) {
+      if (!runs && !first_round && left <= 4u * kNmsThreads && list_n <= 4u * kNmsThreads &&
+          static_cast<uint32_t>(last_round_kept) * 20u < last_round_size) {
+        constexpr int kOwn = 4;
+        static_assert(kOwn == 4, "the pull below is written out four times");
+        uint64_t mk[kOwn];
+        float mb[kOwn][4], mc[kOwn];
+#pragma unroll
+        for (int u = 0; u < kOwn; ++u) {
+          const uint32_t i = static_cast<uint32_t>(u) * kNmsThreads + tid;
+          uint64_t key = i < list_n ? s_keys[i] : 0;
+          key = key < upper ? key : 0;                         // already handed to a round
+          mk[u] = key;
+          mc[u] = 0.0f;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) mb[u][k] = 0.0f;
+          if (key) {
+            const uint32_t p = key_index(key);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) mb[u][k] = in_b[static_cast<size_t>(p) * 4 + k];
+            mc[u] = in_c[p];
+          }
+        }
+        if (kept > pulled) {                                   // (the boxes kept since the last filter pass)
+          if (mk[0] && !pull_against_kept(s_kcls, s_kbox, pulled, kept, 1, mb[0], mc[0], true, thr)) mk[0] = 0;
+          if (mk[1] && !pull_against_kept(s_kcls, s_kbox, pulled, kept, 1, mb[1], mc[1], true, thr)) mk[1] = 0;
+          if (mk[2] && !pull_against_kept(s_kcls, s_kbox, pulled, kept, 1, mb[2], mc[2], true, thr)) mk[2] = 0;
+          if (mk[3] && !pull_against_kept(s_kcls, s_kbox, pulled, kept, 1, mb[3], mc[3], true, thr)) mk[3] = 0;
+        }
+        while (kept < ndet) {                                  // block-uniform trip count
+          const uint64_t b01 = mk[0] > mk[1] ? mk[0] : mk[1], b23 = mk[2] > mk[3] ? mk[2] : mk[3];
+          uint64_t best = b01 > b23 ? b01 : b23;
+#pragma unroll
+          for (int d = 32; d > 0; d >>= 1) {
+            const uint64_t o = shfl_xor_u64(best, d);
+            best = o > best ? o : best;
+          }
+          if (lane == 0) s_alive[wave] = best;
+          __syncthreads();
+          best = 0;
+          for (int w = 0; w < kNmsThreads / kWave; ++w) best = s_alive[w] > best ? s_alive[w] : best;
+          best = uniform_u64(best);
+          if (best == 0) { __syncthreads(); break; }           // nothing alive
+#pragma unroll
+          for (int u = 0; u < kOwn; ++u) {
+            if (mk[u] == best) {                               // its owner keeps it (keys are unique) and shows its box to everybody
+#pragma unroll
+              for (int k = 0; k < 4; ++k) { s_kbox[kept * 4 + k] = mb[u][k]; s_box[k] = mb[u][k]; }
+              s_kcls[kept] = mc[u];
+              s_cls[0] = mc[u];
+              s_kscore[kept] = key_score(best);
+              s_ksrc[kept] = static_cast<int32_t>(key_index(best));
+              mk[u] = 0;
+            }
+          }
+          __syncthreads();
+          float kb[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) kb[k] = s_box[k];
+          const float kc = s_cls[0];
+#pragma unroll
+          for (int u = 0; u < kOwn; ++u)
+            if (mk[u] && mc[u] == kc && axis_suppresses(kb, mb[u], thr)) mk[u] = 0;
+          ++kept;
+        }
+        if (tid == 0) s_misc[34] = static_cast<uint32_t>(kept);
+        examined += left;
+        left = 0;
+        phase(5);
+        break;
+      }
+    }
     const int kept_at_round_start = kept;
     // ---- round: the next (up to) 1024 best candidates, in order, into s_sel ----
     uint32_t n_round = left < kNmsRound ? left : kNmsRound;

@@ -220,8 +220,10 @@ def infer(model, path, detections_file, resize, max_size, batch_size, mixed_prec
                 json.dump(doc, f, indent=4)
     if has_truth:
         if rotated_bbox:
-            if verbose:
-                print('Rotated boxes: the polygon-mask evaluation of the reference (pycocotools segm) is not provided.')
+            # said on every rank-0 run, verbose or not: a training loop validating rotated boxes gets NO mAP from this
+            # (reference infer.py:160-172 rasterises the polygons with pycocotools' C mask code, which is not available here)
+            print('Rotated boxes: detections were written, but the polygon-mask (segm) evaluation of the reference needs '
+                  'pycocotools and is not provided -- no mAP is computed.', flush=True)
             return 0
         if verbose:
             print('Evaluating model...')

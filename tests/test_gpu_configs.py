@@ -82,3 +82,29 @@ def test_config4_rotated_model():
     assert int((ref[0] > 0).sum()) > 20
     for h, r in zip(out, ref[:3]):
         assert np.array_equal(np.ascontiguousarray(h.cpu().numpy()).view(np.uint32), r.view(np.uint32))
+
+
+def test_two_backbones_through_model_forward():
+    """a model with several backbones (reference model.py:138) has ten pyramid levels and no fused engine:
+    `Model.forward` decodes in two C-ABI calls and hands 10 x 1000 = 10 000 candidates per image -- more than the NMS keeps
+    LDS-resident -- to the generic NMS.  Against the oracle on the same head tensors."""
+    model, x = _calibrated(['ResNet18FPN', 'ResNet34FPN'], False, (256, 384), 2, seed=3, classes=20)
+    assert model.inference_engine(torch.float32) is None            # no fused form: the eager graph + detect
+    with torch.no_grad():
+        model.cls_head[-1].weight.mul_(1.6)                          # dense: P3 and P4 of both backbones fill their 1000 slots
+        cls_heads, box_heads = model.heads(x)
+        assert len(cls_heads) == 10
+        model.heads = lambda _x: (cls_heads, box_heads)
+        out = model(x)
+    strides = [384 // c.shape[-1] for c in cls_heads]
+    scores = [c.sigmoid() for c in cls_heads]
+    n_cand = sum(min(1000, int((s[0] >= model.threshold).sum())) for s in scores)
+    assert len(scores) * model.top_n > 7680 and n_cand > 2000, n_cand   # 10 000 NMS slots per image: the workspace-key kernel
+    hip = box.detect(scores, box_heads, strides, model.anchors, model.threshold, model.top_n, model.nms, model.detections)
+    for a, b in zip(out, hip):
+        assert torch.equal(a, b)                                     # logits path == strict op on materialised scores
+    ref = box_check.reference_with_proof([s.cpu() for s in scores], [b.cpu() for b in box_heads], strides, model.anchors,
+                                         model.threshold, model.top_n, model.nms, model.detections)
+    assert torch.equal(out[0].cpu(), ref[0]) and torch.equal(out[2].cpu(), ref[2])
+    box_check.check_boxes(out[1], ref[1], ref[3], ref[4], 'two-backbone boxes')
+    assert int((out[0] > 0).sum()) == 2 * model.detections
