@@ -98,8 +98,12 @@ int odtk_decode_rotate(int batch_size, const void *const *inputs, void *const *o
  *   inputs[1]  boxes   float32 [batch, count, {4|6}]
  *   inputs[2]  classes float32 [batch, count]
  *   outputs[0..2]      float32 [batch, detections_per_im], [.., {4|6}], [..]
- * count <= ODTK_MAX_NMS_COUNT: everything is LDS-resident, the workspace query returns a token size.  Larger
- * counts (the reference has no cap, nms.cu:82-160): the query returns batch * count * 8 bytes for the key lists.
+ * Workspace: ALWAYS query (two-phase convention).  Axis-aligned with count <= ODTK_MAX_NMS_COUNT: everything is
+ * LDS-resident and the query returns a token size -- unless detections_per_im is in the thousands and the kept list
+ * leaves no room, then, as for larger counts (the reference has no cap, nms.cu:82-160), batch * count * 8 bytes for
+ * the key lists.  Rotated: additionally the first round in NMS order and its pairwise suppression matrix
+ * (m x m bits per image, m = min(count, 8 * detections_per_im, 1024) rounded up to 64): the rotated NMS is three to
+ * five launches (first round -> matrix on the whole chip -> resolve; csrc/nms.hpp).
  */
 int odtk_nms(int batch_size, const void *const *inputs, void *const *outputs,
              size_t count, int detections_per_im, float nms_thresh,

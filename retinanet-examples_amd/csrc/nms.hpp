@@ -75,6 +75,9 @@ struct NmsArgs {
   uint32_t *first_state;       // [batch, 16]        its size, and where the selection stood after it (run cursors | lower key bound)
   unsigned long long *sup;     // [batch, m_max, m_max / 64]  bit (j % 64) of word j / 64 of row i: candidate i suppresses candidate j (i < j)
   uint32_t m_max;              // multiple of 64, <= kNmsRound
+  uint32_t m_first;            // two-step speculation: the first matrix launch covers candidates < m_first (multiple of 64) ...
+  uint32_t step;               // ... stage 2 runs as step 1 (resolve those; done[img] = did it suffice) and step 2 (the rest); 0: one step
+  uint32_t *done;              // [batch]
 };
 
 // Rotated boxes: the polygon clip is ~1000 wave instructions, and ONE workgroup per image -- one CU out of 256 -- cannot
@@ -95,7 +98,10 @@ struct SupArgs {
   const float *first_cls;
   const uint32_t *first_n;
   unsigned long long *sup;
-  uint32_t m_max;
+  uint32_t m_max;              // row stride of `sup` = m_max / 64 words
+  uint32_t m_launch;           // candidates this launch covers (its grid holds the tiles of m_launch / 64 blocks)
+  uint32_t m_done;             // tiles whose column block lies below m_done were written by an earlier launch
+  const uint32_t *done;        // [batch] or null: images that need no more of the matrix
   float thresh;
   uint32_t flags;
 };
@@ -114,13 +120,15 @@ __global__ __launch_bounds__(kSupThreads) void rotated_sup_matrix_kernel(const S
   __shared__ uint32_t s_words[kRows * 2];
   __shared__ uint16_t s_queue[kRows * 64];
   __shared__ uint32_t s_count;
-  const uint32_t nblk = a.m_max / 64;
+  const uint32_t nblk = a.m_max / 64, nblk_launch = a.m_launch / 64;
   const uint32_t row0 = (blockIdx.x % kSlices) * kRows;      // first row of the slice inside its tile
   uint32_t t = blockIdx.x / kSlices, bi = 0;
-  while (t >= nblk - bi) { t -= nblk - bi; ++bi; }           // upper-triangular tile index -> (row block, column block)
+  while (t >= nblk_launch - bi) { t -= nblk_launch - bi; ++bi; }   // upper-triangular tile index -> (row block, column block)
   const uint32_t bj = bi + t;
   const uint32_t img = blockIdx.y;
-  const uint32_t n = a.first_n[img];
+  if (bj * 64 + 64 <= a.m_done || (a.done && a.done[img])) return;   // written by the first step | image already finished
+  uint32_t n = a.first_n[img];
+  n = n < a.m_launch ? n : a.m_launch;
   if (bj * 64 >= n || bi * 64 + row0 >= n) return;           // (bi <= bj) nothing of this slice exists
   const int tid = static_cast<int>(threadIdx.x);
   const int lane = lane_id();
@@ -288,6 +296,9 @@ __device__ __forceinline__ uint32_t count_above(const uint64_t *A, uint32_t n, u
 template <int NB, bool kGlobalKeys = false, int kStage = 0>
 __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsArgs a) {
   static_assert(kStage == 0 || NB == 6, "the staged form exists for rotated boxes only");
+  if constexpr (kStage == 2) {
+    if (a.step == 2 && a.done[blockIdx.x]) return;           // (block-uniform) step 1 finished this image: leave at once
+  }
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const NmsLds lay(a.count, a.ndet, NB, kGlobalKeys);
   uint64_t *s_keys = kGlobalKeys ? a.key_scratch + static_cast<size_t>(blockIdx.x) * a.count
@@ -777,7 +788,10 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsArgs a) {
       s_cls[tid] = in_c[p];
     }
     // candidates of the first round the suppression matrix covers: all of them, or the first m_max (whole chunks)
-    const uint32_t m_cov = kStage != 0 && first_round ? (n_round <= a.m_max ? n_round : a.m_max) : 0u;
+    // (two-step speculation, step 1: only the first m_first of them have their rows yet)
+    const uint32_t m_all = kStage != 0 && first_round ? (n_round <= a.m_max ? n_round : a.m_max) : 0u;
+    const bool first_step = kStage == 2 && a.step == 1 && m_all > a.m_first;
+    const uint32_t m_cov = first_step ? a.m_first : m_all;
     if constexpr (kStage == 1) {
       if (static_cast<uint32_t>(tid) < m_cov) {
 #pragma unroll
@@ -853,7 +867,7 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsArgs a) {
     }
 
     // ---- chunks of 64 candidates ----
-    for (uint32_t c0 = 0; c0 < n_round && kept < ndet && !pushed; c0 += kNmsChunk) {
+    for (uint32_t c0 = 0; c0 < n_round && kept < ndet && !pushed && !(first_step && c0 >= m_cov); c0 += kNmsChunk) {
       const int kept_before = kept;
       // debug: per-chunk timeline of image 0's first round (3 stamps per chunk: start, after the pair work, after the resolve)
       auto cstamp = [&](int k) {
@@ -970,6 +984,12 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsArgs a) {
       cstamp(2);
       cstamp(3);
     }
+    if constexpr (kStage == 2) {
+      if (first_step && kept < ndet) {                       // the first m_first candidates did not suffice: step 2 redoes the
+        if (tid == 0) a.done[img] = 0;                       // round with the whole matrix (this launch writes no output)
+        return;
+      }
+    }
     first_round = false;
     phase(3);
     last_round_kept = kept - kept_at_round_start;
@@ -1053,6 +1073,9 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsArgs a) {
     a.trace[(gridDim.x + blockIdx.x) * 8 + 7] = static_cast<unsigned long long>(clock64() - shader_clock0);
   }
   // ---- outputs: kept boxes, then the zero-padded tail (box.py:322-324) ----
+  if constexpr (kStage == 2) {
+    if (a.step == 1 && tid == 0) a.done[img] = 1;
+  }
   float *out_scores = reinterpret_cast<float *>(uniform_u64(s_out[0])), *out_boxes = reinterpret_cast<float *>(uniform_u64(s_out[1]));
   float *out_classes = reinterpret_cast<float *>(uniform_u64(s_out[2]));
   int32_t *out_indices = reinterpret_cast<int32_t *>(uniform_u64(s_out[3]));

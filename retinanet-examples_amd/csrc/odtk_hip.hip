@@ -373,17 +373,44 @@ int nms_launch(const odtk::NmsArgs &na, int batch, size_t lds, hipStream_t strea
 
 // rotated boxes: first round in order -> pairwise suppression matrix on the whole chip -> resolve (csrc/nms.hpp)
 template <bool kGlobalKeys>
-int nms_rotated_staged(const odtk::NmsArgs &na, int batch, size_t lds, hipStream_t stream) {
+int nms_rotated_staged(odtk::NmsArgs na, int batch, size_t lds, hipStream_t stream) {
   int rc = nms_launch<6, kGlobalKeys, 1>(na, batch, lds, stream);
   if (rc != ODTK_OK) return rc;
   odtk::SupArgs sa;
   sa.first_box = na.first_box; sa.first_cls = na.first_cls; sa.first_n = na.first_n; sa.sup = na.sup;
   sa.m_max = na.m_max; sa.thresh = na.thresh; sa.flags = na.flags;
-  const unsigned nblk = na.m_max / 64;
-  timed_launch(ODTK_KERNEL_NMS_MATRIX, odtk::rotated_sup_matrix_kernel, dim3(nblk * (nblk + 1) / 2 * 4, batch), dim3(odtk::kSupThreads), 0,
-               stream, sa);
+  auto matrix = [&](uint32_t m_launch, uint32_t m_done, const uint32_t *done) {
+    sa.m_launch = m_launch; sa.m_done = m_done; sa.done = done;
+    const unsigned nblk = m_launch / 64;
+    timed_launch(ODTK_KERNEL_NMS_MATRIX, odtk::rotated_sup_matrix_kernel, dim3(nblk * (nblk + 1) / 2 * 4, batch),
+                 dim3(odtk::kSupThreads), 0, stream, sa);
+  };
+  if (na.m_first >= na.m_max) {                              // the matrix is small: one step
+    na.step = 0;
+    matrix(na.m_max, 0, nullptr);
+    ODTK_HIP_TRY(hipGetLastError());
+    return nms_launch<6, kGlobalKeys, 2>(na, batch, lds, stream);
+  }
+  // two-step speculation: the pairs of the first m_first candidates, a resolve that stops there; only the images it did not
+  // finish pay for the rest of the matrix and a second resolve (the other workgroups of those two launches leave at once)
+  matrix(na.m_first, 0, nullptr);
   ODTK_HIP_TRY(hipGetLastError());
+  na.step = 1;
+  rc = nms_launch<6, kGlobalKeys, 2>(na, batch, lds, stream);
+  if (rc != ODTK_OK) return rc;
+  matrix(na.m_max, na.m_first, na.done);
+  ODTK_HIP_TRY(hipGetLastError());
+  na.step = 2;
   return nms_launch<6, kGlobalKeys, 2>(na, batch, lds, stream);
+}
+
+// ... and what the first of two matrix launches covers: 2.5 x detections_per_im (a detector whose boxes are well separated
+// examines 1.5 .. 2.5 x as many candidates as it keeps), at least four chunks
+uint32_t rotated_matrix_first(uint32_t m_max, int ndet) {
+  size_t m = static_cast<size_t>(ndet) * 5 / 2;
+  if (m < 256) m = 256;
+  m = (m + 63) / 64 * 64;
+  return m > m_max ? m_max : static_cast<uint32_t>(m);
 }
 
 // candidates of the first round the rotated suppression matrix covers: 8 x detections_per_im (the lazy pull of a typical
@@ -417,7 +444,8 @@ int nms_impl(int batch, const void *const *inputs, void *const *outputs, int n_o
   const size_t off_fk = off_fn + (nb == 6 ? align_up(sizeof(uint32_t) * batch) : 0);
   const size_t off_fs = off_fk + (nb == 6 ? align_up(sizeof(uint64_t) * batch * odtk::kNmsRound) : 0);
   const size_t off_sup = off_fs + (nb == 6 ? align_up(sizeof(uint32_t) * 16 * batch) : 0);
-  const size_t need = off_sup + (nb == 6 ? align_up(sizeof(uint64_t) * batch * m_max * (m_max / 64)) : 0);
+  const size_t off_done = off_sup + (nb == 6 ? align_up(sizeof(uint64_t) * batch * m_max * (m_max / 64)) : 0);
+  const size_t need = off_done + (nb == 6 ? align_up(sizeof(uint32_t) * batch) : 0);
   if (need > 0x7fffffffull) return ODTK_ERR_INVALID;
   if (!workspace || !workspace_size) return static_cast<int>(need);
   if (workspace_size < need) return ODTK_ERR_WORKSPACE;
@@ -452,6 +480,8 @@ int nms_impl(int batch, const void *const *inputs, void *const *outputs, int n_o
     na.first_state = reinterpret_cast<uint32_t *>(ws + off_fs);
     na.sup = reinterpret_cast<unsigned long long *>(ws + off_sup);
     na.m_max = m_max;
+    na.m_first = rotated_matrix_first(m_max, ndet);
+    na.done = reinterpret_cast<uint32_t *>(ws + off_done);
     return global_keys ? nms_rotated_staged<true>(na, batch, lds, stream) : nms_rotated_staged<false>(na, batch, lds, stream);
   }
   return global_keys ? nms_launch<4, true>(na, batch, lds, stream) : nms_launch<4, false>(na, batch, lds, stream);

@@ -344,7 +344,8 @@ def decode_levels(cls_heads, box_heads, anchors_list, strides, score_thresh, top
 
 def detect(cls_heads, box_heads, anchors_list, strides, score_thresh, top_n, nms_thresh, detections_per_im,
            rotated=False, logits=False, cls_bias=None, box_bias=None):
-    """decode_levels + nms back to back (the whole of odtk/model.py:140-165), 3 kernel launches."""
+    """decode_levels + nms back to back (the whole of odtk/model.py:140-165): six launches (rotated boxes: eight to ten),
+    no host synchronisation, one workspace."""
     lib = library()
     nb = 6 if rotated else 4
     arr, keep, batch, num_anchors, num_classes, dtype = _levels(cls_heads, box_heads, anchors_list, strides, nb,

@@ -375,7 +375,7 @@ def decode_levels(cls_heads, box_heads, strides, threshold, top_n, anchors_per_s
 def detect(cls_heads, box_heads, strides, anchors_per_stride, threshold=0.05, top_n=1000, nms=0.5,
            ndetections=100, rotated=False, logits=False, cls_bias=None, box_bias=None):
     """sigmoid (logits=True) + decode of all levels + nms: the whole inference post-processing of the
-    reference (model.py:140-165) in three kernel launches, reading the head tensors in place.
+    reference (model.py:140-165) in one enqueue of six launches (rotated: eight to ten), reading the head tensors in place.
     cls_bias / box_bias: the heads' last-conv biases, added inside the kernels (see _C.decode_levels)."""
     anchors = [anchors_per_stride[s][0] if rotated else anchors_per_stride[s] for s in strides]
     for t in cls_heads:

@@ -8,7 +8,7 @@ training scripts and checkpoints carry over.  What runs where:
   eval forward on a GPU (the default)               the BN-folded inference engine (odtk/fused.py: folded
                                                     weights, HIP bias/skip/ReLU epilogues, 1x1 convs as
                                                     fused GEMMs) + `odtk.box.detect`: sigmoid + decode of all
-                                                    five levels + batched NMS, hand-written HIP, 3 launches,
+                                                    five levels + batched NMS, hand-written HIP, six launches,
                                                     no host sync, head tensors read in place.  Built lazily
                                                     from the current weights, rebuilt when they change.
   `fused_graph = False`                             the eager nn.Module graph (what training uses) + the same
