@@ -185,8 +185,8 @@ struct NmsFixedLds {
   static constexpr size_t cls = box + static_cast<size_t>(kNmsRound) * NB * 4;   // ... and classes
   static constexpr size_t hist = cls + kNmsRound * 4;                          // range_threshold's histogram | sorted-run windows | pair queue
   static constexpr size_t misc = hist + kRadixBins * 4;
-  static constexpr size_t sup = misc + kNmsMisc * 4;                           // suppression words of the current chunk
-  static constexpr size_t end = sup + kNmsChunk * 8;
+  static constexpr size_t sup = misc + kNmsMisc * 4;                           // suppression words of the current chunk and the next
+  static constexpr size_t end = sup + 2 * kNmsChunk * 8;
   static_assert(end % 16 == 0, "16-byte aligned regions");
 };
 
@@ -866,6 +866,34 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsArgs a) {
       }
     }
 
+    // axis-aligned: suppression rows of the chunk at rank c_at into `rows` (row i = the lanes j > i of the same class that
+    // candidate i WOULD suppress if it is kept), by waves w0, w0 + 1, ... (n_w of them; lane <-> candidate j)
+    auto chunk_rows = [&](uint32_t c_at, uint64_t *rows, int w0, int n_w) {
+      if constexpr (NB == 4) {
+        const uint32_t rj = c_at + lane;
+        const uint32_t n_c = n_round - c_at < kNmsChunk ? n_round - c_at : kNmsChunk;
+        float jb[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) jb[k] = s_box[rj * 4 + k];
+        const float jc = s_cls[rj];
+        for (uint32_t i = static_cast<uint32_t>(wave - w0); i < n_c; i += static_cast<uint32_t>(n_w)) {
+          const float ic = s_cls[c_at + i];                    // same address in every lane: LDS broadcast
+          const bool rival = static_cast<uint32_t>(lane) > i && rj < n_round && jc == ic;
+          uint64_t row = 0;
+          if (__ballot(rival)) {                               // wave-uniform: most rows have no same-class follower
+            float ib[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) ib[k] = s_box[(c_at + i) * 4 + k];
+            row = __ballot(rival && axis_suppresses(ib, jb, thr));
+          }
+          if (lane == 0) rows[i] = row;
+        }
+      }
+    };
+    if constexpr (NB == 4) {
+      if (!pushed && kept < ndet) chunk_rows(0, s_sup, 0, 16);   // rows of the first chunk: all waves (the pull's barrier publishes them)
+    }
+
     // ---- chunks of 64 candidates ----
     for (uint32_t c0 = 0; c0 < n_round && kept < ndet && !pushed && !(first_step && c0 >= m_cov); c0 += kNmsChunk) {
       const int kept_before = kept;
@@ -882,29 +910,16 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsArgs a) {
 #pragma unroll
         for (int k = 0; k < NB; ++k) jb[k] = s_box[r * NB + k];
         const float jc = s_cls[r];
-        // (1) EVERY wave looks at the same 64 candidates (lane <-> candidate).
-        //   pull: against its own slice of the kept list (ranks pulled + wave, + 16, ...): a candidate's tests are spread over
-        //         16 threads.  Wave w publishes its verdict word; the AND is the set still alive.
-        //   suppression rows: row i of the chunk = the lanes j > i of the same class that candidate i WOULD suppress if it is
-        //         kept.  Wave w computes rows w, w + 16, ...: all of the chunk's pairwise IoUs happen here, in parallel on
-        //         every wave, and not on the serial chain of (2) -- measured before: 0.28 us per kept box in (2), 28 of the
-        //         kernel's 50 us (one wave, ~10 dependent branches per box).
+        // (1) EVERY wave looks at the same 64 candidates (lane <-> candidate) and pulls against its own slice of the kept list
+        //     (ranks pulled + wave, + 16, ...): a candidate's tests are spread over 16 threads.  Wave w publishes its verdict
+        //     word; the AND is the set still alive.  The chunk's pairwise suppression ROWS are already there: they do not
+        //     depend on what was kept, so they were computed while the previous chunk was being resolved (below) -- all of
+        //     the chunk's IoUs off the serial chain of (2) (measured before the rows existed: 0.28 us per kept box in (2), 28
+        //     of the kernel's 50 us), and since round 3 off the critical path altogether.
         bool alive = r < n_round;
         if (alive) alive = pull_against_kept(s_kcls, s_kbox, pulled + wave, kept_before, 16, jb, jc, true, thr);
         const uint64_t word = __ballot(alive);
         if (lane == 0) s_alive[wave] = word;
-        for (uint32_t i = wave; i < n_chunk; i += 16) {
-          const float ic = s_cls[c0 + i];                      // same address in every lane: LDS broadcast
-          const bool rival = static_cast<uint32_t>(lane) > i && r < n_round && jc == ic;
-          uint64_t row = 0;
-          if (__ballot(rival)) {                               // wave-uniform: most rows have no same-class follower
-            float ib[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) ib[k] = s_box[(c0 + i) * 4 + k];
-            row = __ballot(rival && axis_suppresses(ib, jb, thr));
-          }
-          if (lane == 0) s_sup[i] = row;
-        }
         __syncthreads();
       } else if (kStage == 2 && c0 < m_cov) {
         // rotated, first round, inside the matrix: the dead bits already hold the rows of every box kept so far; the chunk's
@@ -934,7 +949,8 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsArgs a) {
           const uint64_t dead = static_cast<uint64_t>(s_dead[c0 >> 5]) | (static_cast<uint64_t>(s_dead[(c0 >> 5) + 1]) << 32);
           word = ~dead;
         }
-        const uint64_t my_row = static_cast<uint32_t>(lane) < n_chunk ? s_sup[lane] : 0;
+        const uint64_t *rows = NB == 4 ? s_sup + ((c0 >> 6) & 1u) * kNmsChunk : s_sup;   // (axis-aligned: two buffers, in turn)
+        const uint64_t my_row = static_cast<uint32_t>(lane) < n_chunk ? rows[lane] : 0;
         const uint32_t row_lo = static_cast<uint32_t>(my_row), row_hi = static_cast<uint32_t>(my_row >> 32);
         // (LDS values are VGPRs, "divergent" to the compiler: pin the loop state to SGPRs so the loop is scalar control flow)
         uint64_t mask = (static_cast<uint64_t>(__builtin_amdgcn_readfirstlane(static_cast<uint32_t>(word >> 32))) << 32) |
@@ -963,6 +979,10 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsArgs a) {
           s_misc[38] = static_cast<uint32_t>(kept_mask);
           s_misc[39] = static_cast<uint32_t>(kept_mask >> 32);
         }
+      } else if (NB == 4 && c0 + kNmsChunk < n_round) {
+        // ... while the other 15 waves compute the NEXT chunk's rows into the other buffer (wasted only when this chunk
+        // turns out to be the last one)
+        chunk_rows(c0 + kNmsChunk, s_sup + (((c0 >> 6) + 1u) & 1u) * kNmsChunk, 1, 15);
       }
       __syncthreads();
       kept = __builtin_amdgcn_readfirstlane(static_cast<int>(s_misc[34]));

@@ -162,7 +162,7 @@ def _workspace(device, nbytes):
     scratch that an eager call -- or another graph -- may grow, replace or overwrite, and the cache never holds
     memory of a graph that no longer exists."""
     stream = torch.cuda.current_stream(device)
-    if torch.cuda.is_current_stream_capturing() and not os.environ.get('ODTK_WS_CACHE_IN_CAPTURE'):
+    if torch.cuda.is_current_stream_capturing():
         return torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device), stream.cuda_stream
     key = (device.index, stream.cuda_stream)
     ws = _workspaces.get(key)

@@ -147,6 +147,7 @@ class FusedRetinaNet(nn.Module):
         self._streams = None
         self.tower_plan = 0
         self._graphs = {}                                               # input geometry -> (hipGraph, static input, outputs)
+        self.max_graphs = 8
 
     def features(self, x):
         x = self.stem.conv_then_pool(x)                                  # conv1 -> (bias + ReLU + maxpool, one pass)
@@ -255,6 +256,8 @@ class FusedRetinaNet(nn.Module):
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 out = self.forward(static_x)
+            while len(self._graphs) >= self.max_graphs:                 # a graph pins its activations: keep a handful of geometries
+                self._graphs.pop(next(iter(self._graphs)))              # (oldest first: dicts keep insertion order)
             entry = self._graphs[key] = (graph, static_x, out)
         graph, static_x, out = entry
         static_x.copy_(x)

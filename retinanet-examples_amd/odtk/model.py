@@ -217,6 +217,8 @@ class Model(nn.Module):
         once per input geometry into ONE hipGraph and replayed (batch 1: launch-bound eager); the graph
         belongs to the engine and goes with it when the weights change."""
         if self.training:
+            if graph:
+                raise RuntimeError('Model.forward(graph=True) is an inference option (eval mode)')
             images, targets = x
             cls_heads, box_heads = self.heads(images)
             return self._compute_loss(images, cls_heads, box_heads, targets.float())

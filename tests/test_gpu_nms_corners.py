@@ -214,3 +214,35 @@ def test_heavy_suppression_through_detect(rotated):
     n_cand = int((cat[0][0] > 0).sum())
     kept = int((out[0][0] > 0).sum())
     assert n_cand > 1500 and 3 <= kept < n_cand // 10, (n_cand, kept)   # (the oracle comparison above is what matters)
+
+
+@pytest.mark.parametrize('rotated', [False, True], ids=['axis', 'rotated'])
+def test_detect_with_a_non_positive_threshold(rotated):
+    """score_thresh <= 0: decode emits zero and negative scores too (`score >= thresh`), nms takes `score > 0` only.  In
+    `detect` the positive entries of every level's list are a PREFIX whose length select_decode hands over (`run_valid`,
+    not the list length): the runs the NMS reads must end there."""
+    strides = [8, 16, 32]
+    A, nb = (27, 6) if rotated else (9, 4)
+    g = torch.Generator().manual_seed(5 + rotated)
+    cls, dl = [], []
+    for s in strides:
+        h, w = 64 // s, 96 // s
+        c = torch.randn(2, A * 3, h, w, generator=g) * 0.4                 # signed "scores": about half are <= 0
+        c[:, :, ::2, ::2] = 0.0                                             # exact zeros as well
+        cls.append(c)
+        d = torch.randn(2, A * nb, h, w, generator=g) * 0.3
+        dl.append(d)
+    sizes = [c[0].numel() for c in cls]
+    joint = synthetic.make_unique_scores(torch.cat([c.reshape(2, -1) for c in cls], 1), 1e-6)   # positive scores distinct
+    cls = [j.reshape(c.shape) for j, c in zip(joint.split(sizes, 1), cls)]
+    anchors = {s: (box.generate_anchors_rotated(s, RATIOS, SCALES, ANGLES) if rotated else box.generate_anchors(s, RATIOS, SCALES))
+               for s in strides}
+    for thr, top_n in ((-0.25, 400), (0.0, 300), (-10.0, 150)):
+        out = box.detect([c.cuda() for c in cls], [d.cuda() for d in dl], strides, anchors, thr, top_n, 0.5, 120, rotated)
+        cat, ref = _oracle_detect(cls, dl, strides, anchors, thr, top_n, 0.5, 120, rotated)
+        positives = (cat[0] > 0).sum(1)
+        assert (cat[0] <= 0).any() and positives.min() > 50            # lists really carry non-positive entries behind the positive ones
+        same_bits(out, ref, 'detect, thresh %g' % thr)
+        two = _C.nms(*[torch.from_numpy(t).cuda() for t in cat[:3]], 0.5, 120, rotated)
+        for a, b in zip(out, two):
+            assert torch.equal(a, b)
