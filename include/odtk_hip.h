@@ -336,6 +336,12 @@ int odtk_profile_enable(int on);
 /* Debug: device buffer (>= 16 KiB) that select_decode / nms workgroups stamp with wall_clock64()
  * (100 MHz) at their phase boundaries; NULL (default) disables.  Not for production use. */
 int odtk_debug_set_trace(void *device_buffer);
+/* Debug / tuning: launch shape of the loss kernels for one direction (backward = 0 / 1) and head width (fp32_heads =
+ * 0: bf16 / fp16, 1: fp32): workgroup size (multiple of 64, <= 1024), resident workgroups per CU the logit walk is
+ * capped at (1..64), 16-byte vectors per lane per trip (1, 2 or 4), workgroups of the box-delta walk
+ * (1..16384); both workgroup caps are per pyramid level.  The defaults are the measured best; results do not depend on the shape beyond the
+ * order of the partial sums.  Process-wide, not thread-safe against concurrent loss launches. */
+int odtk_debug_loss_tuning(int backward, int fp32_heads, int threads, int blocks_per_cu, int unroll, int box_blocks);
 int odtk_profile_collect(double total_ms[ODTK_KERNEL_COUNT], int launches[ODTK_KERNEL_COUNT]);
 
 #ifdef __cplusplus

@@ -18,17 +18,26 @@
 //
 // Roofline: HBM-bound.  Algorithmic bytes per level: forward sizeof(T) per logit; backward 2 x sizeof(T) per
 // logit (read + gradient write); depth / box terms are < 2 % of that.
-// Arithmetic per element follows loss.py operation by operation in fp32 (the sums are accumulated in fp32 per
-// lane over <= 64 elements, then in fp64): forward values agree with the torch expression to ~1e-7 relative.
+// Measured (round 3, tools/loss_probe.py, 2 images of 800x1280, cold inputs): fp32 forward 33 us (3.7 TB/s),
+// backward 52 us (4.8 TB/s); in the training step 88.7 us for both = 0.52 of 8 TB/s (round 2: 124.7 us, 0.37).
+// What the forward still pays for is its reduction: every workgroup ends in a double atomic on its level's word, so
+// the launch runs with few, large workgroups (launch shapes: odtk_debug_loss_tuning, defaults in odtk_hip.hip).
+// Arithmetic per element: loss.py's expressions in fp32, in the symmetric form derived at focal_term below (the sums
+// are accumulated in fp32 per lane over <= 32 elements, then in fp64): forward values agree with the torch expression
+// evaluated in float64 to 1e-6 relative, gradients to 1e-5 of the largest gradient (tests/test_gpu_loss.py).
+// Index arithmetic: offset -> (image, anchor, class, pixel) by multiply-high (fastdiv.hpp), three per 16-byte vector.
 #pragma once
 
+#include <type_traits>
+
 #include "common.hpp"
+#include "fastdiv.hpp"
 #include "prefilter.hpp"   // element types F32 / BF16 / F16, vuint4, load_raw, round_to_*
 #include "../../include/odtk_hip.h"
 
 namespace odtk {
 
-constexpr int kLossThreads = 256;
+constexpr int kLossMaxThreads = 1024;         // the kernels take any workgroup size that is a multiple of 64 up to this
 
 struct LossArgs {
   const void *cls;          // [B, A*C, H, W] logits, element type T
@@ -44,32 +53,40 @@ struct LossArgs {
   uint32_t channels_last;   // layout of cls and box (0: NCHW, 1: NHWC)
   uint32_t cls_blocks;      // blocks [0, cls_blocks) walk the logits, the rest walk the deltas
   float alpha, gamma, beta;
+  FastDiv by_channels, by_hw, by_classes, by_anchors;   // A*C, H*W, C, A (host: fastdiv_make)
 };
 
-// loss.py:13-19 for one element; t is 0 or 1.  Returns the loss, *grad = d(loss)/dx.
-// The kernel was ALU-bound on ocml's expf / log1pf / IEEE division (~320 instructions per logit: 990 GB/s); this form
-// needs one hardware exp2, one log2 and one reciprocal per logit (each accurate to ~1 ulp, i.e. ~1e-7 relative on the
-// terms that carry the sums -- the parity bars are 1e-6 on the sums and 1e-5 on the gradients, tests/test_gpu_loss.py):
-//   e = exp(-|x|) in (0, 1];  sigmoid(x) = 1 / (1 + e) for x >= 0, e / (1 + e) for x < 0;  log1p(e) = log(1 + e), 1 + e in (1, 2]
-template <bool kGrad>
-__device__ __forceinline__ float focal_element(float x, bool positive, float alpha, float gamma, float *grad) {
-  const float t = positive ? 1.0f : 0.0f;
-  const float e = __expf(-fabsf(x));
-  const float r = __builtin_amdgcn_rcpf(1.0f + e);
-  const float p = x >= 0.0f ? r : e * r;                                        // pred_logits.sigmoid()
-  // F.binary_cross_entropy_with_logits: (1 - t) * x + max(-x, 0) + log1p(exp(-|x|))
-  const float ce = (1.0f - t) * x + fmaxf(-x, 0.0f) + __logf(1.0f + e);
-  const float a_t = t * alpha + (1.0f - t) * (1.0f - alpha);
-  const float pt = positive ? p : 1.0f - p;
-  const float q = 1.0f - pt;                                                    // (1. - pt)
-  const float mod = gamma == 2.0f ? q * q : powf(q, gamma);
-  if constexpr (kGrad) {
-    // d q / d x = -p (1 - p) for t = 1, +p (1 - p) for t = 0;  d ce / d x = p - t
-    const float dq = positive ? -(p * (1.0f - p)) : p * (1.0f - p);
-    const float dmod = gamma == 2.0f ? 2.0f * q : (q > 0.0f ? gamma * powf(q, gamma - 1.0f) : 0.0f);
-    *grad = a_t * (dmod * dq * ce + mod * (p - t));
+// loss.py:13-19 for one element with target t in {0, 1}.  kBackward = false: the loss times `w`; true: d(loss)/dx times `w`
+// (the caller folds alpha_t -- and, backward, the upstream gradient and the sign below -- into w_neg / w_pos).
+//
+// Round 3.  The loss is symmetric under (x, t) -> (-x, 1 - t): with s = x for t = 0 and s = -x for t = 1,
+//     q  = sigmoid(s)            = 1 - pt                       (loss.py:16-17)
+//     ce = softplus(s)           = BCE-with-logits(x, t)        (loss.py:15: (1-t) x + max(-x, 0) + log1p(exp(-|x|)))
+//     loss = alpha_t q^gamma ce,  d loss / d s = alpha_t q^gamma (gamma (1 - q) ce + q),  d s / d x = +1 (t = 0), -1 (t = 1)
+// so one form serves both targets, `1 - q` comes out of the same reciprocal without a cancelling subtraction (more
+// accurate than the reference's fp32 `1 - pt` where pt -> 1), and an element costs one hardware exp2, one rcp, one log2
+// (each ~1 ulp; the parity bars are 1e-6 on the sums and 1e-5 on the gradients, tests/test_gpu_loss.py) plus ~15
+// full-rate VALU operations: ~27 issue slots forward, ~31 backward.  (History: ocml expf / log1pf / IEEE division, ~320
+// instructions per logit, 990 GB/s -> hardware transcendentals in the reference's own operation order, 2.9 TB/s.)
+template <bool kBackward, bool kGamma2>
+__device__ __forceinline__ float focal_term(float x, bool positive, float w_neg, float w_pos, float gamma) {
+  const float s = positive ? -x : x;
+  const float e = __builtin_amdgcn_exp2f(fabsf(s) * -1.4426950408889634f);      // exp(-|s|) in (0, 1]
+  const float d = 1.0f + e;
+  const float r = __builtin_amdgcn_rcpf(d);
+  const float er = e * r;
+  const bool nonneg = s >= 0.0f;
+  const float q = nonneg ? r : er;                                               // sigmoid(s)
+  const float ce = fmaf(__builtin_amdgcn_logf(d), 0.6931471805599453f, fmaxf(s, 0.0f));   // softplus(s); 1 + e in (1, 2]
+  const float w = positive ? w_pos : w_neg;
+  // q^gamma: q in [0, 1]; the general form is exp2(gamma log2 q) on the hardware units (log2 0 = -inf -> 0)
+  const float mod = kGamma2 ? q * q : __builtin_amdgcn_exp2f(gamma * __builtin_amdgcn_logf(q));
+  if constexpr (!kBackward) {
+    return w * mod * ce;
+  } else {
+    const float omq = nonneg ? er : r;                                           // 1 - sigmoid(s), no cancellation
+    return w * mod * fmaf((kGamma2 ? 2.0f : gamma) * omq, ce, q);
   }
-  return a_t * mod * ce;
 }
 
 // loss.py:27-31
@@ -92,6 +109,40 @@ __device__ __forceinline__ void store_elem(void *base, uint64_t idx, float v) {
   }
 }
 
+template <typename T>
+__device__ __forceinline__ float vec_elem(const vuint4 &raw, int e) {
+  if constexpr (std::is_same_v<T, F32>) {
+    return __uint_as_float(raw[e]);
+  } else {
+    const uint32_t w = raw[e >> 1];
+    if constexpr (std::is_same_v<T, BF16>) return __uint_as_float((e & 1) ? (w & 0xffff0000u) : (w << 16));
+    else return f16_bits_to_float((e & 1) ? (w >> 16) : (w & 0xffffu));
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ vuint4 pack_vec(const float *out) {
+  vuint4 w;
+  if constexpr (std::is_same_v<T, F32>) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) w[e] = __float_as_uint(out[e]);
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      uint32_t lo, hi;
+      if constexpr (std::is_same_v<T, BF16>) {
+        lo = __float_as_uint(round_to_bf16(out[2 * e])) >> 16;
+        hi = __float_as_uint(round_to_bf16(out[2 * e + 1])) >> 16;
+      } else {
+        lo = __builtin_bit_cast(uint16_t, static_cast<_Float16>(out[2 * e]));
+        hi = __builtin_bit_cast(uint16_t, static_cast<_Float16>(out[2 * e + 1]));
+      }
+      w[e] = lo | (hi << 16);
+    }
+  }
+  return w;
+}
+
 __device__ __forceinline__ double block_sum(double v, double *s_red) {
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, kWave);
@@ -101,161 +152,176 @@ __device__ __forceinline__ double block_sum(double v, double *s_red) {
   __syncthreads();
   double r = 0.0;
   if (threadIdx.x == 0)
-    for (int i = 0; i < kLossThreads / kWave; ++i) r += s_red[i];
+    for (uint32_t i = 0; i < (blockDim.x >> 6); ++i) r += s_red[i];
   return r;                                                                    // valid on thread 0
 }
 
-// One workgroup's share of one level: workgroup `block` of the `n_blocks` that level's launch (or its slice of a
-// multi-level launch) consists of.  kBackward = false: accumulate the three sums.  kBackward = true: write the gradients.
-template <typename T, bool kBackward>
-__device__ __forceinline__ void retina_loss_block(const LossArgs &a, uint32_t block, uint32_t n_blocks, double *s_red) {
+// The logits of one level, in memory order, 16 bytes per lane per vector, kUnroll vectors per trip: all of a trip's
+// loads (logits AND the depth words they need) are issued before any arithmetic -- the kernel is a stream with ~30 issue
+// slots of work per element, and at one 16-byte load per wave in flight (round 2) it was latency-bound at 0.37 of HBM.
+//   kCL (channels_last), vector inside one anchor's class run (C % kPer == 0: always): ONE depth value per vector
+//   NCHW, vector inside one (image, anchor, class) plane row (hw % kPer == 0: P3..P6): kPer consecutive depth values
+//   otherwise (tiny levels, class counts that are no multiple of the vector): element by element with carries
+template <typename T, bool kBackward, bool kGamma2, bool kCL, int kUnroll>
+__device__ __forceinline__ double focal_stream(const LossArgs &a, uint32_t block) {
   constexpr int kPer = T::kPerLoad;
-  const uint32_t A = a.num_anchors, C = a.num_classes, hw = a.hw, NB = a.nb;
+  constexpr int kDep = kCL ? 1 : kPer;                     // depth words per fast vector
+  const uint32_t A = a.num_anchors, C = a.num_classes, hw = a.hw;
   const uint32_t channels = A * C;
-  float sum_cls = 0.0f, sum_box = 0.0f, n_fg = 0.0f;
-  double acc_cls = 0.0, acc_box = 0.0, acc_fg = 0.0;
+  const float g = kBackward ? (a.g_cls ? *a.g_cls : 0.0f) : 1.0f;
+  const float w_neg = (1.0f - a.alpha) * g, w_pos = kBackward ? -(a.alpha * g) : a.alpha;   // loss.py:18 alpha_t (x ds/dx)
+  const float gamma = a.gamma;
+  // (the host guarantees batch * channels * hw < 2^32: index arithmetic stays in 32 bits)
+  const uint32_t n = a.batch * channels * hw;
+  const uint32_t n_vec = n / kPer;
+  const vuint4 *src = static_cast<const vuint4 *>(a.cls);
+  const uint32_t stride = a.cls_blocks * blockDim.x;
+  double acc = 0.0;
 
-  if (block < a.cls_blocks) {
-    // ---- the logits, in memory order, 16 bytes per lane per trip ----
-    const float g = kBackward ? (a.g_cls ? *a.g_cls : 0.0f) : 0.0f;
-    // (the host guarantees batch * channels * hw < 2^32: index arithmetic stays in 32 bits -- a 64-bit division
-    // costs more than the loss of the whole vector)
-    const uint32_t n = a.batch * channels * hw;
-    const uint32_t n_vec = n / kPer;
-    const vuint4 *src = static_cast<const vuint4 *>(a.cls);
-    const uint32_t stride = a.cls_blocks * kLossThreads;
-    int trips = 0;
-    for (uint32_t v = block * kLossThreads + threadIdx.x; v < n_vec; v += stride) {
-      const vuint4 raw = __builtin_nontemporal_load(src + v);
-      const uint32_t r0 = v * kPer;
-      // decompose the first element once; the others follow by increment with carry
-      uint32_t img, an, c, pix;
-      if (a.channels_last) {
-        const uint32_t p = r0 / channels;
-        const uint32_t ch = r0 - p * channels;
-        img = p / hw;
-        pix = p - img * hw;
-        an = ch / C;
-        c = ch - an * C;
+  for (uint32_t v0 = block * blockDim.x + threadIdx.x; v0 < n_vec; v0 += stride * kUnroll) {
+    vuint4 raw[kUnroll];
+    float dep[kUnroll][kDep];
+    uint32_t c0[kUnroll];                                  // class of the vector's first element
+    bool fast[kUnroll];
+#pragma unroll
+    for (int u = 0; u < kUnroll; ++u) {
+      const uint32_t v = v0 + u * stride;
+      fast[u] = false;
+      c0[u] = 0;
+#pragma unroll
+      for (int e = 0; e < kDep; ++e) dep[u][e] = -1.0f;
+      if (v < n_vec) {
+        raw[u] = __builtin_nontemporal_load(src + v);
+        const uint32_t r0 = v * kPer;
+        if constexpr (kCL) {
+          uint32_t ch, pix, c;
+          const uint32_t p = fastdivmod(r0, a.by_channels, &ch);
+          const uint32_t img = fastdivmod(p, a.by_hw, &pix);
+          const uint32_t an = fastdivmod(ch, a.by_classes, &c);
+          c0[u] = c;
+          fast[u] = c + kPer <= C;
+          if (fast[u]) dep[u][0] = a.depth[(img * A + an) * hw + pix];
+        } else {
+          uint32_t pix, c;
+          const uint32_t q = fastdivmod(r0, a.by_hw, &pix);           // (img * A + an) * C + c
+          const uint32_t ia = fastdivmod(q, a.by_classes, &c);
+          c0[u] = c;
+          fast[u] = pix + kPer <= hw;
+          if (fast[u]) {
+#pragma unroll
+            for (int e = 0; e < kDep; ++e) dep[u][e] = a.depth[ia * hw + pix + e];
+          }
+        }
       } else {
-        const uint32_t q = r0 / hw;                          // (img * A + an) * C + c
-        pix = r0 - q * hw;
-        const uint32_t ia = q / C;
-        c = q - ia * C;
-        img = ia / A;
-        an = ia - img * A;
+        raw[u] = vuint4{0u, 0u, 0u, 0u};
       }
-      // depth of every element of the vector, fetched BEFORE the arithmetic (independent loads, one wait) -- an element's
-      // depth read inside the loop put an L2 round trip on every element's critical path.
-      //   channels_last, vector inside one anchor's class run (C % kPer == 0: always): ONE depth value
-      //   NCHW, vector inside one (image, anchor, class) plane row (hw % kPer == 0: P3..P6): kPer consecutive values
-      //   otherwise (tiny levels): element by element with carries
-      float dep[kPer];
-      uint32_t cls_of[kPer];
-      const uint32_t cell = (img * A + an) * hw + pix;
-      if (a.channels_last && c + kPer <= C) {
-        const float d = a.depth[cell];
+    }
+    float sum = 0.0f;                                      // fp32 partial of <= kUnroll * kPer <= 32 elements -> fp64
 #pragma unroll
-        for (int e = 0; e < kPer; ++e) { dep[e] = d; cls_of[e] = c + e; }
-      } else if (!a.channels_last && pix + kPer <= hw) {
-#pragma unroll
-        for (int e = 0; e < kPer; ++e) { dep[e] = a.depth[cell + e]; cls_of[e] = c; }
-      } else {
-        uint32_t i2 = img, a2 = an, c2 = c, p2 = pix;
+    for (int u = 0; u < kUnroll; ++u) {
+      const uint32_t v = v0 + u * stride;
+      if (v >= n_vec) break;
+      float out[kPer];
+      if (fast[u]) {
+        // evaluated for every element (no branch around the arithmetic: lanes diverge on `depth`), masked afterwards.
+        // depth is integral by contract (-1 / 0 / class + 1): "depth > 0 and class == depth - 1" is ONE compare
+        const float tgt0 = static_cast<float>(c0[u] + 1);
+        float vs = 0.0f;
 #pragma unroll
         for (int e = 0; e < kPer; ++e) {
-          dep[e] = a.depth[(static_cast<uint64_t>(i2) * A + a2) * hw + p2];
-          cls_of[e] = c2;
-          if (a.channels_last) { if (++c2 == C) { c2 = 0; if (++a2 == A) { a2 = 0; if (++p2 == hw) { p2 = 0; ++i2; } } } }
+          const float d = dep[u][kCL ? 0 : e];
+          const bool positive = d == (kCL ? tgt0 + static_cast<float>(e) : tgt0);
+          const float t = focal_term<kBackward, kGamma2>(vec_elem<T>(raw[u], e), positive, w_neg, w_pos, gamma);
+          if constexpr (kBackward) out[e] = d >= 0.0f ? t : 0.0f;                // model.py:199 cls_mask
+          else if constexpr (kCL) vs += t;
+          else vs += d >= 0.0f ? t : 0.0f;
+        }
+        if constexpr (!kBackward) sum += kCL ? (dep[u][0] >= 0.0f ? vs : 0.0f) : vs;
+      } else {
+        // decompose the first element again; the others follow by increment with carry
+        const uint32_t r0 = v * kPer;
+        uint32_t i2, a2, c2, p2;
+        if constexpr (kCL) {
+          uint32_t ch;
+          const uint32_t p = fastdivmod(r0, a.by_channels, &ch);
+          i2 = fastdivmod(p, a.by_hw, &p2);
+          a2 = fastdivmod(ch, a.by_classes, &c2);
+        } else {
+          const uint32_t q = fastdivmod(r0, a.by_hw, &p2);
+          const uint32_t ia = fastdivmod(q, a.by_classes, &c2);
+          i2 = fastdivmod(ia, a.by_anchors, &a2);
+        }
+#pragma unroll
+        for (int e = 0; e < kPer; ++e) {
+          const float d = a.depth[(i2 * A + a2) * hw + p2];
+          const bool positive = d == static_cast<float>(c2 + 1);
+          const float t = focal_term<kBackward, kGamma2>(vec_elem<T>(raw[u], e), positive, w_neg, w_pos, gamma);
+          if constexpr (kBackward) out[e] = d >= 0.0f ? t : 0.0f;
+          else sum += d >= 0.0f ? t : 0.0f;
+          if constexpr (kCL) { if (++c2 == C) { c2 = 0; if (++a2 == A) { a2 = 0; if (++p2 == hw) { p2 = 0; ++i2; } } } }
           else { if (++p2 == hw) { p2 = 0; if (++c2 == C) { c2 = 0; if (++a2 == A) { a2 = 0; ++i2; } } } }
         }
       }
-      float out[kPer];
-#pragma unroll
-      for (int e = 0; e < kPer; ++e) {
-        float x;
-        if constexpr (std::is_same_v<T, F32>) {
-          x = __uint_as_float(raw[e]);
-        } else {
-          const uint32_t h = (raw[e >> 1] >> (16 * (e & 1))) & 0xffffu;
-          x = std::is_same_v<T, BF16> ? bf16_bits_to_float(h) : f16_bits_to_float(h);
-        }
-        // evaluated for every element (no branch around the arithmetic: lanes diverge on `dep`), masked afterwards
-        const bool positive = dep[e] > 0.0f && static_cast<uint32_t>(dep[e] - 1.0f) == cls_of[e];
-        float grad = 0.0f;
-        const float l = focal_element<kBackward>(x, positive, a.alpha, a.gamma, &grad);
-        const bool counted = dep[e] >= 0.0f;                                    // model.py:199 cls_mask
-        if constexpr (!kBackward) sum_cls += counted ? l : 0.0f;
-        out[e] = counted ? g * grad : 0.0f;
-      }
-      if constexpr (kBackward) {
-        vuint4 w;
-        if constexpr (std::is_same_v<T, F32>) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) w[e] = __float_as_uint(out[e]);
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            uint32_t lo, hi;
-            if constexpr (std::is_same_v<T, BF16>) {
-              lo = __float_as_uint(round_to_bf16(out[2 * e])) >> 16;
-              hi = __float_as_uint(round_to_bf16(out[2 * e + 1])) >> 16;
-            } else {
-              lo = __builtin_bit_cast(uint16_t, static_cast<_Float16>(out[2 * e]));
-              hi = __builtin_bit_cast(uint16_t, static_cast<_Float16>(out[2 * e + 1]));
-            }
-            w[e] = lo | (hi << 16);
-          }
-        }
-        static_cast<vuint4 *>(a.dcls)[v] = w;
-      } else if (++trips == 8) {                                               // fp32 partial of <= 64 elements -> fp64
-        acc_cls += sum_cls;
-        sum_cls = 0.0f;
-        trips = 0;
-      }
+      if constexpr (kBackward) __builtin_nontemporal_store(pack_vec<T>(out), static_cast<vuint4 *>(a.dcls) + v);
     }
-    // scalar tail (n % kPer elements), first block only
-    if (block == 0 && threadIdx.x < n - n_vec * kPer) {
-      const uint32_t r = n_vec * kPer + threadIdx.x;
-      uint32_t img, an, c, pix;
-      if (a.channels_last) {
-        const uint32_t p = r / channels, ch = r - p * channels;
-        img = p / hw; pix = p - img * hw;
-        an = ch / C; c = ch - an * C;
-      } else {
-        const uint32_t q = r / hw, ia = q / C;
-        pix = r - q * hw;
-        c = q - ia * C; img = ia / A; an = ia - img * A;
-      }
-      const float x = load_raw<T>(a.cls, r);
-      const float dep = a.depth[(static_cast<uint64_t>(img) * A + an) * hw + pix];
-      float grad = 0.0f;
-      if (dep >= 0.0f) {
-        const bool positive = dep > 0.0f && static_cast<uint32_t>(dep - 1.0f) == c;
-        const float l = focal_element<kBackward>(x, positive, a.alpha, a.gamma, &grad);
-        if constexpr (!kBackward) sum_cls += l;
-      }
-      if constexpr (kBackward) store_elem<T>(a.dcls, r, g * grad);
+    if constexpr (!kBackward) acc += sum;
+  }
+
+  // scalar tail (n % kPer elements), first block only
+  if (block == 0 && threadIdx.x < n - n_vec * kPer) {
+    const uint32_t r = n_vec * kPer + threadIdx.x;
+    uint32_t img, an, c, pix;
+    if constexpr (kCL) {
+      uint32_t ch;
+      const uint32_t p = fastdivmod(r, a.by_channels, &ch);
+      img = fastdivmod(p, a.by_hw, &pix);
+      an = fastdivmod(ch, a.by_classes, &c);
+    } else {
+      const uint32_t q = fastdivmod(r, a.by_hw, &pix);
+      const uint32_t ia = fastdivmod(q, a.by_classes, &c);
+      img = fastdivmod(ia, a.by_anchors, &an);
     }
-    acc_cls += sum_cls;
+    const float d = a.depth[(img * A + an) * hw + pix];
+    const float t = focal_term<kBackward, kGamma2>(load_raw<T>(a.cls, r), d == static_cast<float>(c + 1), w_neg, w_pos, gamma);
+    if constexpr (kBackward) store_elem<T>(a.dcls, r, d >= 0.0f ? t : 0.0f);
+    else acc += d >= 0.0f ? t : 0.0f;
+  }
+  return acc;
+}
+
+// One workgroup's share of one level: workgroup `block` of the `n_blocks` that level's slice of the launch consists of.
+// kBackward = false: accumulate the three sums.  kBackward = true: write the gradients.
+template <typename T, bool kBackward, int kUnroll>
+__device__ __forceinline__ void retina_loss_block(const LossArgs &a, uint32_t block, uint32_t n_blocks, double *s_red) {
+  const uint32_t A = a.num_anchors, hw = a.hw, NB = a.nb;
+  double acc_cls = 0.0, acc_box = 0.0, acc_fg = 0.0;
+
+  if (block < a.cls_blocks) {
+    const bool g2 = a.gamma == 2.0f;                        // launch-uniform
+    if (a.channels_last) acc_cls = g2 ? focal_stream<T, kBackward, true, true, kUnroll>(a, block)
+                                      : focal_stream<T, kBackward, false, true, kUnroll>(a, block);
+    else acc_cls = g2 ? focal_stream<T, kBackward, true, false, kUnroll>(a, block)
+                      : focal_stream<T, kBackward, false, false, kUnroll>(a, block);
   } else {
     // ---- the box deltas: one lane per (image, anchor, pixel), NB parameters each; only foreground anchors count ----
     const float g = kBackward ? (a.g_box ? *a.g_box : 0.0f) : 0.0f;
-    const uint64_t cells = static_cast<uint64_t>(a.batch) * A * hw;
-    const uint64_t stride = static_cast<uint64_t>(n_blocks - a.cls_blocks) * kLossThreads;
-    for (uint64_t cell = static_cast<uint64_t>(block - a.cls_blocks) * kLossThreads + threadIdx.x; cell < cells; cell += stride) {
-      const uint64_t ia = cell / hw;                          // img * A + an
-      const uint32_t pix = static_cast<uint32_t>(cell - ia * hw);
-      const uint32_t img = static_cast<uint32_t>(ia / A), an = static_cast<uint32_t>(ia - static_cast<uint64_t>(img) * A);
+    float sum_box = 0.0f, n_fg = 0.0f;
+    const uint32_t cells = a.batch * A * hw;                // < 2^32 (host)
+    const uint32_t stride = (n_blocks - a.cls_blocks) * blockDim.x;
+    for (uint32_t cell = (block - a.cls_blocks) * blockDim.x + threadIdx.x; cell < cells; cell += stride) {
+      uint32_t pix, an;
+      const uint32_t ia = fastdivmod(cell, a.by_hw, &pix);  // img * A + an
+      const uint32_t img = fastdivmod(ia, a.by_anchors, &an);
       const bool fg = a.depth[cell] > 0.0f;                                     // model.py:204 box_mask
       if (!kBackward && fg) n_fg += 1.0f;
       if (!fg && !kBackward) continue;
       for (uint32_t k = 0; k < NB; ++k) {
         const uint64_t off = a.channels_last ? (static_cast<uint64_t>(img) * hw + pix) * (A * NB) + an * NB + k
-                                             : (ia * NB + k) * hw + pix;
+                                             : (static_cast<uint64_t>(ia) * NB + k) * hw + pix;
         float grad = 0.0f;
         if (fg) {
-          const float l = smooth_l1_element<kBackward>(load_raw<T>(a.box, off), a.box_target[(ia * NB + k) * hw + pix], a.beta, &grad);
+          const float l = smooth_l1_element<kBackward>(load_raw<T>(a.box, off),
+                                                       a.box_target[(static_cast<uint64_t>(ia) * NB + k) * hw + pix], a.beta, &grad);
           if constexpr (!kBackward) sum_box += l;
         }
         if constexpr (kBackward) store_elem<T>(a.dbox, off, g * grad);
@@ -277,13 +343,7 @@ __device__ __forceinline__ void retina_loss_block(const LossArgs &a, uint32_t bl
   }
 }
 
-template <typename T, bool kBackward>
-__global__ __launch_bounds__(kLossThreads) void retina_loss_kernel(const LossArgs a) {
-  __shared__ double s_red[kLossThreads / kWave];
-  retina_loss_block<T, kBackward>(a, blockIdx.x, gridDim.x, s_red);
-}
-
-// All pyramid levels of the batch in ONE launch per direction (ten launches per training step become two): the
+// One or all pyramid levels of the batch in ONE launch per direction (ten launches per training step become two): the
 // workgroups of level l are [block_begin[l], block_begin[l + 1]).
 struct LossLevelsArgs {
   LossArgs lv[ODTK_MAX_LEVELS];
@@ -291,14 +351,14 @@ struct LossLevelsArgs {
   int n_levels;
 };
 
-template <typename T, bool kBackward>
-__global__ __launch_bounds__(kLossThreads) void retina_loss_levels_kernel(const LossLevelsArgs a) {
-  __shared__ double s_red[kLossThreads / kWave];
+template <typename T, bool kBackward, int kUnroll>
+__global__ __launch_bounds__(kLossMaxThreads) void retina_loss_kernel(const LossLevelsArgs a) {
+  __shared__ double s_red[kLossMaxThreads / kWave];
   int l = 0;
 #pragma unroll
   for (int i = 1; i < ODTK_MAX_LEVELS; ++i)
     if (i < a.n_levels && blockIdx.x >= a.block_begin[i]) l = i;
-  retina_loss_block<T, kBackward>(a.lv[l], blockIdx.x - a.block_begin[l], a.block_begin[l + 1] - a.block_begin[l], s_red);
+  retina_loss_block<T, kBackward, kUnroll>(a.lv[l], blockIdx.x - a.block_begin[l], a.block_begin[l + 1] - a.block_begin[l], s_red);
 }
 
 }  // namespace odtk

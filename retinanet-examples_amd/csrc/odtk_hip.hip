@@ -529,6 +529,15 @@ int bias_act_dispatch(void *y, const float *bias, const void *res, uint64_t n, u
   return bias_act_typed<odtk::F16>(y, bias, res, n, c, relu, s);
 }
 
+// Launch shape of the loss kernels (odtk_debug_loss_tuning; defaults = the measured best):
+// workgroup size, resident workgroups per CU the logit walk is capped at, 16-byte vectors a lane loads per trip.
+struct LossTuning {
+  int threads, per_cu, unroll, box_blocks;
+};
+// [16-bit heads, fp32 heads][forward, backward] = threads, logit workgroups per CU and level, vectors per trip, box
+// workgroups per level; measured with tools/loss_probe.py (profiles/r03_loss_probe.txt)
+LossTuning g_loss_tuning[2][2] = {{{512, 1, 2, 64}, {256, 4, 1, 256}}, {{512, 1, 4, 64}, {1024, 16, 2, 1024}}};
+
 // fills the kernel arguments of one level; returns the number of workgroups it wants (0 on error, *rc set)
 unsigned retina_loss_fill(odtk::LossArgs &la, bool backward, const void *cls, const void *box, const float *depth,
                           const float *box_target, int batch, int A, int C, int height, int width, int nb, int dtype,
@@ -541,50 +550,47 @@ unsigned retina_loss_fill(odtk::LossArgs &la, bool backward, const void *cls, co
   if (backward && (!dcls || !dbox || ((reinterpret_cast<uintptr_t>(dcls) | reinterpret_cast<uintptr_t>(dbox)) & 15u))) return 0;
   const unsigned long long n = 1ull * batch * A * C * height * width;
   if (n >= (1ull << 32)) return 0;
+  if (1ull * batch * A * nb * height * width >= (1ull << 32)) return 0;
   std::memset(&la, 0, sizeof la);
   la.cls = cls; la.box = box; la.depth = depth; la.box_target = box_target;
   la.acc = sums; la.g_cls = g_cls; la.g_box = g_box; la.dcls = dcls; la.dbox = dbox;
   la.batch = batch; la.num_anchors = A; la.num_classes = C; la.hw = static_cast<uint32_t>(height) * width; la.nb = nb;
   la.channels_last = channels_last;
   la.alpha = alpha; la.gamma = gamma; la.beta = beta;
+  la.by_channels = odtk::fastdiv_make(static_cast<uint32_t>(A) * C);
+  la.by_hw = odtk::fastdiv_make(la.hw);
+  la.by_classes = odtk::fastdiv_make(C);
+  la.by_anchors = odtk::fastdiv_make(A);
+  const LossTuning &t = g_loss_tuning[dtype == ODTK_F32][backward];
+  const unsigned threads = t.threads, unroll = t.unroll;
   const unsigned per = dtype == ODTK_F32 ? 4u : 8u;
-  unsigned long long cls_blocks = (n / per + odtk::kLossThreads * 4ull - 1) / (odtk::kLossThreads * 4ull);   // ~4 vectors per lane
+  // at least two trips of `unroll` vectors per lane where the level is large enough
+  unsigned long long cls_blocks = (n / per + threads * unroll * 2ull - 1) / (threads * unroll * 2ull);
   if (cls_blocks < 1) cls_blocks = 1;
-  // forward: every block ends in (up to) three double atomics on the SAME three words, ~11 ns each when they queue up
-  // (MI355X_MICROARCH.md "fanin") -- 4096 blocks cost 40 us of pure queueing per launch; backward has no such tail
-  const unsigned long long block_cap = backward ? 256 * 16 : 256 * 4;
+  // forward: every block ends in (up to) three double atomics on the SAME three words of its level, ~11 ns each when
+  // they queue up (MI355X_MICROARCH.md "fanin") -- 4096 blocks cost 40 us of pure queueing per launch, and the ~2 800
+  // box-delta blocks of round 2 (one cell per lane, two atomics each) cost ~30 us on their own: the forward launch
+  // keeps both kinds of workgroup few (a lane walks several vectors / cells); backward has no such tail.
+  // The cap is PER LEVEL: dealing one budget to the levels in proportion to their size (P3 = 3/4 of the logits) was
+  // measured slower -- 768 atomics on P3's word instead of 256 (profiles/r03_loss_probe_proportional_dealing.txt).
+  const unsigned long long block_cap = 256ull * t.per_cu;
   if (cls_blocks > block_cap) cls_blocks = block_cap;
-  unsigned long long box_blocks = (1ull * batch * A * height * width + odtk::kLossThreads - 1) / odtk::kLossThreads;
-  if (box_blocks > 1024) box_blocks = 1024;
+  unsigned long long box_blocks = (1ull * batch * A * height * width + threads - 1) / threads;
+  if (box_blocks > static_cast<unsigned>(t.box_blocks)) box_blocks = t.box_blocks;
   la.cls_blocks = static_cast<uint32_t>(cls_blocks);
   *rc = ODTK_OK;
   return static_cast<unsigned>(cls_blocks + box_blocks);
 }
 
-int retina_loss_launch(bool backward, const void *cls, const void *box, const float *depth, const float *box_target,
-                       int batch, int A, int C, int height, int width, int nb, int dtype, int channels_last, float alpha,
-                       float gamma, float beta, double *sums, const float *g_cls, const float *g_box, void *dcls,
-                       void *dbox, hipStream_t stream) {
-  if (dtype != ODTK_F32 && dtype != ODTK_BF16 && dtype != ODTK_F16) return ODTK_ERR_UNSUPPORTED;
-  odtk::LossArgs la;
-  int rc;
-  const unsigned blocks = retina_loss_fill(la, backward, cls, box, depth, box_target, batch, A, C, height, width, nb, dtype,
-                                           channels_last, alpha, gamma, beta, sums, g_cls, g_box, dcls, dbox, &rc);
-  if (rc != ODTK_OK) return rc;
-  const dim3 grid(blocks), block(odtk::kLossThreads);
-  {
-#define ODTK_LOSS(T)                                                                                            \
-  do {                                                                                                          \
-    if (backward) timed_launch(ODTK_KERNEL_LOSS, odtk::retina_loss_kernel<T, true>, grid, block, 0, stream, la);   \
-    else timed_launch(ODTK_KERNEL_LOSS, odtk::retina_loss_kernel<T, false>, grid, block, 0, stream, la);           \
-  } while (0)
-    if (dtype == ODTK_F32) ODTK_LOSS(odtk::F32);
-    else if (dtype == ODTK_BF16) ODTK_LOSS(odtk::BF16);
-    else ODTK_LOSS(odtk::F16);
-#undef ODTK_LOSS
+template <typename T, bool kBackward>
+void retina_loss_dispatch(const odtk::LossLevelsArgs &la, unsigned total, hipStream_t stream) {
+  const LossTuning &t = g_loss_tuning[std::is_same_v<T, odtk::F32>][kBackward];
+  const dim3 grid(total), block(t.threads);
+  switch (t.unroll) {
+    case 1: timed_launch(ODTK_KERNEL_LOSS, odtk::retina_loss_kernel<T, kBackward, 1>, grid, block, 0, stream, la); break;
+    case 2: timed_launch(ODTK_KERNEL_LOSS, odtk::retina_loss_kernel<T, kBackward, 2>, grid, block, 0, stream, la); break;
+    default: timed_launch(ODTK_KERNEL_LOSS, odtk::retina_loss_kernel<T, kBackward, 4>, grid, block, 0, stream, la); break;
   }
-  ODTK_HIP_TRY(hipGetLastError());
-  return ODTK_OK;
 }
 
 int retina_loss_levels_launch(bool backward, int n_levels, const odtk_loss_level_t *levels, int batch, int A, int C, int nb,
@@ -607,18 +613,24 @@ int retina_loss_levels_launch(bool backward, int n_levels, const odtk_loss_level
     total += blocks;
   }
   for (int l = n_levels; l <= ODTK_MAX_LEVELS; ++l) la.block_begin[l] = total;
-  const dim3 grid(total), block(odtk::kLossThreads);
-#define ODTK_LOSS(T)                                                                                                   \
-  do {                                                                                                                 \
-    if (backward) timed_launch(ODTK_KERNEL_LOSS, odtk::retina_loss_levels_kernel<T, true>, grid, block, 0, stream, la);  \
-    else timed_launch(ODTK_KERNEL_LOSS, odtk::retina_loss_levels_kernel<T, false>, grid, block, 0, stream, la);          \
-  } while (0)
-  if (dtype == ODTK_F32) ODTK_LOSS(odtk::F32);
-  else if (dtype == ODTK_BF16) ODTK_LOSS(odtk::BF16);
-  else ODTK_LOSS(odtk::F16);
-#undef ODTK_LOSS
+  if (dtype == ODTK_F32) backward ? retina_loss_dispatch<odtk::F32, true>(la, total, stream) : retina_loss_dispatch<odtk::F32, false>(la, total, stream);
+  else if (dtype == ODTK_BF16) backward ? retina_loss_dispatch<odtk::BF16, true>(la, total, stream) : retina_loss_dispatch<odtk::BF16, false>(la, total, stream);
+  else backward ? retina_loss_dispatch<odtk::F16, true>(la, total, stream) : retina_loss_dispatch<odtk::F16, false>(la, total, stream);
   ODTK_HIP_TRY(hipGetLastError());
   return ODTK_OK;
+}
+
+// one level = a one-entry level table through the same kernel
+int retina_loss_launch(bool backward, const void *cls, const void *box, const float *depth, const float *box_target,
+                       int batch, int A, int C, int height, int width, int nb, int dtype, int channels_last, float alpha,
+                       float gamma, float beta, double *sums, const float *g_cls, const float *g_box, void *dcls,
+                       void *dbox, hipStream_t stream) {
+  odtk_loss_level_t lv;
+  std::memset(&lv, 0, sizeof lv);
+  lv.cls = cls; lv.box = box; lv.depth = depth; lv.box_target = box_target;
+  lv.dcls = dcls; lv.dbox = dbox;
+  lv.height = height; lv.width = width; lv.channels_last = channels_last;
+  return retina_loss_levels_launch(backward, 1, &lv, batch, A, C, nb, dtype, alpha, gamma, beta, sums, g_cls, g_box, stream);
 }
 
 int decode_single(bool rotated, int batch, const void *const *inputs, void *const *outputs, size_t height,
@@ -653,6 +665,14 @@ const char *odtk_last_hip_error(void) { return g_last_error; }
 
 int odtk_debug_set_trace(void *device_buffer) {
   g_trace = static_cast<unsigned long long *>(device_buffer);
+  return ODTK_OK;
+}
+
+int odtk_debug_loss_tuning(int backward, int fp32_heads, int threads, int blocks_per_cu, int unroll, int box_blocks) {
+  if (threads < 64 || threads > odtk::kLossMaxThreads || threads % 64 || blocks_per_cu < 1 || blocks_per_cu > 64 ||
+      (unroll != 1 && unroll != 2 && unroll != 4) || box_blocks < 1 || box_blocks > 16384)
+    return ODTK_ERR_INVALID;
+  g_loss_tuning[fp32_heads != 0][backward != 0] = LossTuning{threads, blocks_per_cu, unroll, box_blocks};
   return ODTK_OK;
 }
 

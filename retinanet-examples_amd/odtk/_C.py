@@ -89,6 +89,7 @@ _SIGNATURES = {
     'odtk_bias_act': (ctypes.c_int, [_vp, _vp, _vp, _sz, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp]),
     'odtk_profile_enable': (ctypes.c_int, [ctypes.c_int]),
     'odtk_debug_set_trace': (ctypes.c_int, [_vp]),
+    'odtk_debug_loss_tuning': (ctypes.c_int, [ctypes.c_int] * 6),
     'odtk_bias_act_maxpool': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
                                              ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     'odtk_gemm_init': (ctypes.c_int, [ctypes.c_char_p]),
@@ -119,6 +120,13 @@ def library():
             fn.restype = res
             fn.argtypes = args
         _lib = lib
+        # Debug knob (tools/loss_probe.py): ODTK_LOSS_TUNING="fwd32:threads,blocks_per_cu,unroll,box_blocks;bwd16:..."
+        # overrides the built-in launch shape of the loss kernels for this process
+        for part in filter(None, os.environ.get('ODTK_LOSS_TUNING', '').split(';')):
+            side, _, vals = part.partition(':')
+            side = side.strip()
+            _check(lib.odtk_debug_loss_tuning(int(side.startswith('bwd')), int(side.endswith('32')),
+                                              *(int(v) for v in vals.split(','))), 'ODTK_LOSS_TUNING')
     return _lib
 
 
@@ -640,6 +648,13 @@ def gemm_bias_act(x, weight, bias, residual=None, relu=True):
                                             b * h * w, n, k, _DTYPES[x.dtype], 1 if relu else 0,
                                             ws.data_ptr(), ws.numel(), stream), 'gemm_bias_act')
     return y
+
+
+def loss_tuning(backward, fp32_heads, threads, blocks_per_cu, unroll, box_blocks):
+    """Debug / tuning: launch shape of the loss kernels of one direction and head width (include/odtk_hip.h:
+    odtk_debug_loss_tuning)."""
+    _check(library().odtk_debug_loss_tuning(int(bool(backward)), int(bool(fp32_heads)), int(threads), int(blocks_per_cu),
+                                            int(unroll), int(box_blocks)), 'loss_tuning')
 
 
 def profile_enable(on=True, kernels=None):

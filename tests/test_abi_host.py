@@ -155,3 +155,59 @@ def test_new_entry_points_validate_before_touching_the_device():
     assert lib.odtk_decode_levels(2, 1, lv, 9, 3, _C.BF16, _C.FLAG_LOGITS, 0.05, 100, None, 0, None, 0, None) == _C.ERR_UNSUPPORTED
     lv[0].channels_last = 0
     assert lib.odtk_decode_levels(2, 1, lv, 9, 80, _C.BF16, _C.FLAG_LOGITS, 0.05, 100, None, 0, None, 0, None) == _C.ERR_UNSUPPORTED
+
+
+def test_loss_tuning_hook_validates_without_a_gpu():
+    """odtk_debug_loss_tuning (launch shape of the loss kernels) never touches HIP: bad shapes are refused, good ones stick
+    until set back.  The built-in defaults are the ones tools/loss_probe.py measured (profiles/r03_loss_probe.txt)."""
+    lib = _C.library()
+    for bad in ((0, 1, 100, 1, 4, 64), (0, 1, 2048, 1, 4, 64), (0, 1, 512, 0, 4, 64), (0, 1, 512, 1, 3, 64),
+                (1, 0, 256, 4, 1, 0), (1, 0, 256, 65, 1, 256)):
+        assert lib.odtk_debug_loss_tuning(*bad) == _C.ERR_INVALID, bad
+    for good in ((0, 0, 512, 1, 2, 64), (1, 0, 256, 4, 1, 256), (0, 1, 512, 1, 4, 64), (1, 1, 1024, 16, 2, 1024)):   # = the defaults
+        assert lib.odtk_debug_loss_tuning(*good) == 0, good
+    with pytest.raises(RuntimeError, match='invalid argument'):
+        _C.loss_tuning(0, 1, 100, 1, 4, 64)
+
+
+def test_fastdiv_is_exact(tmp_path):
+    """csrc/fastdiv.hpp (division by a launch-constant divisor: multiply-high + shifts, Granlund & Montgomery fig. 4.1)
+    against `/` and `%`: every divisor the kernels can see at the edges, random pairs over the whole 32-bit range."""
+    import subprocess
+    src = tmp_path / 'fd.cpp'
+    src.write_text(r'''
+#include "%s"
+#include <cstdio>
+#include <random>
+int main() {
+  std::mt19937_64 g(1);
+  unsigned long long bad = 0, n = 0;
+  const uint32_t ds[] = {1, 2, 3, 4, 5, 7, 9, 27, 80, 90, 720, 2160, 1000, 4000, 16000, 65535, 65536, 65537,
+                         0x7fffffffu, 0x80000000u, 0x80000001u, 0xfffffffeu, 0xffffffffu};
+  for (uint32_t d : ds) {
+    const odtk::FastDiv f = odtk::fastdiv_make(d);
+    const uint32_t xs[] = {0, 1, d - 1, d, d + 1, 2 * d - 1, 2 * d, 0xffffffffu, 0xfffffffeu, 0x80000000u, 0x7fffffffu};
+    for (uint32_t x : xs) { ++n; if (odtk::fastdiv(x, f) != x / d) ++bad; }
+    for (int i = 0; i < 100000; ++i) {
+      const uint32_t x = static_cast<uint32_t>(g());
+      uint32_t r;
+      const uint32_t q = odtk::fastdivmod(x, f, &r);
+      ++n;
+      if (q != x / d || r != x %% d) ++bad;
+    }
+  }
+  for (int i = 0; i < 1000000; ++i) {
+    uint32_t d = static_cast<uint32_t>(g()) >> (g() %% 32);
+    if (!d) d = 1;
+    const uint32_t x = static_cast<uint32_t>(g()) >> (g() %% 32);
+    ++n;
+    if (odtk::fastdiv(x, odtk::fastdiv_make(d)) != x / d) ++bad;
+  }
+  std::printf("%%llu %%llu\n", n, bad);
+  return bad != 0;
+}
+''' % os.path.join(ROOT, 'retinanet-examples_amd', 'csrc', 'fastdiv.hpp'))
+    exe = tmp_path / 'fd'
+    subprocess.run(['g++', '-O2', '-std=c++17', '-o', str(exe), str(src)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
+    assert int(out[0]) > 3_000_000 and int(out[1]) == 0, out

@@ -144,9 +144,13 @@ def candidate_paths(model, x):
         with torch.autocast('cuda', dtype=torch.bfloat16):
             out['engine_bf16'] = model(x)                    # the default path = what bench.py times
         out['engine_fp32'] = model(x)
+        with torch.autocast('cuda', dtype=torch.float16):
+            out['engine_fp16'] = model(x)                    # what `odtk infer` runs by default (mixed precision = fp16, as the reference)
         model.fused_graph = False
         with torch.autocast('cuda', dtype=torch.bfloat16):
             out['eager_autocast_bf16'] = model(x)
+        with torch.autocast('cuda', dtype=torch.float16):
+            out['eager_autocast_fp16'] = model(x)            # ... and what a model without a fused engine runs there
         model.fused_graph = True
     return out
 
@@ -219,3 +223,7 @@ def test_engines_agree_with_fp32_eager_plus_oracle():
     # measured on MI355X (round 2): reference 1.0, engine_fp32 1.0, engine_bf16 0.9833, eager autocast bf16 0.7668
     assert abs(ap['engine_bf16'] - ap['reference']) <= 0.05, ap          # bf16 arithmetic of the timed path
     assert ap['eager_autocast_bf16'] < ap['engine_bf16'] - 0.1, ap       # the eager graph's damped logits cost AP
+    # round 3 (ADVICE): `infer()`'s mixed precision is fp16 like the reference's -- three more mantissa bits than bf16
+    assert ap['engine_fp16'] >= ap['engine_bf16'] - 0.005, ap
+    assert abs(ap['engine_fp16'] - ap['reference']) <= 0.05, ap
+    assert ap['eager_autocast_fp16'] > ap['eager_autocast_bf16'], ap     # the fallback for models without a fused engine

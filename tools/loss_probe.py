@@ -1,0 +1,107 @@
+#!/usr/bin/env python
+"""Launch-shape sweep of the fused loss kernels (csrc/loss.hpp) at the training step's own sizes
+(BASELINE config 3 per GPU: 2 images of 800x1280, five levels, 9 anchors x 80 classes, channels_last).
+
+For each dtype and direction: workgroup size x resident-workgroup cap per CU x vectors per lane per trip x
+box-delta workgroups per level (odtk_debug_loss_tuning), event-timed over calls that ROTATE through three input sets -- one set (123 MB of fp32
+logits) would otherwise be re-read out of the 256 MiB Infinity Cache, which the real step never enjoys.
+Every shape's results are compared with the first shape's (sums to 1e-6 relative: the fp32 per-lane partials depend on the unroll, gradients bit for bit).
+Prints the table and the best shape per (dtype, direction) as an ODTK_LOSS_TUNING string (last line)."""
+import itertools
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, 'retinanet-examples_amd')]
+import torch
+from odtk import _C
+
+SIZES = [(100, 160), (50, 80), (25, 40), (13, 20), (7, 10)]
+B, A, C, NB = 2, 9, 80, 4
+SETS = 3
+
+
+def make_set(dtype, seed):
+    g = torch.Generator(device='cuda').manual_seed(seed)
+    cls, box, depth, tgt = [], [], [], []
+    for h, w in SIZES:
+        c = (torch.randn(B, A * C, h, w, device='cuda', generator=g) * 1.5 - 4.0).to(dtype).contiguous(memory_format=torch.channels_last)
+        b = (torch.randn(B, A * NB, h, w, device='cuda', generator=g) * 0.3).to(dtype).contiguous(memory_format=torch.channels_last)
+        u = torch.rand(B, A, 1, h, w, device='cuda', generator=g)
+        d = torch.zeros_like(u)
+        d[u < 0.02] = -1.0                                                      # ignored
+        fg = u > 0.995                                                          # foreground
+        d[fg] = torch.randint(1, C + 1, (int(fg.sum()),), device='cuda', generator=g).float()
+        cls.append(c); box.append(b); depth.append(d.contiguous())
+        tgt.append((torch.randn(B, A, NB, h, w, device='cuda', generator=g) * 0.3).contiguous())
+    return cls, box, depth, tgt
+
+
+def timed(fn, sets, iters):
+    """us per launch from the library's own event pairs (the dispatch's begin / end timestamps: no python in it)."""
+    for s in sets:
+        fn(s)
+    torch.cuda.synchronize()
+    _C.profile_collect()
+    for i in range(iters):
+        fn(sets[i % len(sets)])
+    torch.cuda.synchronize()
+    ms, n = _C.profile_collect()['retina_loss_kernel']
+    assert n == iters, (n, iters)
+    return ms * 1e3 / n
+
+
+def main():
+    iters = 30
+    _C.profile_enable(True, ('retina_loss_kernel',))
+    logits = sum(B * A * C * h * w for h, w in SIZES)
+    out = {}
+    best_spec = {}
+    for dtype, name in ((torch.float32, 'fp32'), (torch.float16, 'fp16')):
+        sets = [make_set(dtype, 10 + i) for i in range(SETS)]
+        gc = torch.full((len(SIZES),), 0.37, device='cuda')
+        gb = torch.full((len(SIZES),), -1.9, device='cuda')
+        elem = 4 if dtype == torch.float32 else 2
+        for backward in (0, 1):
+            def call(s, backward=backward):
+                if backward:
+                    return _C.retina_loss_levels_backward(s[0], s[1], s[2], s[3], 0.25, 2.0, 0.11, gc, gb)
+                return _C.retina_loss_levels_forward(s[0], s[1], s[2], s[3], 0.25, 2.0, 0.11)
+            ref = None
+            rows = []
+            caps = (1, 2, 4, 8) if not backward else (4, 8, 16)
+            boxes = (16, 64, 256, 1024) if not backward else (256, 1024)
+            for threads, per_cu, unroll, box_blocks in itertools.product((256, 512, 1024), caps, (1, 2, 4), boxes):
+                _C.loss_tuning(backward, dtype == torch.float32, threads, per_cu, unroll, box_blocks)
+                got = call(sets[0])
+                if backward:
+                    flat = [t for pair in got for t in pair]
+                    if ref is None:
+                        ref = [t.clone() for t in flat]
+                    else:
+                        assert all(torch.equal(a, b) for a, b in zip(flat, ref)), (name, threads, per_cu, unroll, box_blocks)
+                else:
+                    if ref is None:
+                        ref = got.clone()
+                    else:
+                        assert torch.allclose(got, ref, rtol=1e-6, atol=0), (name, threads, per_cu, unroll, box_blocks, got, ref)
+                us = timed(call, sets, iters)
+                rows.append((us, threads, per_cu, unroll, box_blocks))
+            rows.sort()
+            alg = logits * elem * (2 if backward else 1)
+            key = '%s %s' % (name, 'backward' if backward else 'forward')
+            out[key] = {'best_us': round(rows[0][0], 2), 'best_shape': rows[0][1:], 'GBps': round(alg / rows[0][0] / 1e3, 1),
+                        'frac_of_8TBps': round(alg / rows[0][0] / 1e3 / 8000, 3),
+                        'all': [(round(r[0], 2),) + r[1:] for r in rows]}
+            print('%-14s best %7.2f us = %6.1f GB/s (%.3f of 8 TB/s) at threads %d, %d WG/CU, unroll %d, %d box WGs' %
+                  (key, rows[0][0], alg / rows[0][0] / 1e3, alg / rows[0][0] / 1e3 / 8000, *rows[0][1:]))
+            for r in rows[:8] + rows[-3:]:
+                print('      %7.2f us  threads %4d  per_cu %2d  unroll %d  box %4d' % r)
+            best_spec[('bwd' if backward else 'fwd') + ('32' if name == 'fp32' else '16')] = rows[0][1:]
+    print(json.dumps(out))
+    print('ODTK_LOSS_TUNING=' + ';'.join('%s:%d,%d,%d,%d' % ((k,) + tuple(v)) for k, v in best_spec.items()))
+
+
+if __name__ == '__main__':
+    main()
