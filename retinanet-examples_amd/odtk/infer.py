@@ -219,15 +219,13 @@ def infer(model, path, detections_file, resize, max_size, batch_size, mixed_prec
             with open(name, 'w') as f:
                 json.dump(doc, f, indent=4)
     if has_truth:
-        if rotated_bbox:
-            # said on every rank-0 run, verbose or not: a training loop validating rotated boxes gets NO mAP from this
-            # (reference infer.py:160-172 rasterises the polygons with pycocotools' C mask code, which is not available here)
-            print('Rotated boxes: detections were written, but the polygon-mask (segm) evaluation of the reference needs '
-                  'pycocotools and is not provided -- no mAP is computed.', flush=True)
-            return 0
         if verbose:
             print('Evaluating model...')
-        evaluation = COCOeval(data_iterator.coco, data_iterator.coco.loadRes(detections), 'bbox')
+        # reference infer.py:164-168: rotated boxes are scored as regions ('segm' on the corner polygons), not by their
+        # axis-aligned fields.  odtk/cocoeval.py computes the polygons' IoU exactly where pycocotools counts mask pixels
+        evaluation = COCOeval(data_iterator.coco, data_iterator.coco.loadRes(detections), 'segm' if rotated_bbox else 'bbox')
+        if rotated_bbox and verbose:
+            print(' (rotated boxes: exact polygon IoU in place of pycocotools\' rasterised masks)')
         evaluation.evaluate()
         evaluation.accumulate()
         evaluation.summarize(out=print if verbose else (lambda line: None))

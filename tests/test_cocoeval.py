@@ -6,7 +6,7 @@ import random
 import numpy as np
 import pytest
 
-from odtk.cocoeval import COCOeval, box_iou
+from odtk.cocoeval import COCOeval, box_iou, polygon_iou
 from odtk.data import CocoIndex
 from oracle import cocoeval_loops
 
@@ -90,7 +90,7 @@ def test_no_detections_and_annotation_area_field():
     assert stats[3] == -1.0 and stats[4] == pytest.approx(1.0)
     with pytest.raises(NotImplementedError):
         index = CocoIndex(dataset={'images': [], 'annotations': []})
-        COCOeval(index, index, 'segm')
+        COCOeval(index, index, 'keypoints')
 
 
 @pytest.mark.parametrize('seed', [0, 1, 2])
@@ -121,3 +121,109 @@ def test_equals_the_loop_restatement_on_random_scenes(seed):
     want = cocoeval_loops.stats(gt, list(res.anns.values()), images, cats)
     np.testing.assert_allclose(got, want, rtol=0, atol=1e-12)
     assert 0 < got[0] < 1
+
+
+# ---- iouType 'segm': rotated boxes as polygons (reference infer.py:166), exact polygon IoU ----------------------------
+def _quad(x, y, w, h, theta=0.0):
+    """Corners of a w x h rectangle whose top-left corner sits at (x, y) before it is turned by theta about its centre."""
+    cx, cy = x + w / 2, y + h / 2
+    c, s = np.cos(theta), np.sin(theta)
+    pts = [(-w / 2, -h / 2), (w / 2, -h / 2), (w / 2, h / 2), (-w / 2, h / 2)]
+    return [[float(v) for px, py in pts for v in (cx + c * px - s * py, cy + s * px + c * py)]]
+
+
+def test_polygon_iou_of_axis_aligned_rectangles_is_the_box_iou():
+    rng = np.random.default_rng(0)
+    boxes = np.concatenate([rng.random((40, 2)) * 60, rng.random((40, 2)) * 50 + 2], 1)
+    anns = [{'id': i + 1, 'segmentation': _quad(*b)} for i, b in enumerate(boxes)]
+    crowd = rng.random(20) < 0.3
+    got = polygon_iou(anns[:20], anns[20:], crowd)
+    want = box_iou(boxes[:20], boxes[20:], crowd)
+    assert np.abs(got - want).max() < 1e-12 and (want > 0).sum() > 50
+    # clockwise corner order and a different starting corner describe the same region
+    flipped = [{'id': a['id'], 'segmentation': [list(np.asarray(a['segmentation'][0]).reshape(-1, 2)[::-1].ravel())]} for a in anns[:20]]
+    assert np.abs(polygon_iou(flipped, anns[20:], crowd) - want).max() < 1e-12
+
+
+def test_polygon_iou_known_rotations():
+    sq = {'id': 1, 'segmentation': _quad(0, 0, 10, 10)}
+    # a square turned by 45 degrees about the same centre: the intersection is a regular octagon, IoU = 1 / sqrt(2)... of the union:
+    # inter = 200 (sqrt(2) - 1), union = 200 - inter
+    turned = {'id': 2, 'segmentation': _quad(0, 0, 10, 10, np.pi / 4)}
+    inter = 200 * (np.sqrt(2) - 1)
+    assert polygon_iou([turned], [sq], [False])[0, 0] == pytest.approx(inter / (200 - inter), abs=1e-12)
+    assert polygon_iou([turned], [sq], [True])[0, 0] == pytest.approx(inter / 100, abs=1e-12)       # crowd: over the detection
+    # a 20 x 2 bar turned by 90 degrees about the centre of a 20 x 2 bar: they share a 2 x 2 square
+    bar, cross = {'id': 3, 'segmentation': _quad(0, 9, 20, 2)}, {'id': 4, 'segmentation': _quad(0, 9, 20, 2, np.pi / 2)}
+    assert polygon_iou([bar], [cross], [False])[0, 0] == pytest.approx(4 / 76, abs=1e-12)
+    far = {'id': 5, 'segmentation': _quad(100, 100, 5, 5, 0.3)}
+    assert polygon_iou([far, sq], [sq], [False]).tolist() == [[0.0], [pytest.approx(1.0, abs=1e-12)]]
+    touching = {'id': 6, 'segmentation': _quad(10, 0, 10, 10)}                                       # shares an edge only
+    assert polygon_iou([touching], [sq], [False])[0, 0] == 0.0
+
+
+def test_polygon_iou_refuses_what_it_cannot_do_exactly():
+    with pytest.raises(NotImplementedError, match='not ONE polygon'):
+        polygon_iou([{'id': 1, 'segmentation': {'counts': 'abc', 'size': [4, 4]}}], [{'id': 2, 'segmentation': _quad(0, 0, 1, 1)}], [False])
+    with pytest.raises(NotImplementedError, match='not ONE polygon'):
+        polygon_iou([{'id': 1, 'segmentation': _quad(0, 0, 1, 1) * 2}], [{'id': 2, 'segmentation': _quad(0, 0, 1, 1)}], [False])
+    arrow = [[0, 0, 10, 0, 10, 10, 5, 2, 0, 10]]                                                     # a notch: not convex
+    with pytest.raises(NotImplementedError, match='not convex'):
+        polygon_iou([{'id': 1, 'segmentation': arrow}], [{'id': 2, 'segmentation': _quad(0, 0, 1, 1)}], [False])
+
+
+def test_segm_evaluation_of_rotated_detections():
+    """Rotated ground truth (RotatedCocoDataset form: x, y, w, h, theta + the polygon) against rotated detections: a
+    detection with the right extent but the wrong angle is a miss under 'segm' and a hit under 'bbox'."""
+    def ann(i, x, y, w, h, theta, **extra):
+        return dict({'id': i, 'image_id': 1, 'category_id': 1, 'bbox': [x, y, w, h, theta], 'area': float(w * h), 'iscrowd': 0,
+                     'segmentation': _quad(x, y, w, h, theta)}, **extra)
+    gt = [ann(1, 10, 10, 60, 12, 0.5), ann(2, 100, 40, 30, 30, 0.0)]
+    index = CocoIndex(dataset={'images': [{'id': 1}], 'annotations': gt, 'categories': [{'id': 1}]})
+
+    def run(dets, kind):
+        ev = COCOeval(index, index.loadRes(dets), kind)
+        ev.evaluate()
+        ev.accumulate()
+        return ev.summarize(out=lambda line: None)
+
+    def det(score, x, y, w, h, theta):
+        return {'image_id': 1, 'category_id': 1, 'score': score, 'bbox': [x, y, w, h, theta], 'segmentation': _quad(x, y, w, h, theta)}
+    right = [det(0.9, 10, 10, 60, 12, 0.5), det(0.8, 100, 40, 30, 30, 0.0)]
+    assert run(right, 'segm')[0] == pytest.approx(1.0, abs=1e-12)
+    wrong_angle = [det(0.9, 10, 10, 60, 12, -0.5), det(0.8, 100, 40, 30, 30, 0.0)]
+    assert run(wrong_angle, 'bbox')[0] == pytest.approx(1.0, abs=1e-12)       # the axis-aligned fields agree ...
+    s = run(wrong_angle, 'segm')
+    assert s[8] == pytest.approx(0.5) and s[0] < 0.6                          # ... the regions do not: one of two found
+    slightly_off = [det(0.9, 10, 10, 60, 12, 0.52), det(0.8, 101, 40, 30, 30, 0.0)]
+    s = run(slightly_off, 'segm')
+    assert 0.5 < s[0] < 1.0 and s[1] == pytest.approx(1.0, abs=1e-12)         # hits at IoU 0.5, not at 0.95
+
+
+def test_segm_on_the_rotated_annotation_fixture():
+    """The rotated data-set fixture (bbox = x, y, w, h, theta; no polygon in the file: derived with infer.rotated_corners):
+    its own boxes as detections score AP 1, the same boxes with the angles negated do not."""
+    import json
+    import os
+    from odtk import infer
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'data', 'annotations_rotated.json')
+    index = CocoIndex(path)
+    gt = json.load(open(path))['annotations']
+
+    def dets(sign):
+        out = []
+        for k, a in enumerate(gt):
+            x, y, w, h, theta = (list(a['bbox']) + [0.0])[:5]                  # plain boxes: theta = 0, as RotatedCocoDataset reads them
+            seg = infer.rotated_corners([x], [y], [w], [h], [sign * theta])[0].tolist()
+            out.append({'image_id': a['image_id'], 'category_id': a['category_id'], 'score': 0.9 - 0.01 * k,
+                        'bbox': [x, y, w, h, sign * theta], 'segmentation': [seg]})
+        return out
+
+    def run(d):
+        ev = COCOeval(index, index.loadRes(d), 'segm')
+        ev.evaluate()
+        ev.accumulate()
+        return ev.summarize(out=lambda line: None)
+    assert run(dets(1.0))[0] == pytest.approx(1.0, abs=1e-12)
+    assert any(len(a['bbox']) == 5 and abs(a['bbox'][4]) > 0.3 for a in gt)
+    assert run(dets(-1.0))[0] < 0.9
