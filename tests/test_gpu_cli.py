@@ -59,3 +59,24 @@ def test_train_then_infer_through_the_command_line(tmp_path, capsys):
         assert {d['image_id'] for d in doc['annotations']} <= {100, 103, 106, 109, 112}
         assert all(d['category_id'] in (7, 3, 11) and 0.05 <= d['score'] <= 1 and len(d['bbox']) == 4 for d in doc['annotations'])
         assert len(doc['annotations']) >= 5
+
+
+def test_rotated_infer_reports_an_ap(tmp_path, capsys):
+    """`odtk infer --rotated-bbox` with ground truth: the reference scores the corner polygons ('segm', infer.py:166); round 3
+    provides that evaluation (exact polygon IoU, odtk/cocoeval.py) -- before, a rotated model got no AP at all."""
+    torch.manual_seed(0)
+    model = Model('ResNet18FPN', classes=3, rotated_bbox=True)
+    model.initialize(None)
+    with torch.no_grad():
+        model.cls_head[-1].bias.fill_(0.0)                                            # detections exist
+    path = str(tmp_path / 'rotated.pth')
+    model.save({'path': path})
+    out_file = str(tmp_path / 'rotated.json')
+    stats = cli.main(['infer', path, '--images', DATA, '--annotations', os.path.join(DATA, 'annotations_rotated.json'),
+                      '--output', out_file, '--batch', '2', '--resize', '128', '--max-size', '160', '--workers', '0', '--rotated-bbox'])
+    text = capsys.readouterr().out
+    assert 'exact polygon IoU' in text and 'Average Precision  (AP) @[ IoU=0.50:0.95' in text
+    assert isinstance(stats, np.ndarray) and stats.shape == (12,) and np.all((stats >= 0) | (stats == -1.0))
+    doc = json.load(open(out_file))
+    assert len(doc['annotations']) >= 5
+    assert all(len(d['bbox']) == 5 and len(d['segmentation']) == 1 and len(d['segmentation'][0]) == 8 for d in doc['annotations'])
