@@ -303,6 +303,13 @@ typedef struct odtk_loss_level {
 int odtk_retina_loss_levels_forward(int n_levels, const odtk_loss_level_t *levels, int batch_size, int num_anchors,
                                     int num_classes, int box_params, int dtype, float alpha, float gamma, float beta,
                                     double *sums, void *stream);
+/* The forward through a workspace: every workgroup writes its three sums to the workspace and a second (tiny) launch adds
+ * them up in a fixed order -- no atomics (the plain form above ends every workgroup in a double atomic on its level's
+ * word, which bounds how many workgroups it can afford: DESIGN.md section 4) and a result that is bitwise reproducible
+ * from run to run.  Two-phase: workspace == NULL returns the bytes needed for these shapes; `sums` is overwritten. */
+int odtk_retina_loss_levels_forward_ws(int n_levels, const odtk_loss_level_t *levels, int batch_size, int num_anchors,
+                                       int num_classes, int box_params, int dtype, float alpha, float gamma, float beta,
+                                       double *sums, void *workspace, size_t workspace_size, void *stream);
 int odtk_retina_loss_levels_backward(int n_levels, const odtk_loss_level_t *levels, int batch_size, int num_anchors,
                                      int num_classes, int box_params, int dtype, float alpha, float gamma, float beta,
                                      const float *grad_cls_sums, const float *grad_box_sums, void *stream);
@@ -336,12 +343,13 @@ int odtk_profile_enable(int on);
 /* Debug: device buffer (>= 16 KiB) that select_decode / nms workgroups stamp with wall_clock64()
  * (100 MHz) at their phase boundaries; NULL (default) disables.  Not for production use. */
 int odtk_debug_set_trace(void *device_buffer);
-/* Debug / tuning: launch shape of the loss kernels for one direction (backward = 0 / 1) and head width (fp32_heads =
- * 0: bf16 / fp16, 1: fp32): workgroup size (multiple of 64, <= 1024), resident workgroups per CU the logit walk is
- * capped at (1..64), 16-byte vectors per lane per trip (1, 2 or 4), workgroups of the box-delta walk
- * (1..16384); both workgroup caps are per pyramid level.  The defaults are the measured best; results do not depend on the shape beyond the
- * order of the partial sums.  Process-wide, not thread-safe against concurrent loss launches. */
-int odtk_debug_loss_tuning(int backward, int fp32_heads, int threads, int blocks_per_cu, int unroll, int box_blocks);
+/* Debug / tuning: launch shape of the loss kernels for one form (which = 0: forward with atomics, 1: backward, 2: forward
+ * through a workspace) and head width (fp32_heads = 0: bf16 / fp16, 1: fp32): workgroup size (multiple of 64, <= 1024),
+ * resident workgroups per CU the logit walk is capped at (1..64), 16-byte vectors per lane per trip (1, 2 or 4),
+ * workgroups of the box-delta walk (1..16384); both workgroup caps are per pyramid level.  The defaults are the measured
+ * best; results do not depend on the shape beyond the order of the partial sums.  Process-wide, not
+ * thread-safe against concurrent loss launches; a workspace size queried before a change is stale after it. */
+int odtk_debug_loss_tuning(int which, int fp32_heads, int threads, int blocks_per_cu, int unroll, int box_blocks);
 int odtk_profile_collect(double total_ms[ODTK_KERNEL_COUNT], int launches[ODTK_KERNEL_COUNT]);
 
 #ifdef __cplusplus

@@ -20,8 +20,11 @@
 // logit (read + gradient write); depth / box terms are < 2 % of that.
 // Measured (round 3, tools/loss_probe.py, 2 images of 800x1280, cold inputs): fp32 forward 33 us (3.7 TB/s),
 // backward 52 us (4.8 TB/s); in the training step 88.7 us for both = 0.52 of 8 TB/s (round 2: 124.7 us, 0.37).
-// What the forward still pays for is its reduction: every workgroup ends in a double atomic on its level's word, so
-// the launch runs with few, large workgroups (launch shapes: odtk_debug_loss_tuning, defaults in odtk_hip.hip).
+// The forward is VALU-bound (fp16 heads take the same 30 us as fp32 ones, and an atomic-free reduction -- the workspace form
+// below -- measures the same): ~27 issue slots of arithmetic + ~5 of index math per logit, three of the instructions
+// quarter-rate (exp2, rcp, log2), against 39 T lane-operations/s.  Launch shapes: odtk_debug_loss_tuning, defaults in
+// odtk_hip.hip -- the forward with atomics wants few, large workgroups (every workgroup ends in a double atomic on its
+// level's word: 2048 workgroups per level cost +80 us of queueing).
 // Arithmetic per element: loss.py's expressions in fp32, in the symmetric form derived at focal_term below (the sums
 // are accumulated in fp32 per lane over <= 32 elements, then in fp64): forward values agree with the torch expression
 // evaluated in float64 to 1e-6 relative, gradients to 1e-5 of the largest gradient (tests/test_gpu_loss.py).
@@ -45,6 +48,8 @@ struct LossArgs {
   const float *depth;       // [B, A, 1, H, W]  -1 ignore / 0 background / class + 1
   const float *box_target;  // [B, A, NB, H, W]
   double *acc;              // forward: [3] = cls_sum, box_sum, foreground count (atomically accumulated; pre-zeroed)
+  double *partial;          // forward, workspace form: [gridDim.x][3] per-workgroup sums of the whole launch (acc unused);
+                            // loss_reduce_kernel adds them up afterwards -- no atomics, one fixed summation order
   const float *g_cls;       // backward: device scalar d(out)/d(cls_sum)   (null: 0)
   const float *g_box;       // backward: device scalar d(out)/d(box_sum)   (null: 0)
   void *dcls;               // backward: gradient w.r.t. cls, same dtype / layout as cls
@@ -336,9 +341,14 @@ __device__ __forceinline__ void retina_loss_block(const LossArgs &a, uint32_t bl
     const double b_ = block_sum(acc_box, s_red);
     const double f_ = block_sum(acc_fg, s_red);
     if (threadIdx.x == 0) {
-      if (c_ != 0.0) atomicAdd(a.acc + 0, c_);
-      if (b_ != 0.0) atomicAdd(a.acc + 1, b_);
-      if (f_ != 0.0) atomicAdd(a.acc + 2, f_);
+      if (a.partial) {
+        double *mine = a.partial + 3 * static_cast<size_t>(blockIdx.x);
+        mine[0] = c_; mine[1] = b_; mine[2] = f_;
+      } else {
+        if (c_ != 0.0) atomicAdd(a.acc + 0, c_);
+        if (b_ != 0.0) atomicAdd(a.acc + 1, b_);
+        if (f_ != 0.0) atomicAdd(a.acc + 2, f_);
+      }
     }
   }
 }
@@ -359,6 +369,30 @@ __global__ __launch_bounds__(kLossMaxThreads) void retina_loss_kernel(const Loss
   for (int i = 1; i < ODTK_MAX_LEVELS; ++i)
     if (i < a.n_levels && blockIdx.x >= a.block_begin[i]) l = i;
   retina_loss_block<T, kBackward, kUnroll>(a.lv[l], blockIdx.x - a.block_begin[l], a.block_begin[l + 1] - a.block_begin[l], s_red);
+}
+
+// Second launch of the workspace form of the forward: workgroup l adds up the per-workgroup sums of level l in a fixed
+// order (thread t takes partials t, t + 256, ...; then the wave / block tree) -> sums[l][0..2].  The loss is then bitwise
+// reproducible from run to run, which the atomic form is not.
+struct LossReduceArgs {
+  const double *partial;                       // [total workgroups][3]
+  double *sums;                                // [n_levels][3]
+  uint32_t block_begin[ODTK_MAX_LEVELS + 1];
+};
+
+__global__ __launch_bounds__(256) void loss_reduce_kernel(const LossReduceArgs a) {
+  __shared__ double s_red[256 / kWave];
+  const uint32_t l = blockIdx.x, b0 = a.block_begin[l], b1 = a.block_begin[l + 1];
+  double v[3] = {0.0, 0.0, 0.0};
+  for (uint32_t b = b0 + threadIdx.x; b < b1; b += 256) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) v[k] += a.partial[3 * static_cast<size_t>(b) + k];
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const double r = block_sum(v[k], s_red);
+    if (threadIdx.x == 0) a.sums[3 * l + k] = r;
+  }
 }
 
 }  // namespace odtk

@@ -534,15 +534,18 @@ int bias_act_dispatch(void *y, const float *bias, const void *res, uint64_t n, u
 struct LossTuning {
   int threads, per_cu, unroll, box_blocks;
 };
-// [16-bit heads, fp32 heads][forward, backward] = threads, logit workgroups per CU and level, vectors per trip, box
-// workgroups per level; measured with tools/loss_probe.py (profiles/r03_loss_probe.txt)
-LossTuning g_loss_tuning[2][2] = {{{512, 1, 2, 64}, {256, 4, 1, 256}}, {{512, 1, 4, 64}, {1024, 16, 2, 1024}}};
+// [16-bit heads, fp32 heads][forward with atomics, backward, forward through a workspace] = threads, logit workgroups per
+// CU and level, vectors per trip, box workgroups per level; measured with tools/loss_probe.py (profiles/r03_loss_probe.txt)
+enum { kLossFwd = 0, kLossBwd = 1, kLossFwdWs = 2 };
+LossTuning g_loss_tuning[2][3] = {{{512, 1, 2, 64}, {256, 4, 1, 256}, {256, 4, 1, 256}},
+                                  {{512, 1, 4, 64}, {1024, 16, 2, 1024}, {256, 4, 1, 256}}};
 
 // fills the kernel arguments of one level; returns the number of workgroups it wants (0 on error, *rc set)
-unsigned retina_loss_fill(odtk::LossArgs &la, bool backward, const void *cls, const void *box, const float *depth,
+unsigned retina_loss_fill(odtk::LossArgs &la, int which, const void *cls, const void *box, const float *depth,
                           const float *box_target, int batch, int A, int C, int height, int width, int nb, int dtype,
                           int channels_last, float alpha, float gamma, float beta, double *sums, const float *g_cls,
                           const float *g_box, void *dcls, void *dbox, int *rc) {
+  const bool backward = which == kLossBwd;
   *rc = ODTK_ERR_INVALID;
   if (!cls || !box || !depth || !box_target || batch <= 0 || A <= 0 || C <= 0 || height <= 0 || width <= 0 || nb <= 0) return 0;
   if (channels_last != 0 && channels_last != 1) return 0;
@@ -561,7 +564,7 @@ unsigned retina_loss_fill(odtk::LossArgs &la, bool backward, const void *cls, co
   la.by_hw = odtk::fastdiv_make(la.hw);
   la.by_classes = odtk::fastdiv_make(C);
   la.by_anchors = odtk::fastdiv_make(A);
-  const LossTuning &t = g_loss_tuning[dtype == ODTK_F32][backward];
+  const LossTuning &t = g_loss_tuning[dtype == ODTK_F32][which];
   const unsigned threads = t.threads, unroll = t.unroll;
   const unsigned per = dtype == ODTK_F32 ? 4u : 8u;
   // at least two trips of `unroll` vectors per lane where the level is large enough
@@ -583,8 +586,8 @@ unsigned retina_loss_fill(odtk::LossArgs &la, bool backward, const void *cls, co
 }
 
 template <typename T, bool kBackward>
-void retina_loss_dispatch(const odtk::LossLevelsArgs &la, unsigned total, hipStream_t stream) {
-  const LossTuning &t = g_loss_tuning[std::is_same_v<T, odtk::F32>][kBackward];
+void retina_loss_dispatch(const odtk::LossLevelsArgs &la, unsigned total, int which, hipStream_t stream) {
+  const LossTuning &t = g_loss_tuning[std::is_same_v<T, odtk::F32>][which];
   const dim3 grid(total), block(t.threads);
   switch (t.unroll) {
     case 1: timed_launch(ODTK_KERNEL_LOSS, odtk::retina_loss_kernel<T, kBackward, 1>, grid, block, 0, stream, la); break;
@@ -593,30 +596,44 @@ void retina_loss_dispatch(const odtk::LossLevelsArgs &la, unsigned total, hipStr
   }
 }
 
-int retina_loss_levels_launch(bool backward, int n_levels, const odtk_loss_level_t *levels, int batch, int A, int C, int nb,
+// which: kLossFwd (atomics into `sums`, pre-zeroed), kLossBwd, kLossFwdWs (per-workgroup sums into `partial`, then the
+// reduce launch writes `sums`).  With partial == nullptr and kLossFwdWs: returns the number of workgroups (size query).
+int retina_loss_levels_launch(int which, int n_levels, const odtk_loss_level_t *levels, int batch, int A, int C, int nb,
                               int dtype, float alpha, float gamma, float beta, double *sums, const float *g_cls,
-                              const float *g_box, hipStream_t stream) {
+                              const float *g_box, double *partial, bool query, hipStream_t stream) {
   if (n_levels <= 0 || n_levels > ODTK_MAX_LEVELS || !levels) return ODTK_ERR_INVALID;
   if (dtype != ODTK_F32 && dtype != ODTK_BF16 && dtype != ODTK_F16) return ODTK_ERR_UNSUPPORTED;
+  const bool backward = which == kLossBwd;
   odtk::LossLevelsArgs la;
   std::memset(&la, 0, sizeof la);
   la.n_levels = n_levels;
   unsigned total = 0;
   for (int l = 0; l < n_levels; ++l) {
     int rc;
-    const unsigned blocks = retina_loss_fill(la.lv[l], backward, levels[l].cls, levels[l].box, levels[l].depth, levels[l].box_target,
+    const unsigned blocks = retina_loss_fill(la.lv[l], which, levels[l].cls, levels[l].box, levels[l].depth, levels[l].box_target,
                                              batch, A, C, levels[l].height, levels[l].width, nb, dtype, levels[l].channels_last,
                                              alpha, gamma, beta, sums ? sums + 3 * l : nullptr, g_cls ? g_cls + l : nullptr,
                                              g_box ? g_box + l : nullptr, levels[l].dcls, levels[l].dbox, &rc);
     if (rc != ODTK_OK) return rc;
+    la.lv[l].partial = which == kLossFwdWs ? partial : nullptr;
     la.block_begin[l] = total;
     total += blocks;
   }
   for (int l = n_levels; l <= ODTK_MAX_LEVELS; ++l) la.block_begin[l] = total;
-  if (dtype == ODTK_F32) backward ? retina_loss_dispatch<odtk::F32, true>(la, total, stream) : retina_loss_dispatch<odtk::F32, false>(la, total, stream);
-  else if (dtype == ODTK_BF16) backward ? retina_loss_dispatch<odtk::BF16, true>(la, total, stream) : retina_loss_dispatch<odtk::BF16, false>(la, total, stream);
-  else backward ? retina_loss_dispatch<odtk::F16, true>(la, total, stream) : retina_loss_dispatch<odtk::F16, false>(la, total, stream);
+  if (query) return static_cast<int>(total);
+  if (dtype == ODTK_F32) backward ? retina_loss_dispatch<odtk::F32, true>(la, total, which, stream) : retina_loss_dispatch<odtk::F32, false>(la, total, which, stream);
+  else if (dtype == ODTK_BF16) backward ? retina_loss_dispatch<odtk::BF16, true>(la, total, which, stream) : retina_loss_dispatch<odtk::BF16, false>(la, total, which, stream);
+  else backward ? retina_loss_dispatch<odtk::F16, true>(la, total, which, stream) : retina_loss_dispatch<odtk::F16, false>(la, total, which, stream);
   ODTK_HIP_TRY(hipGetLastError());
+  if (which == kLossFwdWs) {
+    odtk::LossReduceArgs ra;
+    std::memset(&ra, 0, sizeof ra);
+    ra.partial = partial;
+    ra.sums = sums;
+    for (int l = 0; l <= ODTK_MAX_LEVELS; ++l) ra.block_begin[l] = la.block_begin[l];
+    timed_launch(ODTK_KERNEL_LOSS, odtk::loss_reduce_kernel, dim3(n_levels), dim3(256), 0, stream, ra);
+    ODTK_HIP_TRY(hipGetLastError());
+  }
   return ODTK_OK;
 }
 
@@ -630,7 +647,8 @@ int retina_loss_launch(bool backward, const void *cls, const void *box, const fl
   lv.cls = cls; lv.box = box; lv.depth = depth; lv.box_target = box_target;
   lv.dcls = dcls; lv.dbox = dbox;
   lv.height = height; lv.width = width; lv.channels_last = channels_last;
-  return retina_loss_levels_launch(backward, 1, &lv, batch, A, C, nb, dtype, alpha, gamma, beta, sums, g_cls, g_box, stream);
+  return retina_loss_levels_launch(backward ? kLossBwd : kLossFwd, 1, &lv, batch, A, C, nb, dtype, alpha, gamma, beta, sums, g_cls, g_box,
+                                   nullptr, false, stream);
 }
 
 int decode_single(bool rotated, int batch, const void *const *inputs, void *const *outputs, size_t height,
@@ -668,11 +686,11 @@ int odtk_debug_set_trace(void *device_buffer) {
   return ODTK_OK;
 }
 
-int odtk_debug_loss_tuning(int backward, int fp32_heads, int threads, int blocks_per_cu, int unroll, int box_blocks) {
-  if (threads < 64 || threads > odtk::kLossMaxThreads || threads % 64 || blocks_per_cu < 1 || blocks_per_cu > 64 ||
-      (unroll != 1 && unroll != 2 && unroll != 4) || box_blocks < 1 || box_blocks > 16384)
+int odtk_debug_loss_tuning(int which, int fp32_heads, int threads, int blocks_per_cu, int unroll, int box_blocks) {
+  if (which < 0 || which > 2 || threads < 64 || threads > odtk::kLossMaxThreads || threads % 64 || blocks_per_cu < 1 ||
+      blocks_per_cu > 64 || (unroll != 1 && unroll != 2 && unroll != 4) || box_blocks < 1 || box_blocks > 16384)
     return ODTK_ERR_INVALID;
-  g_loss_tuning[fp32_heads != 0][backward != 0] = LossTuning{threads, blocks_per_cu, unroll, box_blocks};
+  g_loss_tuning[fp32_heads != 0][which] = LossTuning{threads, blocks_per_cu, unroll, box_blocks};
   return ODTK_OK;
 }
 
@@ -856,15 +874,32 @@ int odtk_retina_loss_levels_forward(int n_levels, const odtk_loss_level_t *level
                                     double *sums, void *stream) {
   if (!sums || n_levels <= 0 || n_levels > ODTK_MAX_LEVELS) return ODTK_ERR_INVALID;
   ODTK_HIP_TRY(hipMemsetAsync(sums, 0, 3 * sizeof(double) * n_levels, static_cast<hipStream_t>(stream)));
-  return retina_loss_levels_launch(false, n_levels, levels, batch_size, num_anchors, num_classes, box_params, dtype, alpha,
-                                   gamma, beta, sums, nullptr, nullptr, static_cast<hipStream_t>(stream));
+  return retina_loss_levels_launch(kLossFwd, n_levels, levels, batch_size, num_anchors, num_classes, box_params, dtype, alpha,
+                                   gamma, beta, sums, nullptr, nullptr, nullptr, false, static_cast<hipStream_t>(stream));
+}
+
+int odtk_retina_loss_levels_forward_ws(int n_levels, const odtk_loss_level_t *levels, int batch_size, int num_anchors,
+                                       int num_classes, int box_params, int dtype, float alpha, float gamma, float beta,
+                                       double *sums, void *workspace, size_t workspace_size, void *stream) {
+  if (n_levels <= 0 || n_levels > ODTK_MAX_LEVELS) return ODTK_ERR_INVALID;
+  const int blocks = retina_loss_levels_launch(kLossFwdWs, n_levels, levels, batch_size, num_anchors, num_classes, box_params,
+                                               dtype, alpha, gamma, beta, nullptr, nullptr, nullptr, nullptr, true, nullptr);
+  if (blocks < 0) return blocks;
+  const size_t need = (static_cast<size_t>(blocks) * 3 * sizeof(double) + 255) & ~static_cast<size_t>(255);
+  if (!workspace) return static_cast<int>(need);                       // two-phase convention of the reference's plugins
+  if (!sums) return ODTK_ERR_INVALID;
+  if (workspace_size < need) return ODTK_ERR_WORKSPACE;
+  if (reinterpret_cast<uintptr_t>(workspace) & 7u) return ODTK_ERR_INVALID;
+  return retina_loss_levels_launch(kLossFwdWs, n_levels, levels, batch_size, num_anchors, num_classes, box_params, dtype, alpha,
+                                   gamma, beta, sums, nullptr, nullptr, static_cast<double *>(workspace), false,
+                                   static_cast<hipStream_t>(stream));
 }
 
 int odtk_retina_loss_levels_backward(int n_levels, const odtk_loss_level_t *levels, int batch_size, int num_anchors,
                                      int num_classes, int box_params, int dtype, float alpha, float gamma, float beta,
                                      const float *grad_cls_sums, const float *grad_box_sums, void *stream) {
-  return retina_loss_levels_launch(true, n_levels, levels, batch_size, num_anchors, num_classes, box_params, dtype, alpha,
-                                   gamma, beta, nullptr, grad_cls_sums, grad_box_sums, static_cast<hipStream_t>(stream));
+  return retina_loss_levels_launch(kLossBwd, n_levels, levels, batch_size, num_anchors, num_classes, box_params, dtype, alpha,
+                                   gamma, beta, nullptr, grad_cls_sums, grad_box_sums, nullptr, false, static_cast<hipStream_t>(stream));
 }
 
 int odtk_bias_act_maxpool(const void *y, const float *bias, void *out, int batch_size, int height, int width,

@@ -84,6 +84,8 @@ _SIGNATURES = {
                                   [_vp, _vp, _vp, _vp, _vp]),
     'odtk_retina_loss_levels_forward': (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(LossLevel)] + [ctypes.c_int] * 5 +
                                         [ctypes.c_float] * 3 + [_vp, _vp]),
+    'odtk_retina_loss_levels_forward_ws': (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(LossLevel)] + [ctypes.c_int] * 5 +
+                                           [ctypes.c_float] * 3 + [_vp, _vp, _sz, _vp]),
     'odtk_retina_loss_levels_backward': (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(LossLevel)] + [ctypes.c_int] * 5 +
                                          [ctypes.c_float] * 3 + [_vp, _vp, _vp]),
     'odtk_bias_act': (ctypes.c_int, [_vp, _vp, _vp, _sz, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp]),
@@ -120,12 +122,12 @@ def library():
             fn.restype = res
             fn.argtypes = args
         _lib = lib
-        # Debug knob (tools/loss_probe.py): ODTK_LOSS_TUNING="fwd32:threads,blocks_per_cu,unroll,box_blocks;bwd16:..."
-        # overrides the built-in launch shape of the loss kernels for this process
+        # Debug knob (tools/loss_probe.py): ODTK_LOSS_TUNING="fwd32:threads,blocks_per_cu,unroll,box_blocks;bwd16:...;ws32:..."
+        # (fwd = forward with atomics, bwd, ws = forward through a workspace) overrides the built-in launch shapes
         for part in filter(None, os.environ.get('ODTK_LOSS_TUNING', '').split(';')):
             side, _, vals = part.partition(':')
             side = side.strip()
-            _check(lib.odtk_debug_loss_tuning(int(side.startswith('bwd')), int(side.endswith('32')),
+            _check(lib.odtk_debug_loss_tuning({'fwd': 0, 'bwd': 1, 'ws': 2}[side[:-2]], int(side.endswith('32')),
                                               *(int(v) for v in vals.split(','))), 'ODTK_LOSS_TUNING')
     return _lib
 
@@ -476,15 +478,26 @@ def _loss_levels(cls_heads, box_heads, depths, box_targets, grads=None):
     return arr, n, geo
 
 
-def retina_loss_levels_forward(cls_heads, box_heads, depths, box_targets, alpha, gamma, beta):
-    """All pyramid levels in ONE launch -> float64 CUDA tensor [L, 3] = per level (cls_sum, box_sum, #foreground)."""
+def retina_loss_levels_forward(cls_heads, box_heads, depths, box_targets, alpha, gamma, beta, reproducible=False):
+    """All pyramid levels in ONE launch -> float64 CUDA tensor [L, 3] = per level (cls_sum, box_sum, #foreground).
+    reproducible=True: the workgroups' sums go through a workspace and a second, tiny launch adds them up in a fixed order
+    (odtk_retina_loss_levels_forward_ws): no atomics, the same bits on every run, the same speed (measured,
+    profiles/r03_loss_probe.txt) plus one launch."""
     arr, n, (b, a, c, nb, dtype) = _loss_levels(cls_heads, box_heads, depths, box_targets)
     dev = cls_heads[0].device
+    lib = library()
     with torch.cuda.device(dev):
         sums = torch.empty((n, 3), dtype=torch.float64, device=dev)
-        stream = torch.cuda.current_stream(dev).cuda_stream
-        _check(library().odtk_retina_loss_levels_forward(n, arr, b, a, c, nb, dtype, float(alpha), float(gamma), float(beta),
-                                                         sums.data_ptr(), stream), 'retina_loss_levels_forward')
+        if not reproducible:
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            _check(lib.odtk_retina_loss_levels_forward(n, arr, b, a, c, nb, dtype, float(alpha), float(gamma), float(beta),
+                                                       sums.data_ptr(), stream), 'retina_loss_levels_forward')
+            return sums
+        need = _check(lib.odtk_retina_loss_levels_forward_ws(n, arr, b, a, c, nb, dtype, float(alpha), float(gamma), float(beta),
+                                                             None, None, 0, None), 'retina_loss_levels_forward (workspace query)')
+        ws, stream = _workspace(dev, need)
+        _check(lib.odtk_retina_loss_levels_forward_ws(n, arr, b, a, c, nb, dtype, float(alpha), float(gamma), float(beta),
+                                                      sums.data_ptr(), ws.data_ptr(), ws.numel(), stream), 'retina_loss_levels_forward')
     return sums
 
 
@@ -650,10 +663,10 @@ def gemm_bias_act(x, weight, bias, residual=None, relu=True):
     return y
 
 
-def loss_tuning(backward, fp32_heads, threads, blocks_per_cu, unroll, box_blocks):
-    """Debug / tuning: launch shape of the loss kernels of one direction and head width (include/odtk_hip.h:
-    odtk_debug_loss_tuning)."""
-    _check(library().odtk_debug_loss_tuning(int(bool(backward)), int(bool(fp32_heads)), int(threads), int(blocks_per_cu),
+def loss_tuning(which, fp32_heads, threads, blocks_per_cu, unroll, box_blocks):
+    """Debug / tuning: launch shape of the loss kernels of one form (0 forward with atomics, 1 backward, 2 forward through a
+    workspace) and head width (include/odtk_hip.h: odtk_debug_loss_tuning)."""
+    _check(library().odtk_debug_loss_tuning(int(which), int(bool(fp32_heads)), int(threads), int(blocks_per_cu),
                                             int(unroll), int(box_blocks)), 'loss_tuning')
 
 

@@ -92,7 +92,10 @@ class _FusedPyramidLoss(torch.autograd.Function):
         from . import _C
         cls_heads, box_heads = tensors[:n], tensors[n:2 * n]
         depths, box_targets = tensors[2 * n:3 * n], tensors[3 * n:4 * n]
-        sums = _C.retina_loss_levels_forward(cls_heads, box_heads, depths, box_targets, alpha, gamma, beta).float()
+        # torch.use_deterministic_algorithms(True): the fixed-order reduction instead of double atomics (same speed, one
+        # more launch; csrc/loss.hpp:loss_reduce_kernel) -- the loss is then the same bits on every run
+        sums = _C.retina_loss_levels_forward(cls_heads, box_heads, depths, box_targets, alpha, gamma, beta,
+                                             reproducible=torch.are_deterministic_algorithms_enabled()).float()
         ctx.save_for_backward(*tensors)
         ctx.meta = (n, alpha, gamma, beta)
         cls_sums, box_sums, foreground = sums[:, 0].contiguous(), sums[:, 1].contiguous(), sums[:, 2].contiguous()

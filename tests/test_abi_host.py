@@ -162,12 +162,29 @@ def test_loss_tuning_hook_validates_without_a_gpu():
     until set back.  The built-in defaults are the ones tools/loss_probe.py measured (profiles/r03_loss_probe.txt)."""
     lib = _C.library()
     for bad in ((0, 1, 100, 1, 4, 64), (0, 1, 2048, 1, 4, 64), (0, 1, 512, 0, 4, 64), (0, 1, 512, 1, 3, 64),
-                (1, 0, 256, 4, 1, 0), (1, 0, 256, 65, 1, 256)):
+                (1, 0, 256, 4, 1, 0), (1, 0, 256, 65, 1, 256), (3, 0, 256, 4, 1, 256), (-1, 1, 256, 4, 1, 256)):
         assert lib.odtk_debug_loss_tuning(*bad) == _C.ERR_INVALID, bad
     for good in ((0, 0, 512, 1, 2, 64), (1, 0, 256, 4, 1, 256), (0, 1, 512, 1, 4, 64), (1, 1, 1024, 16, 2, 1024)):   # = the defaults
         assert lib.odtk_debug_loss_tuning(*good) == 0, good
     with pytest.raises(RuntimeError, match='invalid argument'):
         _C.loss_tuning(0, 1, 100, 1, 4, 64)
+
+
+def test_loss_forward_workspace_query_without_a_gpu():
+    """odtk_retina_loss_levels_forward_ws: NULL workspace -> bytes needed (3 doubles per workgroup of the launch, 256-B
+    aligned), a too-small workspace is reported before anything is launched."""
+    lib = _C.library()
+    levels = (_C.LossLevel * 2)()
+    for lv, (h, w) in zip(levels, ((100, 160), (7, 10))):
+        lv.cls = lv.box = lv.depth = lv.box_target = 1 << 20                   # never dereferenced on this path
+        lv.height, lv.width, lv.channels_last = h, w, 1
+    args = (2, levels, 2, 9, 80, 4, _C.F32, 0.25, 2.0, 0.11)
+    need = lib.odtk_retina_loss_levels_forward_ws(*args, None, None, 0, None)
+    assert need > 0 and need % 256 == 0 and need < (1 << 20)
+    buf = ctypes.create_string_buffer(256)
+    assert lib.odtk_retina_loss_levels_forward_ws(*args, 1 << 20, ctypes.cast(buf, ctypes.c_void_p), 16, None) == _C.ERR_WORKSPACE
+    assert lib.odtk_retina_loss_levels_forward_ws(0, levels, 2, 9, 80, 4, _C.F32, 0.25, 2.0, 0.11,
+                                                  None, None, 0, None) == _C.ERR_INVALID
 
 
 def test_fastdiv_is_exact(tmp_path):
