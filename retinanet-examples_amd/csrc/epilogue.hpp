@@ -17,6 +17,7 @@
 #pragma once
 
 #include "common.hpp"
+#include "fastdiv.hpp"
 #include "prefilter.hpp"   // element types, bf16/f16 conversions
 
 namespace odtk {
@@ -113,19 +114,35 @@ __global__ void bias_act_scalar_kernel(void *y, const float *bias, const void *r
 // One thread = one output pixel x kPer channels (16 bytes); consecutive threads walk the channels of a
 // pixel, then x: every load and store is a coalesced 16-byte access.  Padding never wins (torch pads
 // with -inf).  16-bit types only (the inference dtypes); channels % 8 == 0.
-template <typename T, bool kRelu>
+// k32 (every real size: fewer than 2^32 output vectors): the output index is split into (image, row, column, channel
+// group) by multiply-high (fastdiv.hpp).  Three 64-bit divisions by run-time divisors were ~360 of the ~700 vector
+// instructions per output vector of a kernel that the instruction count, not the stream, bounds (round 3).
+struct PoolDivisors {
+  FastDiv groups, wo, ho;
+};
+
+template <typename T, bool kRelu, bool k32>
 __global__ __launch_bounds__(256) void bias_act_maxpool_kernel(const uint16_t *__restrict__ y, const float *__restrict__ bias,
                                                                uint16_t *__restrict__ out, uint32_t batch, uint32_t h,
-                                                               uint32_t w, uint32_t c, uint32_t ho, uint32_t wo) {
+                                                               uint32_t w, uint32_t c, uint32_t ho, uint32_t wo,
+                                                               const PoolDivisors dv) {
   constexpr int kPer = T::kPerLoad;                        // 8
   const uint32_t groups = c / kPer;
   const uint64_t total = static_cast<uint64_t>(batch) * ho * wo * groups;
   for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < total; i += static_cast<uint64_t>(gridDim.x) * 256ull) {
-    const uint32_t g = static_cast<uint32_t>(i % groups);
-    uint64_t p = i / groups;
-    const uint32_t ox = static_cast<uint32_t>(p % wo);
-    p /= wo;
-    const uint32_t oy = static_cast<uint32_t>(p % ho), b = static_cast<uint32_t>(p / ho);
+    uint32_t g, ox, oy, b;
+    if constexpr (k32) {
+      uint32_t p = fastdivmod(static_cast<uint32_t>(i), dv.groups, &g);
+      p = fastdivmod(p, dv.wo, &ox);
+      b = fastdivmod(p, dv.ho, &oy);
+    } else {
+      g = static_cast<uint32_t>(i % groups);
+      uint64_t p = i / groups;
+      ox = static_cast<uint32_t>(p % wo);
+      p /= wo;
+      oy = static_cast<uint32_t>(p % ho);
+      b = static_cast<uint32_t>(p / ho);
+    }
     float m[kPer];
 #pragma unroll
     for (int e = 0; e < kPer; ++e) m[e] = -__builtin_inff();

@@ -916,12 +916,19 @@ int odtk_bias_act_maxpool(const void *y, const float *bias, void *out, int batch
   KernelTimer t(ODTK_KERNEL_EPILOGUE, s);
   const uint16_t *in = static_cast<const uint16_t *>(y);
   uint16_t *o = static_cast<uint16_t *>(out);
-#define ODTK_POOL(T, R)                                                                                               \
-  hipLaunchKernelGGL((odtk::bias_act_maxpool_kernel<T, R>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, in, \
+  odtk::PoolDivisors dv;
+  dv.groups = odtk::fastdiv_make(static_cast<uint32_t>(channels / 8));
+  dv.wo = odtk::fastdiv_make(wo);
+  dv.ho = odtk::fastdiv_make(ho);
+  const bool small = work < (1ull << 32);
+#define ODTK_POOL_(T, R, S)                                                                                             \
+  hipLaunchKernelGGL((odtk::bias_act_maxpool_kernel<T, R, S>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, in, \
                      bias, o, static_cast<uint32_t>(batch_size), static_cast<uint32_t>(height),                       \
-                     static_cast<uint32_t>(width), static_cast<uint32_t>(channels), ho, wo)
+                     static_cast<uint32_t>(width), static_cast<uint32_t>(channels), ho, wo, dv)
+#define ODTK_POOL(T, R) do { if (small) ODTK_POOL_(T, R, true); else ODTK_POOL_(T, R, false); } while (0)
   if (dtype == ODTK_BF16) { if (relu) ODTK_POOL(odtk::BF16, true); else ODTK_POOL(odtk::BF16, false); }
   else { if (relu) ODTK_POOL(odtk::F16, true); else ODTK_POOL(odtk::F16, false); }
+#undef ODTK_POOL_
 #undef ODTK_POOL
   ODTK_HIP_TRY(hipGetLastError());
   return ODTK_OK;
