@@ -84,8 +84,10 @@ __device__ __forceinline__ float focal_term(float x, bool positive, float w_neg,
   const float q = nonneg ? r : er;                                               // sigmoid(s)
   const float ce = fmaf(__builtin_amdgcn_logf(d), 0.6931471805599453f, fmaxf(s, 0.0f));   // softplus(s); 1 + e in (1, 2]
   const float w = positive ? w_pos : w_neg;
-  // q^gamma: q in [0, 1]; the general form is exp2(gamma log2 q) on the hardware units (log2 0 = -inf -> 0)
-  const float mod = kGamma2 ? q * q : __builtin_amdgcn_exp2f(gamma * __builtin_amdgcn_logf(q));
+  // q^gamma: q in [0, 1]; the general form is exp2(gamma log2 q) on the hardware units.  log2 0 = -inf is held at -150 so
+  // that gamma = 0 gives 0^0 = 1 as torch's pow does (0 * -inf would be NaN); 2^(-150 gamma) is 0 or, for small gamma, a
+  // factor that multiplies a cross entropy of exactly 0 (q == 0 means exp(-|s|) underflowed: s < -87)
+  const float mod = kGamma2 ? q * q : __builtin_amdgcn_exp2f(gamma * fmaxf(__builtin_amdgcn_logf(q), -150.0f));
   if constexpr (!kBackward) {
     return w * mod * ce;
   } else {

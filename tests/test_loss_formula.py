@@ -22,19 +22,20 @@ def focal_term(x, positive, w_neg, w_pos, gamma, backward):
     q = np.where(nonneg, r, er)
     ce = (np.log2(d).astype(f) * f(0.6931471805599453) + np.maximum(s, 0)).astype(f)   # v_log_f32, v_fma_f32
     w = np.where(positive, w_pos, w_neg).astype(f)
-    mod = (q * q).astype(f) if gamma == 2 else np.exp2((f(gamma) * np.log2(q).astype(f)).astype(f)).astype(f)
+    with np.errstate(divide='ignore'):
+        mod = (q * q).astype(f) if gamma == 2 else np.exp2((f(gamma) * np.maximum(np.log2(q).astype(f), f(-150))).astype(f)).astype(f)
     if not backward:
         return (w * mod * ce).astype(f)
     omq = np.where(nonneg, er, r)
     return (w * mod * ((f(2.0 if gamma == 2 else gamma) * omq) * ce + q)).astype(f)
 
 
-@pytest.mark.parametrize('gamma', [2.0, 1.5, 0.5])
+@pytest.mark.parametrize('gamma', [2.0, 1.5, 0.5, 0.0])
 def test_symmetric_focal_form_is_the_reference_expression(gamma):
     rng = np.random.default_rng(int(gamma * 10))
     n, alpha = 200000, 0.25
-    x = np.concatenate([(rng.standard_normal(n) * 3 - 2), [0.0, -0.0, 30.0, -30.0, 88.0, -88.0, 1e-8]]).astype(f)
-    positive = np.concatenate([rng.random(n) < 0.05, [False, True, True, False, False, True, True]])
+    x = np.concatenate([(rng.standard_normal(n) * 3 - 2), [0.0, -0.0, 30.0, -30.0, 88.0, -88.0, 1e-8, -120.0, 120.0]]).astype(f)   # |x| > 104: exp underflows to 0
+    positive = np.concatenate([rng.random(n) < 0.05, [False, True, True, False, False, True, True, False, True]])
     xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
     ref = L.FocalLoss(alpha, gamma)(xt, torch.tensor(positive, dtype=torch.float64))
     ref.sum().backward()
@@ -44,4 +45,9 @@ def test_symmetric_focal_form_is_the_reference_expression(gamma):
     assert np.isfinite(got).all() and np.isfinite(got_grad).all()
     assert abs(got.astype(np.float64).sum() - want.sum()) <= 1e-7 * want.sum()                   # the kernel's bar: 1e-6
     assert np.abs(got - want).max() <= 2e-7 * want.max()                                          # elementwise, absolute
-    assert np.abs(got_grad - grad).max() <= 2e-6 * np.abs(grad).max()                             # the kernel's bar: 1e-5
+    # gamma < 1: autograd of `(1 - pt) ** gamma` at 1 - pt == 0 is inf * 0 = NaN in the reference itself (float64: |x| > ~37,
+    # float32: ~17); the symmetric form has no such singularity and returns the limit, 0
+    ok = np.isfinite(grad)
+    assert ok.all() or gamma < 1
+    assert np.abs(got_grad - grad)[ok].max() <= 2e-6 * np.abs(grad[ok]).max()                     # the kernel's bar: 1e-5
+    assert np.all(got_grad[~ok] == 0)
