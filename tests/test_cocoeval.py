@@ -227,3 +227,31 @@ def test_segm_on_the_rotated_annotation_fixture():
     assert run(dets(1.0))[0] == pytest.approx(1.0, abs=1e-12)
     assert any(len(a['bbox']) == 5 and abs(a['bbox'][4]) > 0.3 for a in gt)
     assert run(dets(-1.0))[0] < 0.9
+
+
+def test_polygon_iou_against_pixel_counting():
+    """The docstring's claim: the exact polygon IoU and an IoU counted on rasterised masks (what pycocotools does; here pixel
+    centres inside the polygon) differ by boundary pixels only -- under 0.03 for boxes of a few hundred pixels and more."""
+    rng = np.random.default_rng(4)
+    ys, xs = np.mgrid[0:160, 0:160]
+    px, py = xs.ravel() + 0.5, ys.ravel() + 0.5
+
+    def mask(seg):
+        pts = np.asarray(seg[0]).reshape(-1, 2)
+        inside = np.ones(px.shape, bool)
+        sign = np.sign(np.sum(pts[:, 0] * np.roll(pts[:, 1], -1) - np.roll(pts[:, 0], -1) * pts[:, 1]))
+        for (ax, ay), (bx, by) in zip(pts, np.roll(pts, -1, axis=0)):
+            inside &= sign * ((bx - ax) * (py - ay) - (by - ay) * (px - ax)) >= 0
+        return inside
+    worst, compared = 0.0, 0
+    for _ in range(60):
+        x, y = rng.random(2) * 60 + 30
+        w, h = rng.random(2) * 50 + 20
+        a = _quad(x, y, w, h, rng.uniform(-1.5, 1.5))
+        b = _quad(x + rng.uniform(-12, 12), y + rng.uniform(-12, 12), w * rng.uniform(0.7, 1.3), h * rng.uniform(0.7, 1.3), rng.uniform(-1.5, 1.5))
+        exact = polygon_iou([{'id': 1, 'segmentation': a}], [{'id': 2, 'segmentation': b}], [False])[0, 0]
+        ma, mb = mask(a), mask(b)
+        counted = (ma & mb).sum() / max((ma | mb).sum(), 1)
+        worst = max(worst, abs(exact - counted))
+        compared += exact > 0.2
+    assert worst < 0.03 and compared > 30, (worst, compared)
