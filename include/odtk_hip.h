@@ -17,7 +17,8 @@
  *     (> 0); call again with a buffer of at least that size -> returns ODTK_OK (0).
  *   - errors are negative return values (the reference never checked a CUDA error and threw
  *     std::runtime_error("Workspace is too small!") across the boundary, utils.h:55-57).
- *   - the workspace is scratch: contents before the call are irrelevant, a call may not
+ *   - the workspace is scratch: contents before the call are irrelevant (nothing is cleared by a launch of
+ *     its own: the first kernel of a call writes every word the second reads), a call may not
  *     share its workspace with another call that is in flight on a different stream.
  *   - outputs are fully written (zero padded tails); they need not be pre-zeroed.
  *
@@ -145,8 +146,8 @@ typedef struct odtk_level {
 } odtk_level_t;
 
 /*
- * odtk_decode_levels -- ALL pyramid levels x whole batch in one enqueue (2 kernel launches,
- * no host synchronisation; the reference needs >= 5 launches + 1 host sync per image per
+ * odtk_decode_levels -- ALL pyramid levels x whole batch in one enqueue (2 kernel launches: prefilter,
+ * select + decode; no host synchronisation; the reference needs >= 5 launches + 1 host sync per image per
  * level, decode.cu:86-168).  Outputs are written directly in the concatenated layout that
  * `torch.cat(per_level, 1)` produces in the reference (odtk/model.py:164):
  *   outputs[0] scores  float32 [batch, n_levels*top_n]
@@ -330,8 +331,8 @@ int odtk_retina_loss_levels_backward(int n_levels, const odtk_loss_level_t *leve
 #define ODTK_KERNEL_TARGETS   5   /* snap_to_anchors_kernel                        */
 #define ODTK_KERNEL_GEMM      6   /* hipBLASLt kernels behind odtk_gemm_bias_act    */
 #define ODTK_KERNEL_LOSS      7   /* retina_loss_kernel (forward and backward)      */
-#define ODTK_KERNEL_SELHIST   8   /* select_hist_kernel (both histogram passes)     */
-#define ODTK_KERNEL_SELFILTER 9   /* select_filter_kernel                           */
+#define ODTK_KERNEL_SELHIST   8   /* (rounds 2-3: the selection's histogram launch; no longer launched, id kept) */
+#define ODTK_KERNEL_SELFILTER 9   /* (rounds 2-3: the selection's filter launch; no longer launched, id kept)    */
 #define ODTK_KERNEL_NMS_ORDER 10  /* nms_kernel, stage 1 (rotated: the first round in order)   */
 #define ODTK_KERNEL_NMS_MATRIX 11 /* rotated_sup_matrix_kernel (rotated: pairwise suppression) */
 #define ODTK_KERNEL_COUNT     12
@@ -340,7 +341,7 @@ int odtk_retina_loss_levels_backward(int n_levels, const odtk_loss_level_t *leve
  * measurably NOT free for the ~110 epilogue launches (about 10 % of an 8.7 ms step), so time those
  * only in a separate pass. */
 int odtk_profile_enable(int on);
-/* Debug: device buffer (>= 16 KiB) that select_decode / nms workgroups stamp with wall_clock64()
+/* Debug: device buffer (>= 64 KiB, zero-filled) that select_decode / nms workgroups stamp with wall_clock64()
  * (100 MHz) at their phase boundaries; NULL (default) disables.  Not for production use. */
 int odtk_debug_set_trace(void *device_buffer);
 /* Debug / tuning: launch shape of the loss kernels for one form (which = 0: forward with atomics, 1: backward, 2: forward

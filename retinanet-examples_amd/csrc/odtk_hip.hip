@@ -117,65 +117,62 @@ int allow_dynamic_lds(const void *kernel, size_t bytes, const char *what) {
 constexpr size_t kAlign = 256;
 inline size_t align_up(size_t v) { return (v + kAlign - 1) / kAlign * kAlign; }
 
-// per-segment candidate capacity: min(scores per image, ODTK_CAND_CAP (default 2^20 keys = 8 MiB))
-uint32_t cand_cap_limit() {
-  static const uint32_t v = [] {
-    const char *e = std::getenv("ODTK_CAND_CAP");
-    long long x = e ? std::atoll(e) : (1ll << 20);
-    if (x < ODTK_MAX_TOP_N) x = ODTK_MAX_TOP_N;      // the radix-select path needs cap >= top_n
-    if (x > (1ll << 28)) x = 1ll << 28;
-    return static_cast<uint32_t>(x);
-  }();
-  return v;
-}
-
-// ODTK_SELECT_MULTI=0 switches the multi-workgroup selection passes off (A/B measurements): select_decode then walks
-// the candidate lists alone, as in round 1.
-bool multi_pass_enabled() {
-  static const bool on = [] { const char *e = std::getenv("ODTK_SELECT_MULTI"); return !(e && e[0] == '0'); }();
-  return on;
-}
-
 struct DecodeLayout {
-  size_t counts_off, sel_off, zero_bytes, cand_off[ODTK_MAX_LEVELS], surv_off, total;
-  uint32_t cap[ODTK_MAX_LEVELS], n[ODTK_MAX_LEVELS];
+  size_t sel_off, counts_off, key_off[ODTK_MAX_LEVELS], surv_off[ODTK_MAX_LEVELS], total;
+  uint32_t cnt_off[ODTK_MAX_LEVELS], n[ODTK_MAX_LEVELS], spans[ODTK_MAX_LEVELS], parts[ODTK_MAX_LEVELS];
+  uint32_t span_tiles, span_elems, budget;
 };
 static_assert(sizeof(odtk::DecodeArgs) <= 4096 && sizeof(odtk::ScanArgs) <= 4096, "kernel arguments travel by value");
 
 // top_n <= 4096: the standard select_decode (32 KiB static sort buffer); beyond: the variant with 128 KiB of dynamic LDS
 uint32_t sort_cap_for(int top_n) { return top_n <= odtk::kSortCap ? odtk::kSortCap : odtk::kSortCapBig; }
-uint32_t surv_cap_for(int top_n) { return top_n <= odtk::kSortCap ? odtk::kSurvCap : 4 * odtk::kSurvCap; }
 
-int decode_layout(int batch, int n_levels, const odtk_level_t *levels, int A, int C, int top_n, DecodeLayout *out) {
+// Order of the prefilter's workgroups inside a level: consecutive workgroups take the same span of DIFFERENT images (the
+// launch sweeps `batch` fronts through memory at once; measured 41.1 vs 42.0 us back to back, 48.1 vs 49.0 us in the step),
+// ODTK_SCAN_ORDER=1: one image after the other (A/B measurements; the result does not depend on it)
+int scan_image_major() {
+  static const int v = [] { const char *e = std::getenv("ODTK_SCAN_ORDER"); return (e && e[0] == '1') ? 1 : 0; }();
+  return v;
+}
+
+// Workspace of a decode call: [segment state | sub-list lengths | candidate pool: kSpanCap keys per span | survivor lists].
+// A span = 1 (fp32) or 2 (16-bit) tiles of 16 384 scores of ONE image; its four prefilter waves own kWaveStage keys each, so
+// no list can overflow into another and nothing is reserved at run time.  A wave with more raw hits than that marks its
+// list kListOverflow and select_decode re-reads the span's raw scores: capacity is a speed knob, never a result.
+int decode_layout(int batch, int n_levels, const odtk_level_t *levels, int A, int C, int top_n, int dtype, DecodeLayout *out) {
   size_t off = 0;
-  out->counts_off = off;
-  off += align_up(sizeof(uint32_t) * static_cast<size_t>(batch) * n_levels * odtk::kSubLists);
-  // per-segment state of the multi-workgroup selection passes, right behind the counters: ONE memset clears both
   out->sel_off = off;
   off += align_up(sizeof(odtk::SelSeg) * static_cast<size_t>(batch) * n_levels);
-  out->zero_bytes = off;
+  out->span_tiles = dtype == ODTK_F32 ? 1u : static_cast<uint32_t>(odtk::kMaxSpanTiles);
+  out->span_elems = out->span_tiles * odtk::kTile;
+  out->budget = sort_cap_for(top_n);                       // keys a workgroup of the tournament route passes on: one sort buffer
+  size_t lists = 0;
   for (int l = 0; l < n_levels; ++l) {
     const unsigned long long n = 1ull * A * C * levels[l].height * levels[l].width;
     if (n == 0 || n > 0x7fff0000ull) return ODTK_ERR_INVALID;
     out->n[l] = static_cast<uint32_t>(n);
-    // Per sub-list capacity.  An image's spans are consecutive and rotate over the kSubLists sub-lists,
-    // so one sub-list receives at most ceil(spans / kSubLists) spans' worth of that image's scores:
-    // with that capacity no sub-list overflows, whatever the density.  (Sized for the longest span;
-    // the fp32 form's one-tile spans need no more.)  Levels with more than ODTK_CAND_CAP scores per
-    // image get ODTK_CAND_CAP / kSubLists instead; if an input overflows a sub-list, select_decode
-    // falls back to scanning that segment's raw scores, so capacity is a speed knob, never a result.
-    const unsigned long long span_elems = static_cast<unsigned long long>(odtk::kTile) * odtk::kMaxSpanTiles;
-    const unsigned long long spans = (n + span_elems - 1) / span_elems + 1;          // +1: unaligned start
-    unsigned long long sub = (spans + odtk::kSubLists - 1) / odtk::kSubLists * span_elems;
-    if (sub > n) sub = n;
-    const unsigned long long limited = (cand_cap_limit() + odtk::kSubLists - 1) / odtk::kSubLists;
-    if (n > cand_cap_limit() && sub > limited) sub = limited;
-    out->cap[l] = static_cast<uint32_t>((sub + 31) / 32 * 32);
-    out->cand_off[l] = off;
-    off += align_up(sizeof(uint64_t) * static_cast<size_t>(batch) * odtk::kSubLists * out->cap[l]);
+    out->spans[l] = static_cast<uint32_t>((n + out->span_elems - 1) / out->span_elems);
+    // workgroups select_decode provides per segment: one per kSpansPerPart spans (they leave at once unless the segment
+    // holds more than kKeysPerPart candidates each), and enough of them for a slice's sub-list lengths to fit in LDS
+    uint32_t parts = (out->spans[l] + odtk::kSpansPerPart - 1) / odtk::kSpansPerPart;
+    if (parts > odtk::kMaxParts) parts = odtk::kMaxParts;
+    const uint32_t fit = (out->spans[l] * odtk::kScanWaves + odtk::kCntSlots - 1) / odtk::kCntSlots;
+    if (parts < fit) parts = fit;
+    out->parts[l] = parts < 1 ? 1 : parts;
+    if (lists + static_cast<size_t>(batch) * out->spans[l] * odtk::kScanWaves > 0xffffffffull) return ODTK_ERR_INVALID;
+    out->cnt_off[l] = static_cast<uint32_t>(lists);
+    lists += static_cast<size_t>(batch) * out->spans[l] * odtk::kScanWaves;
   }
-  out->surv_off = off;
-  off += align_up(sizeof(uint64_t) * static_cast<size_t>(batch) * n_levels * surv_cap_for(top_n));
+  out->counts_off = off;
+  off += align_up(sizeof(uint32_t) * lists);
+  for (int l = 0; l < n_levels; ++l) {
+    out->key_off[l] = off;
+    off += align_up(sizeof(uint64_t) * static_cast<size_t>(batch) * out->spans[l] * odtk::kSpanCap);
+  }
+  for (int l = 0; l < n_levels; ++l) {
+    out->surv_off[l] = off;
+    off += align_up(sizeof(uint64_t) * static_cast<size_t>(batch) * out->parts[l] * out->budget);
+  }
   out->total = off;
   return ODTK_OK;
 }
@@ -192,35 +189,30 @@ float logit_lower_bound(float thresh) {
 }
 
 template <typename T, bool kLogits>
-int launch_decode(bool rotated, uint32_t tiles, int n_seg, size_t scan_lds, const odtk::ScanArgs &sa,
-                  const odtk::DecodeArgs &da, hipStream_t stream) {
-  timed_launch(ODTK_KERNEL_PREFILTER, odtk::prefilter_scan_kernel<T, kLogits>, dim3(tiles), dim3(odtk::kScanThreads), scan_lds, stream, sa);
+int launch_decode(bool rotated, bool aligned, uint32_t scan_blocks, uint32_t sel_blocks, uint32_t sort_cap, size_t scan_lds,
+                  const odtk::ScanArgs &sa, const odtk::DecodeArgs &da, hipStream_t stream) {
+  if (aligned)
+    timed_launch(ODTK_KERNEL_PREFILTER, odtk::prefilter_scan_kernel<T, kLogits, true>, dim3(scan_blocks), dim3(odtk::kScanThreads), scan_lds, stream, sa);
+  else
+    timed_launch(ODTK_KERNEL_PREFILTER, odtk::prefilter_scan_kernel<T, kLogits, false>, dim3(scan_blocks), dim3(odtk::kScanThreads), scan_lds, stream, sa);
   ODTK_HIP_TRY(hipGetLastError());
-  // multi-workgroup narrowing of the segments that hold more candidates than one LDS sort (select_decode.hpp):
-  // histogram, then filter (with a second histogram digit inside the same launch where saturated scores need one).
-  // Segments below that size leave at the first instruction.
-  const uint32_t pass_blocks = da.part_begin[da.n_levels];
-  if (pass_blocks && da.sel) {
-    timed_launch(ODTK_KERNEL_SELHIST, odtk::select_pass_kernel<T, kLogits, 0>, dim3(pass_blocks), dim3(odtk::kPassThreads), 0, stream, da);
-    timed_launch(ODTK_KERNEL_SELFILTER, odtk::select_pass_kernel<T, kLogits, 1>, dim3(pass_blocks), dim3(odtk::kPassThreads), 0, stream, da);
-    ODTK_HIP_TRY(hipGetLastError());
-  }
-  if (da.sort_cap > static_cast<uint32_t>(odtk::kSortCap)) {
-    // top_n > 4096 (the reference has no cap): the sort buffer moves to 128 KiB of dynamic LDS
-    constexpr size_t big_lds = sizeof(uint64_t) * odtk::kSortCapBig;
-    const void *big = rotated ? reinterpret_cast<const void *>(&odtk::select_decode_kernel<6, T, kLogits, odtk::kSortCapBig>)
-                              : reinterpret_cast<const void *>(&odtk::select_decode_kernel<4, T, kLogits, odtk::kSortCapBig>);
-    const int rc = allow_dynamic_lds(big, big_lds, "hipFuncSetAttribute(select_decode_kernel)");
-    if (rc != ODTK_OK) return rc;
-    if (rotated)
-      timed_launch(ODTK_KERNEL_SELECT, odtk::select_decode_kernel<6, T, kLogits, odtk::kSortCapBig>, dim3(n_seg), dim3(odtk::kSelThreads), big_lds, stream, da);
-    else
-      timed_launch(ODTK_KERNEL_SELECT, odtk::select_decode_kernel<4, T, kLogits, odtk::kSortCapBig>, dim3(n_seg), dim3(odtk::kSelThreads), big_lds, stream, da);
-  } else if (rotated) {
-    timed_launch(ODTK_KERNEL_SELECT, odtk::select_decode_kernel<6, T, kLogits>, dim3(n_seg), dim3(odtk::kSelThreads), 0, stream, da);
+  // select_decode's LDS (sort buffer, sub-histograms, sub-list lengths) is one dynamic allocation above the 64 KiB a kernel
+  // gets by default: every variant opts in, once per device.  top_n > 4096 (the reference has no cap): the variant with a
+  // 128 KiB sort buffer.
+#define ODTK_SELECT_LAUNCH(NB_, CAP_)                                                                                          \
+  do {                                                                                                                         \
+    const int rc_ = allow_dynamic_lds(reinterpret_cast<const void *>(&odtk::select_decode_kernel<NB_, T, kLogits, CAP_>),       \
+                                      odtk::SelLds<CAP_>::total, "hipFuncSetAttribute(select_decode_kernel)");                 \
+    if (rc_ != ODTK_OK) return rc_;                                                                                            \
+    timed_launch(ODTK_KERNEL_SELECT, odtk::select_decode_kernel<NB_, T, kLogits, CAP_>, dim3(sel_blocks), dim3(odtk::kSelThreads), \
+                 odtk::SelLds<CAP_>::total, stream, da);                                                                       \
+  } while (0)
+  if (sort_cap > static_cast<uint32_t>(odtk::kSortCap)) {
+    if (rotated) ODTK_SELECT_LAUNCH(6, odtk::kSortCapBig); else ODTK_SELECT_LAUNCH(4, odtk::kSortCapBig);
   } else {
-    timed_launch(ODTK_KERNEL_SELECT, odtk::select_decode_kernel<4, T, kLogits>, dim3(n_seg), dim3(odtk::kSelThreads), 0, stream, da);
+    if (rotated) ODTK_SELECT_LAUNCH(6, odtk::kSortCap); else ODTK_SELECT_LAUNCH(4, odtk::kSortCap);
   }
+#undef ODTK_SELECT_LAUNCH
   ODTK_HIP_TRY(hipGetLastError());
   return ODTK_OK;
 }
@@ -233,19 +225,19 @@ int decode_levels_impl(int batch, int n_levels, const odtk_level_t *levels, int 
   for (int l = 0; l < n_levels; ++l)
     if (levels[l].height <= 0 || levels[l].width <= 0) return ODTK_ERR_INVALID;
   if (dtype != ODTK_F32 && dtype != ODTK_BF16 && dtype != ODTK_F16) return ODTK_ERR_UNSUPPORTED;
-  size_t scan_lds = 0;                                     // per-channel threshold table of the prefilter
+  size_t scan_lds = 0;                                     // per-channel threshold table of the prefilter (floats)
   for (int l = 0; l < n_levels; ++l) {
     if (levels[l].channels_last != 0 && levels[l].channels_last != 1) return ODTK_ERR_INVALID;
     if (levels[l].cls_bias) {
       if (dtype == ODTK_F32 || !(flags & ODTK_FLAG_LOGITS) || !levels[l].channels_last || (A * C) % 8 != 0)
         return ODTK_ERR_UNSUPPORTED;
-      scan_lds = align_up(static_cast<size_t>(A) * C * 2);
+      scan_lds = align_up(static_cast<size_t>(A) * C * sizeof(float));
       if (scan_lds > 48 * 1024) return ODTK_ERR_UNSUPPORTED;
     }
   }
 
   DecodeLayout lay;
-  int rc = decode_layout(batch, n_levels, levels, A, C, top_n, &lay);
+  int rc = decode_layout(batch, n_levels, levels, A, C, top_n, dtype, &lay);
   if (rc != ODTK_OK) return rc;
   if (!workspace || !workspace_size) {
     if (lay.total > 0x7fffffffull) return ODTK_ERR_INVALID;   // the int return cannot carry it
@@ -259,39 +251,37 @@ int decode_levels_impl(int batch, int n_levels, const odtk_level_t *levels, int 
   }
 
   char *ws = static_cast<char *>(workspace);
-  uint32_t *counts = reinterpret_cast<uint32_t *>(ws + lay.counts_off);
-  uint64_t *cand = reinterpret_cast<uint64_t *>(ws);   // cand_off are byte offsets from ws; converted below
-
   odtk::ScanArgs sa;
   std::memset(&sa, 0, sizeof sa);
   odtk::DecodeArgs da;
   std::memset(&da, 0, sizeof da);
-  uint32_t tiles = 0;
-  const uint32_t span = dtype == ODTK_F32 ? 1u : static_cast<uint32_t>(odtk::kMaxSpanTiles);
-  sa.span = static_cast<int>(span);
+  const uint32_t per_load = dtype == ODTK_F32 ? 4u : 8u;
+  bool aligned = true;                                     // every image of every level starts on a 16-byte boundary
+  uint32_t scan_blocks = 0;
   for (int l = 0; l < n_levels; ++l) {
-    const uint64_t total = static_cast<uint64_t>(batch) * lay.n[l];
+    if (lay.n[l] % per_load) aligned = false;
     sa.lv[l].cls = levels[l].cls;
-    sa.lv[l].total = total;
-    sa.lv[l].cand_off = lay.cand_off[l] / sizeof(uint64_t);
+    sa.lv[l].key_off = (lay.key_off[l] - lay.key_off[0]) / sizeof(uint64_t);
+    sa.lv[l].cnt_off = lay.cnt_off[l];
     sa.lv[l].n = lay.n[l];
-    sa.lv[l].tile_begin = tiles;
+    sa.lv[l].blk_begin = scan_blocks;
+    sa.lv[l].spans = lay.spans[l];
     sa.lv[l].seg_base = static_cast<uint32_t>(l) * batch;
-    sa.lv[l].cap = lay.cap[l];
     sa.lv[l].channels = static_cast<uint32_t>(A) * C;
     sa.lv[l].hw = static_cast<uint32_t>(levels[l].height) * levels[l].width;
     sa.lv[l].channels_last = static_cast<uint32_t>(levels[l].channels_last);
+    sa.lv[l].by_channels = odtk::fastdiv_make(static_cast<uint32_t>(A) * C);
     sa.lv[l].bias = levels[l].cls_bias;
-    sa.lv[l].tiles = static_cast<uint32_t>((total + odtk::kTile - 1) / odtk::kTile);
-    sa.lv[l].chunk = (sa.lv[l].tiles + batch - 1) / batch;
-    sa.lv[l].chunk = (sa.lv[l].chunk + span - 1) / span * span;
-    tiles += sa.lv[l].chunk / span * batch;                // launched workgroups (a few idle ones per level)
+    if (static_cast<unsigned long long>(scan_blocks) + 1ull * batch * lay.spans[l] > 0x7fffffffull) return ODTK_ERR_INVALID;
+    scan_blocks += static_cast<uint32_t>(batch) * lay.spans[l];
 
     da.lv[l].cls = levels[l].cls;
     da.lv[l].box = levels[l].box;
-    da.lv[l].cand_off = sa.lv[l].cand_off;
+    da.lv[l].key_off = sa.lv[l].key_off;
+    da.lv[l].surv_off = (lay.surv_off[l] - lay.surv_off[0]) / sizeof(uint64_t);
+    da.lv[l].cnt_off = lay.cnt_off[l];
     da.lv[l].n = lay.n[l];
-    da.lv[l].cap = lay.cap[l];
+    da.lv[l].spans = lay.spans[l];
     da.lv[l].height = levels[l].height;
     da.lv[l].width = levels[l].width;
     da.lv[l].stride = static_cast<float>(levels[l].stride);
@@ -299,31 +289,30 @@ int decode_levels_impl(int batch, int n_levels, const odtk_level_t *levels, int 
     da.lv[l].cls_bias = levels[l].cls_bias;
     da.lv[l].box_bias = levels[l].box_bias;
     std::memcpy(da.lv[l].anchors, levels[l].anchors, sizeof(float) * 4 * A);
-    // workgroups per segment of the selection passes: one per 2^17 scores of the level, none where a single sort
-    // always suffices
-    uint32_t sort_size = odtk::kSelThreads;
-    while (sort_size < static_cast<uint32_t>(top_n)) sort_size <<= 1;
-    uint32_t parts = lay.n[l] <= sort_size ? 0u : (lay.n[l] + (1u << 17) - 1) >> 17;
-    if (parts > static_cast<uint32_t>(odtk::kSelParts)) parts = odtk::kSelParts;
-    if (!multi_pass_enabled()) parts = 0;
-    da.parts[l] = parts;
+    da.parts[l] = lay.parts[l];
     da.part_begin[l] = l == 0 ? 0u : da.part_begin[l - 1] + da.parts[l - 1] * static_cast<uint32_t>(batch);
   }
   da.part_begin[n_levels] = da.part_begin[n_levels - 1] + da.parts[n_levels - 1] * static_cast<uint32_t>(batch);
   for (int l = n_levels + 1; l <= ODTK_MAX_LEVELS; ++l) da.part_begin[l] = da.part_begin[n_levels];
-  da.sel = reinterpret_cast<odtk::SelSeg *>(ws + lay.sel_off);
-  da.surv = reinterpret_cast<uint64_t *>(ws + lay.surv_off);
-  da.sort_cap = sort_cap_for(top_n);
-  da.surv_cap = surv_cap_for(top_n);
-  sa.counts = counts;
-  sa.cand = cand;
+  sa.counts = reinterpret_cast<uint32_t *>(ws + lay.counts_off);
+  sa.cand = reinterpret_cast<uint64_t *>(ws + lay.key_off[0]);
+  sa.sel = reinterpret_cast<odtk::SelSeg *>(ws + lay.sel_off);
   sa.n_levels = n_levels;
   sa.batch = batch;
+  sa.span = static_cast<int>(lay.span_tiles);
+  sa.image_major = scan_image_major();
   sa.thresh = thresh;
   sa.raw_lo = logit_lower_bound(thresh);
 
-  da.counts = counts;
-  da.cand = cand;
+  da.sel = sa.sel;
+  da.surv = reinterpret_cast<uint64_t *>(ws + lay.surv_off[0]);
+  da.counts = sa.counts;
+  da.cand = sa.cand;
+  da.budget = lay.budget;
+  da.span_elems = lay.span_elems;
+  da.aligned = aligned ? 1u : 0u;
+  da.raw_lo = sa.raw_lo;
+  da.by_channels = odtk::fastdiv_make(static_cast<uint32_t>(A) * C);
   da.out_scores = static_cast<float *>(outputs[0]);
   da.out_boxes = static_cast<float *>(outputs[1]);
   da.out_classes = static_cast<float *>(outputs[2]);
@@ -337,26 +326,19 @@ int decode_levels_impl(int batch, int n_levels, const odtk_level_t *levels, int 
   da.thresh = thresh;
   da.trace = g_trace;
 
-  const int n_seg = batch * n_levels;
-  // counters + selection state start at zero.  A kernel of our own, not hipMemsetAsync: a memset NODE inside a hipGraph
-  // was the cause of round 2's "capture -> destroy -> capture again -> GPU memory fault" (tools/graph_bisect.py: graphs of
-  // kernel nodes only -- nms -- survive three capture / destroy rounds, any graph holding this memset faulted on a replay
-  // that followed an eager memset of the same size); a plain kernel node has no such history, and costs the same launch.
-  {
-    const size_t words = (lay.zero_bytes - lay.counts_off) / sizeof(uint4);                 // both ends are 256-byte aligned
-    const unsigned blocks = static_cast<unsigned>((words + 255) / 256 < 1024 ? (words + 255) / 256 : 1024);
-    hipLaunchKernelGGL(odtk::clear_kernel, dim3(blocks), dim3(256), 0, stream, reinterpret_cast<uint4 *>(ws + lay.counts_off), words);
-    ODTK_HIP_TRY(hipGetLastError());
-  }
+  // Two launches, nothing to clear in front of them: the prefilter writes every sub-list length and zeroes the segment
+  // state select_decode's tournament route counts in (rounds 1-3 cleared counters and histograms with a launch of their own).
+  const uint32_t sel_blocks = da.part_begin[n_levels];
+  const uint32_t sort_cap = sort_cap_for(top_n);
   const bool rotated = (flags & ODTK_FLAG_ROTATED) != 0, logits = (flags & ODTK_FLAG_LOGITS) != 0;
   if (dtype == ODTK_F32)
-    return logits ? launch_decode<odtk::F32, true>(rotated, tiles, n_seg, scan_lds, sa, da, stream)
-                  : launch_decode<odtk::F32, false>(rotated, tiles, n_seg, scan_lds, sa, da, stream);
+    return logits ? launch_decode<odtk::F32, true>(rotated, aligned, scan_blocks, sel_blocks, sort_cap, scan_lds, sa, da, stream)
+                  : launch_decode<odtk::F32, false>(rotated, aligned, scan_blocks, sel_blocks, sort_cap, scan_lds, sa, da, stream);
   if (dtype == ODTK_BF16)
-    return logits ? launch_decode<odtk::BF16, true>(rotated, tiles, n_seg, scan_lds, sa, da, stream)
-                  : launch_decode<odtk::BF16, false>(rotated, tiles, n_seg, scan_lds, sa, da, stream);
-  return logits ? launch_decode<odtk::F16, true>(rotated, tiles, n_seg, scan_lds, sa, da, stream)
-                : launch_decode<odtk::F16, false>(rotated, tiles, n_seg, scan_lds, sa, da, stream);
+    return logits ? launch_decode<odtk::BF16, true>(rotated, aligned, scan_blocks, sel_blocks, sort_cap, scan_lds, sa, da, stream)
+                  : launch_decode<odtk::BF16, false>(rotated, aligned, scan_blocks, sel_blocks, sort_cap, scan_lds, sa, da, stream);
+  return logits ? launch_decode<odtk::F16, true>(rotated, aligned, scan_blocks, sel_blocks, sort_cap, scan_lds, sa, da, stream)
+                : launch_decode<odtk::F16, false>(rotated, aligned, scan_blocks, sel_blocks, sort_cap, scan_lds, sa, da, stream);
 }
 
 template <int NB, bool kGlobalKeys, int kStage = 0>

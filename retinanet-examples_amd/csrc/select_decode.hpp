@@ -1,28 +1,30 @@
-// select_decode.hpp -- kernel 2 of the decode path: one 1024-thread workgroup per
-// (level, image) segment picks the top_n candidates (score desc, flat index asc), sorts them
-// in LDS and decodes their boxes.
+// select_decode.hpp -- kernel 2 of the decode path: per (level, image) segment, pick the top_n candidates
+// (score desc, flat index asc) out of the prefilter's per-wave candidate sub-lists, sort them in LDS and decode
+// their boxes.  ONE launch (round 4; rounds 2-3 ran a histogram launch and a filter launch in front of it).
 //
 // Replaces reference steps D4-D6 (csrc/cuda/decode.cu:108-167: gather + cub radix sort of all
 // survivors, the box-decode device lambda, the tail fills) for all images and levels at once.
 // Box arithmetic follows odtk/box.py:97-111 + :302 operation by operation (CPU path is
 // normative: two-sided clamp).
 //
-// Selection is exact for ANY input:
-//   K > sort size           : MULTI-WORKGROUP narrowing first (select_pass_kernel, two launches in front of this
-//                             kernel): a histogram pass over 2048 equal bins of the key range, then a filter pass (with a
-//                             second histogram digit inside the same launch when saturated scores need one), each walked
-//                             by up to kSelParts workgroups per segment, leave the <= ~top_n keys at or above the
-//                             boundary bin in a small survivor list; this kernel then only sorts.  (One workgroup
-//                             walking 1e5..1e7 keys three times was the whole cost of this kernel.)
-//   K <= kSortCap           : all candidates are sorted (bitonic network in LDS).
-//   kSortCap < K <= cap     : MSD radix descent (11-bit digits, LDS histograms) on the 64-bit
-//                             keys of the candidate lists narrows down the bin of the top_n-th
-//                             key until "everything >= that bin" fits the LDS sort buffer
-//                             (usually 2 passes); those keys are gathered and sorted.
-//   K > cap (list overflow) : the same radix-select runs over the segment's RAW scores
-//                             (keys rebuilt on the fly), so correctness never depends on cap.
-// Keys are unique (they embed the index), so "keys >= T" is exactly top_n elements even when
-// every score is equal.
+// Selection is exact for ANY input and needs no state prepared by another launch:
+//   * every workgroup of a segment adds up the segment's sub-list lengths (one coalesced read) and derives the SAME
+//     number G of workgroups that take part: 1 up to kKeysPerPart candidates -- the normal case; the other workgroups
+//     the host provided leave at once --, more for dense inputs or when a sub-list overflowed (kListOverflow: that
+//     span is re-read from the raw scores, keys rebuilt on the fly, so list capacity never decides a result).
+//   * G == 1: the workgroup walks all sub-lists (16 lanes per sub-list, 4 sub-lists = one span per wave instruction,
+//     8 independent loads in flight per lane).  <= LDS sort capacity: everything is gathered and sorted.  More: a
+//     threshold T with top_n <= #{key >= T} <= capacity comes from histogram passes over 2048 EQUAL bins of the
+//     current key range (select_threshold; normally one pass: fp32 scores of one image share their exponent bits, a
+//     linear digit over [key(thresh), key(1.0)] separates what an 11-bit MSD digit cannot; the range is clipped to
+//     [min key, max key] between passes, so saturated scores go straight to the index bits), then one gather pass.
+//   * G > 1 (tournament): workgroup g walks the spans s = g (mod G), keeps its LOCAL top `budget` >= top_n keys --
+//     any key of the global top_n is in its slice's top_n -- and appends them to the segment's survivor list (one
+//     returning atomic per workgroup); the workgroup that takes the last ticket (SelSeg::arrived; nobody waits)
+//     selects among the <= G * budget survivors.
+//   * the selected keys are narrowed to the smallest sortable size in LDS, sorted (bitonic, keys in registers, only
+//     the cross-wave stages through LDS) and decoded.
+// Keys are unique (they embed the index), so "keys >= T" is exactly top_n elements even when every score is equal.
 #pragma once
 
 #include "common.hpp"
@@ -32,54 +34,58 @@
 namespace odtk {
 
 constexpr int kSelThreads = 1024;
+constexpr int kSelWaves = kSelThreads / kWave;
 constexpr int kSortCap = 4096;                  // keys sortable in LDS by the standard kernel (32 KiB)
 constexpr int kSortCapBig = ODTK_MAX_TOP_N;     // ... by the top_n > 4096 variant (128 KiB of dynamic LDS)
 constexpr int kRadixBits = 11;
 constexpr int kRadixBins = 1 << kRadixBits;
+constexpr uint32_t kKeysPerPart = 3072;         // candidates per workgroup: a slice then nearly always fits the sort buffer whole
+constexpr uint32_t kCntSlots = 2048;            // sub-list lengths a workgroup keeps in LDS (512 spans)
+constexpr uint32_t kSpansPerPart = 16;          // host: workgroups provided per segment = ceil(spans / this), <= kMaxParts
+constexpr uint32_t kMaxParts = 64;
+constexpr int kHistCopies = 4;                  // sub-histograms of select_threshold (standard kernel): lane l adds to copy l % 4
+
+// LDS carve-up of select_decode_kernel (one dynamic allocation: more than the 64 KiB a kernel may declare statically)
+template <int CAP>
+struct SelLds {
+  static constexpr int copies = CAP <= kSortCap ? kHistCopies : 1;       // (the 128 KiB sort buffer leaves room for one)
+  static constexpr size_t keys = 0;
+  static constexpr size_t hist = keys + sizeof(uint64_t) * CAP;
+  static constexpr size_t cnt = hist + sizeof(uint32_t) * kRadixBins * copies;
+  static constexpr size_t raw = cnt + sizeof(uint32_t) * kCntSlots;
+  static constexpr size_t total = raw + sizeof(uint16_t) * (kCntSlots / kScanWaves);
+};
 
 struct DecodeLevel {
   const void *cls;
   const void *box;
-  uint64_t cand_off;
+  uint64_t key_off;      // first key of this level's span regions in the candidate pool
+  uint64_t surv_off;     // first key of this level's survivor lists (parts * budget keys per segment)
+  uint32_t cnt_off;      // first sub-list length of this level
   uint32_t n;            // A*C*H*W
-  uint32_t cap;          // per sub-list
+  uint32_t spans;        // spans per image
   int32_t height, width;
   float stride;
   uint32_t channels_last;
+  uint32_t pad_;
   const float *cls_bias; // [A*C] added to the cls head values (logits) before the sigmoid, or null
   const float *box_bias; // [A*NB] added to the gathered deltas, or null
   float anchors[ODTK_MAX_ANCHORS * 4];
 };
 
-constexpr int kSelParts = 64;             // workgroups per segment of the multi-workgroup passes (largest levels)
-constexpr int kPassThreads = 256;          // threads of a pass workgroup: 4 waves, so that the ~10^3 workgroups of a launch are
-                                           // all resident at once (1024-thread workgroups needed two rounds: +6 us per pass)
-constexpr uint32_t kSelSlice = 2048;       // candidate keys per workgroup of a pass (list source): 8 per lane, one round of loads
-constexpr uint32_t kSurvCap = 16384;       // survivor keys per segment the filter pass may emit (4 x that for top_n > 4096)
-constexpr uint32_t kRankCap = 1024;        // keys of the boundary bin select_decode can rank by brute force (one per thread)
-
-// Per-segment scratch of the multi-workgroup selection; zeroed by the host memset before every call.
-struct SelSeg {
-  uint32_t hist[2][1 << 11];               // histograms of pass 0 / pass 1, bins reversed (largest keys first)
-  unsigned long long kmax;                 // pass 0: largest key, and ...
-  unsigned long long kmin_inv;             // ... largest ~key (= ~smallest key)
-  // filter pass (part 0): keys >= T survive, `expected` of them; those > bin_hi (exactly `taken` keys) are wanted
-  // outright, of the `in_bin` keys inside [T, bin_hi] the `need` largest are wanted
-  unsigned long long T, bin_hi;
-  uint32_t expected, need, n_above, n_bin;   // expected = n_above + n_bin
-  uint32_t filtered, surv_count;
-  uint32_t arrived, pad_;                  // second digit: workgroups of the segment that have added their histogram (ticket)
-};
-
 struct DecodeArgs {
   DecodeLevel lv[ODTK_MAX_LEVELS];
-  uint32_t part_begin[ODTK_MAX_LEVELS + 1];   // first workgroup of each level in a select_pass_kernel launch
-  uint32_t parts[ODTK_MAX_LEVELS];            // workgroups per segment of that level (0: level too small to need any)
-  SelSeg *sel;                                // [n_levels * batch]
-  uint64_t *surv;                             // [n_levels * batch][surv_cap]
-  uint32_t sort_cap, surv_cap;                // LDS sort capacity of the select_decode variant in use; survivor keys per segment
-  const uint32_t *counts;
-  const uint64_t *cand;
+  uint32_t part_begin[ODTK_MAX_LEVELS + 1];   // first workgroup of each level
+  uint32_t parts[ODTK_MAX_LEVELS];            // workgroups provided per segment of that level (>= 1)
+  SelSeg *sel;                                // [n_levels * batch], zeroed by the prefilter
+  uint64_t *surv;                             // survivor lists (tournament route)
+  const uint32_t *counts;                     // sub-list lengths written by the prefilter
+  const uint64_t *cand;                       // candidate pool
+  uint32_t budget;                            // keys a workgroup of the tournament route may pass on (>= top_n, <= sort capacity)
+  uint32_t span_elems;                        // elements per span
+  uint32_t aligned;                           // every image of every level starts on a 16-byte boundary (vector loads of raw spans)
+  float raw_lo;                               // logits: conservative lower bound of a candidate's logit (as the prefilter's)
+  FastDiv by_channels;                        // A*C
   float *out_scores;     // [batch, n_levels*top_n]
   float *out_boxes;      // [batch, n_levels*top_n, NB]
   float *out_classes;    // [batch, n_levels*top_n]
@@ -87,77 +93,10 @@ struct DecodeArgs {
   uint32_t *run_valid;   // optional [batch, n_levels]: emitted entries with score > 0 of every (image, level) list (nms sorted-run mode)
   int n_levels, batch, num_anchors, num_classes, top_n;
   float thresh;
-  unsigned long long *trace;   // debug (odtk_debug_set_trace): 8 timestamps per workgroup, or null
+  unsigned long long *trace;   // debug (odtk_debug_set_trace): 8 words per segment, or null
 };
 
 // ---- key sources -------------------------------------------------------------------------
-struct ListSource {   // the kSubLists compacted candidate sub-lists written by prefilter_scan_kernel
-  const uint64_t *keys;              // sub-list s starts at keys + s * cap
-  uint32_t cap;
-  uint32_t start[kSubLists + 1];     // exclusive prefix of the (clamped) sub-list lengths: wave-uniform
-  __device__ ListSource(const uint64_t *k, uint32_t n_flat) : keys(k), cap(n_flat) {   // ONE flat list of n_flat keys
-#pragma unroll
-    for (int s = 0; s <= kSubLists; ++s) start[s] = s == 0 ? 0 : n_flat;
-  }
-  __device__ ListSource(const uint64_t *k, const uint32_t *counts, uint32_t cap_) : keys(k), cap(cap_) {
-    uint32_t acc = 0;
-#pragma unroll
-    for (int s = 0; s < kSubLists; ++s) {
-      start[s] = acc;
-      const uint32_t c = counts[s];
-      acc += c < cap_ ? c : cap_;
-    }
-    start[kSubLists] = acc;
-  }
-  // one flat, fully occupied loop over all sub-lists (walking them one after the other would leave
-  // most of the 1024 threads idle on the short lists and serialise 16 dependent count loads)
-  template <typename F>
-  __device__ __forceinline__ void for_each(F &&f) const {
-    const uint32_t total = start[kSubLists];
-    auto address = [&](uint32_t i) -> const uint64_t * { return address_of(i); };
-    // The lists live in L2 and ONE workgroup walks them: its only source of memory-level parallelism
-    // is independent loads per lane.  16 in flight per lane (128 KiB per workgroup), then 4, then 1.
-    uint32_t i = threadIdx.x;
-    i = batched<16>(i, total, address, f);
-    i = batched<4>(i, total, address, f);
-    for (; i < total; i += kSelThreads) f(*address(i));
-  }
-  __device__ __forceinline__ const uint64_t *address_of(uint32_t i) const {
-    uint32_t sl = 0, base = 0;
-#pragma unroll
-    for (int q = 1; q < kSubLists; ++q)
-      if (i >= start[q]) { sl = q; base = start[q]; }
-    return keys + static_cast<uint64_t>(sl) * cap + (i - base);
-  }
-  // keys [lo, hi) of the flat order; every lane of the workgroup calls f(key, valid) the same number of times
-  // (wave-level ballots inside f stay legal)
-  template <int kThreads, typename F>
-  __device__ __forceinline__ void for_range(uint32_t lo, uint32_t hi, F &&f) const {
-    // the lists come out of L2 at ~1.5 us per dependent round trip: a slice of kSelSlice keys is ONE round (8 loads per lane)
-    constexpr int kLoads = 8;
-    for (uint32_t i0 = lo; i0 < hi; i0 += kLoads * kThreads) {
-      uint64_t k[kLoads];
-#pragma unroll
-      for (int u = 0; u < kLoads; ++u) {
-        const uint32_t i = i0 + u * kThreads + threadIdx.x;
-        k[u] = i < hi ? *address_of(i) : 0;                 // 0 is not a key (an index never has all bits set)
-      }
-#pragma unroll
-      for (int u = 0; u < kLoads; ++u) f(k[u], k[u] != 0);
-    }
-  }
-  template <int kBatch, typename A, typename F>
-  static __device__ __forceinline__ uint32_t batched(uint32_t i, uint32_t total, A &&address, F &&f) {
-    for (; i + (kBatch - 1) * kSelThreads < total; i += kBatch * kSelThreads) {
-      uint64_t k[kBatch];
-#pragma unroll
-      for (int u = 0; u < kBatch; ++u) k[u] = *address(i + u * kSelThreads);
-#pragma unroll
-      for (int u = 0; u < kBatch; ++u) f(k[u]);
-    }
-    return i;
-  }
-};
 struct LdsSource {    // keys already gathered into LDS
   const uint64_t *keys;
   uint32_t count;
@@ -166,24 +105,174 @@ struct LdsSource {    // keys already gathered into LDS
     for (uint32_t i = threadIdx.x; i < count; i += kSelThreads) f(keys[i]);
   }
 };
-template <typename T, bool kLogits>
-struct RawSource {    // the segment's raw head values (overflow path); walks memory order
-  const void *image;  // first element of this image
-  uint32_t n, channels, hw, channels_last;
-  float thresh;
-  const float *bias;  // per-channel head bias (logits only) or null
+
+// A flat list of keys in global memory written by OTHER workgroups of this launch (the survivor list): read past this
+// CU's vector cache.  f(key, valid) is called the same number of times by every lane (ballots inside f are legal).
+struct FlatSource {
+  const uint64_t *keys;
+  uint32_t count;
   template <typename F>
   __device__ __forceinline__ void for_each(F &&f) const {
-    for (uint32_t r = threadIdx.x; r < n; r += kSelThreads) {
-      float raw = load_raw<T>(image, r);
-      if (kLogits && bias) raw += bias[channels_last ? r % channels : (r / hw) % channels];
-      const float s = score_of<T, kLogits>(raw);
-      if (s >= thresh) {
-        uint32_t i = r;
-        if (channels_last) { const uint32_t pix = r / channels, ch = r - pix * channels; i = ch * hw + pix; }
-        f(make_key(s, i));
+    constexpr int kLoads = 8;
+    for (uint32_t i0 = 0; i0 < count; i0 += kLoads * kSelThreads) {
+      uint64_t k[kLoads];
+#pragma unroll
+      for (int u = 0; u < kLoads; ++u) {
+        const uint32_t i = i0 + u * kSelThreads + threadIdx.x;
+        k[u] = i < count ? __hip_atomic_load(keys + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;   // 0 is not a key
+      }
+#pragma unroll
+      for (int u = 0; u < kLoads; ++u) f(k[u], k[u] != 0);
+    }
+  }
+};
+
+// The spans s = part, part + G, part + 2G, ... of one segment: per span four sub-lists (one per prefilter wave) of up to
+// kWaveStage keys, or -- a sub-list length of kListOverflow -- the span's raw scores.
+//   lists     : a wave takes one span per load instruction -- 16 lanes per sub-list, a 16-byte load = 2 keys per lane, i.e.
+//               the first 32 keys of each of the four sub-lists (at realistic densities: all of them) -- and eight spans
+//               at a time, so that eight independent loads are in flight per lane; longer sub-lists follow in a second,
+//               rolled loop that a wave enters only if one of its sub-lists needs it.
+//   raw spans : (collected once per workgroup in `s_raw`) walked by the WHOLE workgroup, 16-byte vector loads, keys
+//               rebuilt on the fly behind the prefilter's own conservative raw-domain test.
+// f(key, valid): same number of calls in every lane of a wave (ballots inside f are legal).  for_each must be called by
+// all threads of the workgroup.
+template <typename T, bool kLogits>
+struct SliceSource {
+  const uint64_t *seg_keys;      // span 0 of this segment in the candidate pool
+  const uint32_t *s_cnt;         // LDS: sub-list lengths, 4 per span
+  const uint16_t *s_raw;         // LDS: this slice's raw spans (k indices)
+  uint32_t n_raw;
+  uint32_t part, G, ns;          // this workgroup's spans: part + k * G, k < ns
+  uint32_t direct;               // s_cnt holds the whole segment (index by span) / only this slice (index by k)
+  const void *image;             // raw scores of this image
+  uint32_t n, hw, channels_last, span_elems, aligned;
+  FastDiv by_channels;
+  float thresh, raw_lo;
+  const float *bias;             // per-channel head bias (logits only) or null
+
+  __device__ __forceinline__ uint32_t cnt_index(uint32_t k) const { return (direct ? part + k * G : k) * kScanWaves; }
+
+  // one raw element -> f(key, take)
+  template <typename F>
+  __device__ __forceinline__ void raw_element(float x, uint32_t r, bool inside, F &&f) const {
+    bool take = inside;
+    uint64_t key = 0;
+    if (take) {
+      uint32_t i = r;
+      if (channels_last) {
+        uint32_t ch;
+        const uint32_t pix = fastdivmod(r, by_channels, &ch);
+        i = ch * hw + pix;
+        if (kLogits && bias) x += bias[ch];
+      }
+      take = kLogits ? x >= raw_lo : x >= thresh;            // (conservative for logits: the sigmoid only for the few that pass)
+      if (take) {
+        const float s = score_of<T, kLogits>(x);
+        take = s >= thresh;
+        key = make_key(s, i);
       }
     }
+    f(key, take);
+  }
+
+  template <typename F>
+  __device__ __forceinline__ void raw_span(uint32_t span, F &&f) const {
+    constexpr int kPer = T::kPerLoad;
+    const uint32_t lo = span * span_elems;
+    const uint32_t hi = n - lo < span_elems ? n : lo + span_elems;
+    if (aligned) {                                           // every image starts on a 16-byte boundary, spans too
+      const vuint4 *src = reinterpret_cast<const vuint4 *>(static_cast<const typename T::storage *>(image) + lo);
+      const uint32_t n_vec = (hi - lo) / kPer;
+      for (uint32_t q0 = 0; q0 < n_vec; q0 += 2 * kSelThreads) {
+        vuint4 v[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const uint32_t q = q0 + u * kSelThreads + threadIdx.x;
+          v[u] = q < n_vec ? src[q] : vuint4{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const uint32_t q = q0 + u * kSelThreads + threadIdx.x;
+#pragma unroll
+          for (int e = 0; e < kPer; ++e) {
+            float x;
+            if constexpr (std::is_same_v<T, F32>) x = __uint_as_float(v[u][e]);
+            else x = storage_to_float<T>(static_cast<uint16_t>((v[u][e >> 1] >> (16 * (e & 1))) & 0xffffu));
+            raw_element(x, lo + q * kPer + e, q < n_vec, f);
+          }
+        }
+      }
+    } else {
+      for (uint32_t r0 = lo; r0 < hi; r0 += 4 * kSelThreads) {
+        float raw[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const uint32_t r = r0 + u * kSelThreads + threadIdx.x;
+          raw[u] = r < hi ? load_raw<T>(image, r) : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const uint32_t r = r0 + u * kSelThreads + threadIdx.x;
+          raw_element(raw[u], r, r < hi, f);
+        }
+      }
+    }
+  }
+
+  template <typename F>
+  __device__ __forceinline__ void for_each(F &&f) const {
+    constexpr int kGroup = 8;
+    const uint32_t wave = threadIdx.x >> 6, lane = static_cast<uint32_t>(lane_id());
+    const uint32_t sub = lane >> 4, l16 = lane & 15u;
+    bool more = false;                                                   // a sub-list of mine holds more than 32 keys
+    for (uint32_t k0 = wave; k0 < ns; k0 += kSelWaves * kGroup) {        // (wave-uniform)
+      vuint4 kv[kGroup];
+      uint32_t cc[kGroup];
+#pragma unroll
+      for (int u = 0; u < kGroup; ++u) {
+        const uint32_t k = k0 + kSelWaves * u;
+        uint32_t c = k < ns ? s_cnt[cnt_index(k) + sub] : 0u;
+        if (__ballot(c == kListOverflow)) c = 0;                         // one overflowed wave: the whole span is read raw (below)
+        cc[u] = c;
+        more = more || c > 32u;
+        kv[u] = vuint4{0u, 0u, 0u, 0u};
+        if (2 * l16 < c)
+          kv[u] = *reinterpret_cast<const vuint4 *>(seg_keys + static_cast<uint64_t>(part + k * G) * kSpanCap + sub * kWaveStage + 2 * l16);
+      }
+#pragma unroll
+      for (int u = 0; u < kGroup; ++u) {
+        f((static_cast<uint64_t>(kv[u][1]) << 32) | kv[u][0], 2 * l16 < cc[u]);
+        f((static_cast<uint64_t>(kv[u][3]) << 32) | kv[u][2], 2 * l16 + 1 < cc[u]);
+      }
+    }
+    if (__ballot(more)) {                                                // (wave-uniform) dense inputs: what the first 32 slots did not cover
+#pragma unroll 1
+      for (uint32_t k = wave; k < ns; k += kSelWaves) {
+        uint32_t c = s_cnt[cnt_index(k) + sub];
+        if (__ballot(c == kListOverflow)) continue;
+        uint32_t cmax = c;
+        cmax = max(cmax, static_cast<uint32_t>(__shfl_xor(cmax, 16, kWave)));
+        cmax = max(cmax, static_cast<uint32_t>(__shfl_xor(cmax, 32, kWave)));
+        cmax = __builtin_amdgcn_readfirstlane(cmax);
+        const uint64_t *list = seg_keys + static_cast<uint64_t>(part + k * G) * kSpanCap + sub * kWaveStage;
+        for (uint32_t base = 32; base < cmax; base += 128) {             // 4 x 2 keys per lane in flight
+          vuint4 kk[4];
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            const uint32_t i = base + 32 * v + 2 * l16;
+            kk[v] = i < c ? *reinterpret_cast<const vuint4 *>(list + i) : vuint4{0u, 0u, 0u, 0u};
+          }
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            const uint32_t i = base + 32 * v + 2 * l16;
+            f((static_cast<uint64_t>(kk[v][1]) << 32) | kk[v][0], i < c);
+            f((static_cast<uint64_t>(kk[v][3]) << 32) | kk[v][2], i + 1 < c);
+          }
+        }
+      }
+    }
+    for (uint32_t q = 0; q < n_raw; ++q) raw_span(part + static_cast<uint32_t>(s_raw[q]) * G, f);   // (block-uniform)
   }
 };
 
@@ -314,7 +403,7 @@ __device__ __forceinline__ void scan_boundary(const uint32_t *s_hist, uint32_t r
 // caller sorts a few extra keys instead of paying for more passes.  Keys are unique; the source
 // must hold at least `want` keys and max_take >= want.  s_misc: [0..15] wave totals, [16..18] result.
 template <typename Source>
-__device__ uint64_t radix_threshold(const Source &src, uint32_t want, uint32_t max_take, uint32_t *s_hist,
+__device__ __forceinline__ uint64_t radix_threshold(const Source &src, uint32_t want, uint32_t max_take, uint32_t *s_hist,
                                     uint32_t *s_misc, uint32_t *n_out) {
   uint64_t prefix = 0, pmask = 0;
   uint32_t remaining = want, taken_above = 0, in_bin = 0;
@@ -344,24 +433,6 @@ __device__ uint64_t radix_threshold(const Source &src, uint32_t want, uint32_t m
   return prefix;                                    // undecided low bits are 0 = start of the boundary bin
 }
 
-// ---- multi-workgroup narrowing (two launches in front of select_decode_kernel) ----------------------------
-// A digit cuts the current key range [lo, hi] into 2048 equal bins (digit = (key - lo) >> sh) and histograms the keys
-// inside it; the bin in which the running count, from the top, crosses top_n becomes the next range.
-//   launch 0: first digit over [key(thresh, last index), key(1.0 | +inf, index 0)] -- every candidate lies in it; also
-//             records the smallest and the largest key.
-//   launch 1: FILTER -- every key >= the boundary bin's lower end goes to the segment's survivor list: the `taken` keys
-//             above the bin, all wanted, and the bin's own `in_bin` keys of which select_decode keeps the `need` largest.
-//             Where more keys than the survivor list holds share the boundary bin (saturated scores: all keys share
-//             their score bits and differ only in the index bits) a SECOND DIGIT comes first, inside the same launch:
-//             over the bin clipped to [min key, max key] (the clip makes the 2048 bins land on the bits that differ); the
-//             workgroup that adds its histogram last finishes the segment (select_pass_kernel).
-// Up to kSelParts workgroups of 256 threads per segment walk disjoint slices of the candidate lists (or of the raw
-// scores when a sub-list overflowed); segments with <= sort-size candidates leave both launches at once.
-struct SelState {
-  uint64_t lo, hi;                      // current range, both ends inclusive
-  uint32_t remaining, taken, in_bin, done;
-};
-
 __device__ __forceinline__ uint32_t sort_size_for(uint32_t top_n) {
   uint32_t sort_size = kSelThreads;
   while (sort_size < top_n) sort_size <<= 1;
@@ -372,59 +443,6 @@ __device__ __forceinline__ int range_shift(uint64_t lo, uint64_t hi) {   // (hi 
   const uint64_t w = hi - lo;
   const int bl = w ? 64 - __clzll(static_cast<long long>(w)) : 0;
   return bl > kRadixBits ? bl - kRadixBits : 0;
-}
-
-// scan_boundary for a 256-thread workgroup: 8 consecutive bins per thread.  s_misc: [0..3] wave totals, [16..18] result.
-__device__ __forceinline__ void scan_boundary_256(const uint32_t *s_hist, uint32_t remaining, uint32_t *s_misc, uint32_t *rbin,
-                                                  uint32_t *above, uint32_t *in_bin) {
-  constexpr int kPerThread = kRadixBins / kPassThreads;
-  uint32_t h[kPerThread], sum = 0;
-#pragma unroll
-  for (int k = 0; k < kPerThread; ++k) { h[k] = s_hist[threadIdx.x * kPerThread + k]; sum += h[k]; }
-  const uint32_t inc = wave_inclusive_sum(sum);
-  const int w = threadIdx.x >> 6;
-  if (lane_id() == kWave - 1) s_misc[w] = inc;
-  __syncthreads();
-  uint32_t run = inc - sum;
-  for (int i = 0; i < w; ++i) run += s_misc[i];
-#pragma unroll
-  for (int k = 0; k < kPerThread; ++k) {
-    if (run < remaining && remaining <= run + h[k]) { s_misc[16] = threadIdx.x * kPerThread + k; s_misc[17] = run; s_misc[18] = h[k]; }
-    run += h[k];
-  }
-  __syncthreads();
-  // (values read from LDS are VGPRs -- "divergent" to the compiler; callers steer loops with them, so pin them to SGPRs:
-  // the descent loops then compile to scalar control flow instead of exec-masked waterfall loops)
-  *rbin = __builtin_amdgcn_readfirstlane(s_misc[16]);
-  *above = __builtin_amdgcn_readfirstlane(s_misc[17]);
-  *in_bin = __builtin_amdgcn_readfirstlane(s_misc[18]);
-  __syncthreads();
-}
-
-// Folds one histogram pass into the state (block-wide, uniform result).  [kmin, kmax]: all keys of the segment.
-// kFresh: the histogram was completed by OTHER workgroups of this launch (ticket): read it past this CU's vector cache.
-template <bool kFresh = false>
-__device__ __forceinline__ void advance_state(SelState &st, const uint32_t *g_hist, uint64_t kmin, uint64_t kmax, uint32_t sort_cap,
-                                              uint32_t *s_hist, uint32_t *s_misc) {
-  const int sh = range_shift(st.lo, st.hi);
-  for (uint32_t i = threadIdx.x; i < kRadixBins; i += kPassThreads)
-    s_hist[i] = kFresh ? __hip_atomic_load(g_hist + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : g_hist[i];
-  __syncthreads();
-  uint32_t rbin, above, in_bin;
-  scan_boundary_256(s_hist, st.remaining, s_misc, &rbin, &above, &in_bin);
-  const uint64_t digit = (kRadixBins - 1) - rbin;
-  uint64_t lo = st.lo + (digit << sh);
-  const uint64_t span = sh ? ((1ull << sh) - 1ull) : 0ull;
-  uint64_t hi = lo > ~0ull - span ? ~0ull : lo + span;
-  hi = hi < st.hi ? hi : st.hi;
-  lo = lo > kmin ? lo : kmin;                               // no key lies outside [kmin, kmax]
-  hi = hi < kmax ? hi : kmax;
-  st.lo = lo;
-  st.hi = hi;
-  st.remaining -= above;
-  st.taken += above;
-  st.in_bin = in_bin;
-  if ((in_bin <= kRankCap && st.taken + in_bin <= sort_cap) || lo >= hi) st.done = 1;
 }
 
 // radix_threshold on a KNOWN key range [lo, hi] (both inclusive), 1024-thread workgroups: every pass cuts the range into
@@ -465,235 +483,114 @@ __device__ uint64_t range_threshold(const Source &src, uint32_t want, uint32_t m
   return lo;
 }
 
-// The raw head values of elements [lo, hi) (memory order) of one image, as keys: the overflow path of the passes.
-template <typename T, bool kLogits>
-struct RawSlice {
-  const void *image;
-  uint32_t n, channels, hw, channels_last;
-  float thresh;
-  const float *bias;
-  template <int kThreads, typename F>
-  __device__ __forceinline__ void for_range(uint32_t lo, uint32_t hi, F &&f) const {
-    for (uint32_t r0 = lo; r0 < hi; r0 += 8 * kThreads) {
-      float raw[8];
-      bool ok[8];
+// scan_boundary that also returns the histogram's total; the histogram comes as kCopies interleaved sub-histograms
+// (s_hist[bin * kCopies + c]).  s_misc: [0..15] wave totals, [16..18] result.
+template <int kCopies>
+__device__ __forceinline__ void scan_boundary_total(const uint32_t *s_hist, uint32_t remaining, uint32_t *s_misc, uint32_t *rbin,
+                                                    uint32_t *above, uint32_t *in_bin, uint32_t *total) {
+  uint32_t h0 = 0, h1 = 0;
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const uint32_t r = r0 + u * kThreads + threadIdx.x;
-        ok[u] = r < hi;
-        raw[u] = ok[u] ? load_raw<T>(image, r) : 0.0f;
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const uint32_t r = r0 + u * kThreads + threadIdx.x;
-        float x = raw[u];
-        bool take = ok[u];
-        uint64_t key = 0;
-        if (take) {
-          if (kLogits && bias) x += bias[channels_last ? r % channels : (r / hw) % channels];
-          const float s = score_of<T, kLogits>(x);
-          take = s >= thresh;
-          if (take) {
-            uint32_t i = r;
-            if (channels_last) { const uint32_t pix = r / channels, ch = r - pix * channels; i = ch * hw + pix; }
-            key = make_key(s, i);
-          }
-        }
-        f(key, take);
-      }
-    }
+  for (int c = 0; c < kCopies; ++c) {
+    h0 += s_hist[(2 * threadIdx.x) * kCopies + c];
+    h1 += s_hist[(2 * threadIdx.x + 1) * kCopies + c];
   }
+  const uint32_t inc = wave_inclusive_sum(h0 + h1);
+  const int w = threadIdx.x >> 6;
+  if (lane_id() == kWave - 1) s_misc[w] = inc;
+  if (threadIdx.x == 0) { s_misc[16] = 0; s_misc[17] = 0; s_misc[18] = 0; }
+  __syncthreads();
+  uint32_t woff = 0, all = 0;
+  for (int i = 0; i < kSelWaves; ++i) {
+    const uint32_t t = s_misc[i];
+    if (i < w) woff += t;
+    all += t;
+  }
+  const uint32_t excl = woff + inc - (h0 + h1);
+  __syncthreads();                                         // (the zeroing of [16..18] above is ordered before these writes)
+  if (excl < remaining && remaining <= excl + h0) { s_misc[16] = 2 * threadIdx.x; s_misc[17] = excl; s_misc[18] = h0; }
+  else if (excl + h0 < remaining && remaining <= excl + h0 + h1) { s_misc[16] = 2 * threadIdx.x + 1; s_misc[17] = excl + h0; s_misc[18] = h1; }
+  __syncthreads();
+  *rbin = __builtin_amdgcn_readfirstlane(s_misc[16]);
+  *above = __builtin_amdgcn_readfirstlane(s_misc[17]);
+  *in_bin = __builtin_amdgcn_readfirstlane(s_misc[18]);
+  *total = __builtin_amdgcn_readfirstlane(all);
+  __syncthreads();
+}
+
+// What a selection pass leaves: T = lower end of the boundary bin, [T, bin_hi] = the bin; n_above keys lie above it (all of
+// them wanted), in_bin inside it, of which the `need` largest are wanted: n_above + need = min(want, all keys).
+struct Split {
+  uint64_t T, bin_hi;
+  uint32_t n_above, in_bin, need;
 };
 
-// PASS 0: the first histogram (+ smallest / largest key).
-// PASS 1: what follows it, in ONE launch (round 3; there were two, the first of them launched and skipped in the normal case):
-//   * every workgroup derives the state after pass 0 from the segment's histogram (8 KiB out of L2);
-//   * boundary bin rankable, or everything at or above it fits the survivor list  -> FILTER now: this workgroup's slice of
-//     the keys >= the bin's lower end goes to the survivor list (select_decode ranks a bin of <= kRankCap keys by brute
-//     force and radix-selects a larger one in LDS);
-//   * otherwise (saturated scores, plateaus: > surv_cap keys share the boundary bin)  -> SECOND DIGIT: histogram of the
-//     slice over the bin, clipped to [min key, max key]; the workgroup that arrives LAST at the segment's ticket counter
-//     (no grid barrier, nobody waits) folds that histogram into the state and filters the WHOLE segment alone -- slower
-//     than 64 workgroups, but it is the rare route and costs the common one no launch.
-template <typename T, bool kLogits, int PASS>
-__global__ __launch_bounds__(kPassThreads) void select_pass_kernel(const DecodeArgs a) {
-  __shared__ __attribute__((aligned(8))) uint32_t s_hist[kRadixBins];
-  __shared__ uint32_t s_misc[32];
-  __shared__ unsigned long long s_range[2];
-
-  int l = 0;
-#pragma unroll
-  for (int i = 1; i < ODTK_MAX_LEVELS; ++i)
-    if (i < a.n_levels && blockIdx.x >= a.part_begin[i]) l = i;
-  const uint32_t P = a.parts[l];
-  const uint32_t j = blockIdx.x - a.part_begin[l];
-  const uint32_t b = j / P, part = j - b * P;
-  const int seg = l * a.batch + static_cast<int>(b);
-  const DecodeLevel &L = a.lv[l];
-  const uint32_t *sub_counts = a.counts + static_cast<size_t>(seg) * kSubLists;
-  uint32_t count = 0;
-  bool complete = true;
-#pragma unroll
-  for (int s = 0; s < kSubLists; ++s) {
-    const uint32_t c = sub_counts[s];
-    count += c;
-    complete = complete && c <= L.cap;
-  }
-  if (count <= sort_size_for(a.top_n)) return;              // select_decode sorts these directly (block-uniform exit)
-  SelSeg &S = a.sel[seg];
-  // debug trace (odtk_debug_set_trace): 5 timestamps of part 0 per (pass, segment), behind the select_decode / nms slots
-  auto stamp = [&](int k) {
-    if (a.trace && part == 0 && threadIdx.x == 0) a.trace[1024 + (PASS * 64 + seg) * 8 + k] = wall_clock64();
-  };
-  stamp(0);
-
-  // ---- this workgroup's slice of the segment ----
-  const uint32_t hw = static_cast<uint32_t>(L.height) * L.width;
-  const uint32_t channels = static_cast<uint32_t>(a.num_anchors) * a.num_classes;
-  const ListSource lists(a.cand + L.cand_off + static_cast<uint64_t>(b) * kSubLists * L.cap, sub_counts, L.cap);
-  const uint32_t total = complete ? lists.start[kSubLists] : L.n;
-  uint32_t active = complete ? (total + kSelSlice - 1) / kSelSlice : P;
-  if (active > P) active = P;
-  const uint32_t chunk = ((total + active - 1) / active + kPassThreads - 1) / kPassThreads * kPassThreads;
-  const uint32_t n_live = (total + chunk - 1) / chunk;       // workgroups of this segment that own a non-empty slice
-  const uint32_t lo = part * chunk;
-  const uint32_t hi = lo + chunk < total ? lo + chunk : total;
-  if (part >= active || lo >= hi) return;
-  const typename T::storage *cls_image = static_cast<const typename T::storage *>(L.cls) + static_cast<uint64_t>(b) * L.n;
-  const RawSlice<T, kLogits> raw{cls_image, L.n, channels, hw, L.channels_last, a.thresh, L.cls_bias};
-  auto walk = [&](uint32_t w_lo, uint32_t w_hi, auto &&fn) {
-    if (complete) lists.template for_range<kPassThreads>(w_lo, w_hi, fn);
-    else raw.template for_range<kPassThreads>(w_lo, w_hi, fn);
-  };
-  const int lane = lane_id();
-
-  // histogram of the keys inside [r_lo, r_hi] (2048 equal bins, reversed) into g_hist; pass 0 also records min / max
-  auto histogram = [&](uint64_t r_lo, uint64_t r_hi, bool clip, uint32_t *g_hist) {
-    for (uint32_t i = threadIdx.x; i < kRadixBins; i += kPassThreads) s_hist[i] = 0;
+// Threshold over the keys of `src`, all of which lie inside [lo, hi] (both inclusive): on return #{key >= T} = n_above +
+// in_bin with  min(want, all) <= n_above + in_bin <= max_take  (want <= take_all <= max_take); a source of no more than
+// `take_all` keys is taken whole (T = lo, in_bin = 0).  Every pass histograms the current range in
+// 2048 equal bins and descends into the bin where the running count, from the top, crosses `want`; it stops as soon as
+// everything above that bin plus the bin itself fits max_take -- normally after ONE pass (a linear digit over the score
+// range separates what an 11-bit MSD digit cannot: fp32 scores of one image share their exponent bits).  From the second
+// pass on the range is clipped to the [smallest, largest] key seen inside it, so that keys which share all their score
+// bits (saturated inputs) are split on their index bits.  Per key the first pass costs ~10 instructions: ONE workgroup --
+// one CU, 64 lanes per clock -- pays for every instruction 23 000 times on a P3 segment.
+// Source: for_each(f(key, valid)), uniform call count per wave.  s_misc: [0..18] scan scratch; s_range: 2 words.
+// The histogram is kept as kCopies interleaved sub-histograms, lane l adding to copy l % kCopies: 16-bit scores put
+// thousands of keys into a handful of bins, and lanes of a wave that add to ONE LDS word are served one after the other
+// (measured: the pass over 22 000 bf16-score keys of a P3 segment ~9 us with one histogram).
+template <int kCopies, typename Source>
+__device__ __forceinline__ Split select_threshold(const Source &src, uint32_t want, uint32_t max_take, uint32_t take_all, uint64_t lo,
+                                                  uint64_t hi, uint32_t *s_hist, uint32_t *s_misc, unsigned long long *s_range) {
+  Split r;
+  uint32_t remaining = want, taken = 0, in_bin = 0;
+  bool first = true;
+  for (;;) {
+    const int sh = range_shift(lo, hi);
+    for (uint32_t i = threadIdx.x; i < kRadixBins * kCopies; i += kSelThreads) s_hist[i] = 0;
     if (threadIdx.x < 2) s_range[threadIdx.x] = 0;
     __syncthreads();
-    const int sh = range_shift(r_lo, r_hi);
     uint64_t my_max = 0, my_min_inv = 0;
-    walk(lo, hi, [&](uint64_t key, bool valid) {
-      if (clip) valid = valid && key >= r_lo && key <= r_hi;
-      const uint64_t m = __ballot(valid);
-      if (!m) return;                                       // wave-uniform
-      uint32_t digit = static_cast<uint32_t>((key - r_lo) >> sh);
-      digit = digit > kRadixBins - 1 ? kRadixBins - 1 : digit;
-      const uint32_t bin = (kRadixBins - 1) - digit;
-      // a wave whose lanes all hit ONE bin (saturated inputs: every key) adds once -- 64 LDS atomics on one word
-      // would serialise
-      const int leader = __ffsll(static_cast<unsigned long long>(m)) - 1;
-      const uint32_t bin0 = __shfl(bin, leader, kWave);
-      const uint64_t same = __ballot(valid && bin == bin0);
-      if (same == m) { if (lane == leader) atomicAdd(&s_hist[bin0], static_cast<uint32_t>(__popcll(m))); }
-      else if (valid) atomicAdd(&s_hist[bin], 1u);
-      if (PASS == 0 && valid) {
-        my_max = key > my_max ? key : my_max;
-        my_min_inv = ~key > my_min_inv ? ~key : my_min_inv;
+    const uint32_t my_copy = threadIdx.x & (kCopies - 1);
+    const bool track = !first;                              // (uniform) the first range holds every key: nothing to clip yet
+    src.for_each([&](uint64_t key, bool valid) {
+      if (valid && key >= lo && key <= hi) {
+        atomicAdd(&s_hist[((kRadixBins - 1) - static_cast<uint32_t>((key - lo) >> sh)) * kCopies + my_copy], 1u);   // ((hi - lo) >> sh < 2048)
+        if (track) {
+          my_max = key > my_max ? key : my_max;
+          my_min_inv = ~key > my_min_inv ? ~key : my_min_inv;
+        }
       }
     });
-    if (PASS == 0) {
+    if (track) {
 #pragma unroll
       for (int d = 32; d > 0; d >>= 1) {
         const uint64_t o1 = shfl_xor_u64(my_max, d), o2 = shfl_xor_u64(my_min_inv, d);
         my_max = o1 > my_max ? o1 : my_max;
         my_min_inv = o2 > my_min_inv ? o2 : my_min_inv;
       }
-      if (lane == 0) { atomicMax(&s_range[0], my_max); atomicMax(&s_range[1], my_min_inv); }
+      if (lane_id() == 0 && my_max != 0) { atomicMax(&s_range[0], my_max); atomicMax(&s_range[1], my_min_inv); }
     }
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < kRadixBins; i += kPassThreads) {
-      const uint32_t h = s_hist[i];
-      if (h) atomicAdd(&g_hist[i], h);
+    const uint64_t kmax = track ? uniform_u64(s_range[0]) : hi, kmin = track ? ~uniform_u64(s_range[1]) : lo;
+    uint32_t rbin, above, total;
+    scan_boundary_total<kCopies>(s_hist, remaining, s_misc, &rbin, &above, &in_bin, &total);   // (barriers inside: s_range may be reset after it)
+    if (first && total <= take_all) {                       // few enough to take them all (want <= take_all <= max_take)
+      r.T = lo; r.bin_hi = hi; r.n_above = total; r.in_bin = 0; r.need = 0;
+      return r;
     }
-    if (PASS == 0 && threadIdx.x == 0) { atomicMax(&S.kmax, s_range[0]); atomicMax(&S.kmin_inv, s_range[1]); }
-  };
-
-  // pass 0 range: every candidate has score >= thresh; sigmoid outputs never exceed 1
-  SelState st;
-  st.lo = make_key(a.thresh, 0xffffffffu);
-  st.hi = kLogits ? make_key(1.0f, 0u) : ~0ull;
-  st.remaining = static_cast<uint32_t>(a.top_n);
-  st.taken = st.in_bin = st.done = 0;
-  if (PASS == 0) {
-    stamp(1);
-    histogram(st.lo, st.hi, false, S.hist[0]);
-    stamp(4);
-    return;
+    first = false;
+    const uint64_t digit = (kRadixBins - 1) - rbin;
+    const uint64_t span = sh ? ((1ull << sh) - 1ull) : 0ull;
+    const uint64_t nlo = lo + (digit << sh);
+    uint64_t nhi = nlo > ~0ull - span ? ~0ull : nlo + span;
+    nhi = nhi < hi ? nhi : hi;
+    lo = nlo > kmin ? nlo : kmin;                           // no key of the old range lies outside [kmin, kmax]
+    hi = nhi < kmax ? nhi : kmax;
+    remaining -= above;
+    taken += above;
+    if (taken + in_bin <= max_take || sh == 0 || lo >= hi) break;
   }
-
-  // ---- PASS 1 ----
-  advance_state(st, S.hist[0], ~S.kmin_inv, S.kmax, a.sort_cap, s_hist, s_misc);
-  uint64_t *surv = a.surv + static_cast<uint64_t>(seg) * a.surv_cap;
-  constexpr uint32_t kStageKeys = kRadixBins / 2;           // s_hist reinterpreted as 64-bit keys
-  uint64_t *s_stage = reinterpret_cast<uint64_t *>(s_hist);
-  // every key >= T64 of [w_lo, w_hi) goes to the survivor list: staged in LDS (the histogram's 8 KiB = 1024 keys, idle now),
-  // ONE returning global atomic per workgroup and stage-full; a returning atomic per wave and round cost 1-2 us each
-  auto filter = [&](uint64_t T64, uint32_t w_lo, uint32_t w_hi) {
-    if (threadIdx.x == 0) s_misc[24] = 0;
-    __syncthreads();
-    auto flush = [&]() {                                     // block-uniform call sites
-      __syncthreads();
-      const uint32_t staged = s_misc[24] < kStageKeys ? s_misc[24] : kStageKeys;
-      if (staged) {
-        if (threadIdx.x == 0) s_misc[25] = atomicAdd(&S.surv_count, staged);
-        __syncthreads();
-        const uint32_t g0 = s_misc[25];
-        for (uint32_t i = threadIdx.x; i < staged; i += kPassThreads)
-          if (g0 + i < a.surv_cap) surv[g0 + i] = s_stage[i];
-      }
-      __syncthreads();
-      if (threadIdx.x == 0) s_misc[24] = 0;
-      __syncthreads();
-    };
-    // slabs of one load round (8 keys per lane): the stage (1024 keys) cannot overflow inside a slab of 2048 keys twice
-    for (uint32_t s_lo = w_lo; s_lo < w_hi; s_lo += kSelSlice) {
-      const uint32_t s_hi = s_lo + kSelSlice < w_hi ? s_lo + kSelSlice : w_hi;
-      walk(s_lo, s_hi, [&](uint64_t key, bool valid) {
-        const bool take = valid && key >= T64;
-        const uint64_t m = __ballot(take);
-        if (!m) return;
-        const int leader = __ffsll(static_cast<unsigned long long>(m)) - 1;
-        uint32_t base = 0;
-        if (lane == leader) base = atomicAdd(&s_misc[24], static_cast<uint32_t>(__popcll(m)));
-        base = __shfl(base, leader, kWave);
-        if (take) {
-          const uint32_t pos = base + __popcll(m & ((1ull << lane) - 1ull));
-          if (pos < kStageKeys) s_stage[pos] = key;
-          else { const uint32_t g = atomicAdd(&S.surv_count, 1u); if (g < a.surv_cap) surv[g] = key; }   // stage full (rare)
-        }
-      });
-      if (s_hi < w_hi) flush();                              // (only the last workgroup of a second digit walks more than one slab)
-    }
-    flush();
-  };
-  auto publish = [&](const SelState &f, bool fits) {
-    S.T = f.lo; S.bin_hi = f.hi; S.expected = f.taken + f.in_bin; S.need = f.remaining; S.filtered = fits ? 1u : 0u;
-    S.n_above = f.taken; S.n_bin = f.in_bin;
-  };
-  stamp(1);
-  if (st.done || st.taken + st.in_bin <= a.surv_cap) {
-    // the common routes: filter this slice now
-    if (part == 0 && threadIdx.x == 0) publish(st, true);
-    stamp(2);
-    filter(st.lo, lo, hi);
-    stamp(4);
-    return;
-  }
-  // second digit: this slice's histogram over the boundary bin, then the ticket
-  histogram(st.lo, st.hi, true, S.hist[1]);
-  __threadfence();
-  __syncthreads();
-  if (threadIdx.x == 0) s_misc[26] = atomicAdd(&S.arrived, 1u);
-  __syncthreads();
-  if (s_misc[26] != n_live - 1) return;                      // (block-uniform) somebody else is last
-  __threadfence();
-  advance_state<true>(st, S.hist[1], st.lo, st.hi, a.sort_cap, s_hist, s_misc);
-  const bool fits = st.taken + st.in_bin <= a.surv_cap;
-  if (threadIdx.x == 0) publish(st, fits);
-  if (fits) filter(st.lo, 0, total);                         // (adversarial key sets that two digits cannot split: select_decode walks the source itself)
-  stamp(4);
+  r.T = lo; r.bin_hi = hi; r.n_above = taken; r.in_bin = in_bin; r.need = remaining;
+  return r;
 }
 
 // ---- the kernel ------------------------------------------------------------------------------
@@ -703,123 +600,205 @@ __global__ __launch_bounds__(kPassThreads) void select_pass_kernel(const DecodeA
 // passes CAP * 8 bytes) beyond.
 template <int NB, typename T, bool kLogits, int CAP = kSortCap>
 __global__ __launch_bounds__(kSelThreads) void select_decode_kernel(const DecodeArgs a) {
-  __shared__ uint64_t s_keys_static[CAP <= kSortCap ? CAP : 1];
-  extern __shared__ __attribute__((aligned(16))) unsigned char s_keys_dynamic[];
-  uint64_t *s_keys = CAP <= kSortCap ? s_keys_static : reinterpret_cast<uint64_t *>(s_keys_dynamic);
-  __shared__ uint32_t s_hist[kRadixBins];
-  __shared__ uint32_t s_misc[32];
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn_sel[];
+  using Lds = SelLds<CAP>;
+  uint64_t *s_keys = reinterpret_cast<uint64_t *>(s_dyn_sel + Lds::keys);
+  uint32_t *s_hist = reinterpret_cast<uint32_t *>(s_dyn_sel + Lds::hist);
+  uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_dyn_sel + Lds::cnt);
+  uint16_t *s_raw = reinterpret_cast<uint16_t *>(s_dyn_sel + Lds::raw);
+  __shared__ uint32_t s_misc[96];
+  __shared__ unsigned long long s_range[2];
+  constexpr uint32_t kRankCap = 1024;                      // keys of the boundary bin ranked by brute force (one per thread)
 
-  const int seg = blockIdx.x;
-  const int l = seg / a.batch;
-  const int b = seg - l * a.batch;
-  const DecodeLevel &L = a.lv[l];
-  // exact survivor count = sum over the sub-lists; the lists are complete iff none overflowed
-  const uint32_t *sub_counts = a.counts + static_cast<size_t>(seg) * kSubLists;
-  uint32_t count = 0;
-  bool complete = true;
+  int l = 0;
 #pragma unroll
-  for (int s = 0; s < kSubLists; ++s) {
-    const uint32_t c = sub_counts[s];
-    count += c;
-    complete = complete && c <= L.cap;
-  }
+  for (int i = 1; i < ODTK_MAX_LEVELS; ++i)
+    if (i < a.n_levels && blockIdx.x >= a.part_begin[i]) l = i;
+  const uint32_t P = a.parts[l];
+  const uint32_t jb = blockIdx.x - a.part_begin[l];
+  const uint32_t b = jb / P, part = jb - b * P;
+  const int seg = l * a.batch + static_cast<int>(b);
+  const DecodeLevel &L = a.lv[l];
   const uint32_t top_n = a.top_n;
-  const uint32_t k_out = count < top_n ? count : top_n;
   const int H = L.height, W = L.width, A = a.num_anchors, C = a.num_classes;
   const uint32_t hw = static_cast<uint32_t>(H) * W;
   const uint32_t channels = static_cast<uint32_t>(A) * C;
   const typename T::storage *cls_image = static_cast<const typename T::storage *>(L.cls) + static_cast<uint64_t>(b) * L.n;
+  const uint32_t tid = threadIdx.x;
+  auto stamp = [&](int k) { if (a.trace && tid == 0) a.trace[seg * 8 + k] = wall_clock64(); };
+  // finer phases (16 words per segment behind word 8192): [0..6] as workgroup 0 of the segment sees them, [8..12] the finisher
+  auto stamp2 = [&](int k, bool mine) { if (a.trace && tid == 0 && mine) a.trace[8192 + seg * 16 + k] = wall_clock64(); };
+  stamp2(0, part == 0);
 
-  auto stamp = [&](int k) { if (a.trace && threadIdx.x == 0) a.trace[blockIdx.x * 8 + k] = wall_clock64(); };
-  stamp(0);
-  if (threadIdx.x == 0) s_misc[22] = 0;                                  // positive scores emitted (run_valid)
-  const ListSource lists(a.cand + L.cand_off + static_cast<uint64_t>(b) * kSubLists * L.cap, sub_counts, L.cap);
-  uint32_t n_sort;   // number of valid keys placed in s_keys
-
-  // more candidates than one sort holds: the multi-workgroup passes (select_pass_kernel) have normally left the
-  // keys at or above the boundary bin -- top_n plus a few -- in the segment's survivor list
-  const SelSeg *S = a.sel ? a.sel + seg : nullptr;
-  const bool narrowed = S && count > sort_size_for(top_n) && S->filtered != 0;
-  if (narrowed) {
-    const uint32_t n_surv = S->expected;                               // <= kSurvCap, >= top_n
-    const ListSource surv(a.surv + static_cast<uint64_t>(seg) * a.surv_cap, n_surv);
-    const uint32_t n_hi = S->n_above, in_bin = S->n_bin, need = S->need;   // n_hi + in_bin == n_surv, n_hi + need == top_n
-    if (in_bin <= kRankCap && n_surv <= static_cast<uint32_t>(CAP) && top_n + in_bin <= static_cast<uint32_t>(CAP)) {
-      // the normal route: keys above the boundary bin go to the front of the sort buffer, the bin's own keys to its
-      // back; then every bin key counts the bin keys larger than itself (keys are unique: the counts are the ranks) and
-      // the `need` best land, already in order, behind the others -- exactly top_n keys, no further narrowing
-      const uint64_t bin_hi = S->bin_hi;
-      if (threadIdx.x == 0) { s_misc[20] = 0; s_misc[21] = 0; }
-      __syncthreads();
-      for (uint32_t i0 = 0; i0 < n_surv; i0 += kSelThreads) {            // (block-uniform trip count: ballots are legal)
-        const uint32_t i = i0 + threadIdx.x;
-        const uint64_t key = i < n_surv ? surv.keys[i] : 0;
-        const bool above = key > bin_hi, inside = key != 0 && !above;
-        const uint64_t m_a = __ballot(above), m_i = __ballot(inside);
-        const int lane = lane_id();
-        uint32_t base_a = 0, base_i = 0;
-        if (lane == 0) {
-          if (m_a) base_a = atomicAdd(&s_misc[20], static_cast<uint32_t>(__popcll(m_a)));
-          if (m_i) base_i = atomicAdd(&s_misc[21], static_cast<uint32_t>(__popcll(m_i)));
-        }
-        base_a = __shfl(base_a, 0, kWave);
-        base_i = __shfl(base_i, 0, kWave);
-        const uint64_t lt = (1ull << lane) - 1ull;
-        if (above) s_keys[base_a + __popcll(m_a & lt)] = key;
-        if (inside) s_keys[CAP - 1 - (base_i + __popcll(m_i & lt))] = key;
-      }
-      __syncthreads();
-      if (threadIdx.x < in_bin) {
-        const uint64_t mine = s_keys[CAP - 1 - threadIdx.x];
-        uint32_t rank = 0;
-        for (uint32_t q = 0; q < in_bin; ++q) rank += s_keys[CAP - 1 - q] > mine ? 1u : 0u;   // same address in every lane: broadcast
-        if (rank < need) s_keys[n_hi + rank] = mine;
-      }
-      n_sort = n_hi + need;
-    } else {
-      uint64_t T64 = 0;
-      n_sort = n_surv;
-      if (n_surv > CAP) T64 = radix_threshold(surv, top_n, CAP, s_hist, s_misc, &n_sort);   // tie-heavy inputs only
-      if (threadIdx.x == 0) s_misc[20] = 0;
-      __syncthreads();
-      surv.template for_range<kSelThreads>(0, n_surv, [&](uint64_t key, bool valid) {
-        const bool take = valid && key >= T64;
-        const uint32_t slot = wave_append_slot(&s_misc[20], take);
-        if (take && slot < CAP) s_keys[slot] = key;
-      });
+  // ---- the segment's sub-list lengths: total, overflow; how many workgroups take part ----
+  const uint32_t spans = L.spans, n_lists = spans * kScanWaves;
+  const uint32_t *seg_counts = a.counts + L.cnt_off + static_cast<size_t>(b) * n_lists;
+  const uint32_t direct = n_lists <= kCntSlots ? 1u : 0u;
+  {
+    uint32_t sum = 0;
+    bool raw = false;
+    for (uint32_t i = tid; i < n_lists; i += kSelThreads) {
+      const uint32_t c = seg_counts[i];
+      if (direct) s_cnt[i] = c;
+      if (c == kListOverflow) raw = true;
+      else sum += c;
     }
-  } else if (count <= CAP && complete) {
-    if (threadIdx.x == 0) s_misc[20] = 0;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) sum += __shfl_xor(sum, d, kWave);
+    const uint64_t any_raw = __ballot(raw);
+    if (lane_id() == 0) { s_misc[32 + (tid >> 6)] = sum; s_misc[48 + (tid >> 6)] = any_raw ? 1u : 0u; }
+    if (tid == 0) s_misc[22] = 0;                                          // positive scores emitted (run_valid)
     __syncthreads();
-    lists.template for_range<kSelThreads>(0, lists.start[kSubLists], [&](uint64_t key, bool valid) {   // order is irrelevant
-      const uint32_t slot = wave_append_slot(&s_misc[20], valid);     // one LDS atomic per wave: 4096 on one word cost ~30 us
-      if (valid) s_keys[slot] = key;
-    });
-    n_sort = count;
-  } else {
-    // (reached only when the passes declined: > kSurvCap keys share 22 leading key bits with the top_n-th)
-    const RawSource<T, kLogits> raw{cls_image, L.n, channels, hw, L.channels_last, a.thresh, L.cls_bias};
-    uint64_t T64 = 0;
-    n_sort = count;                // count <= top_n: everything is wanted (overflow path only)
-    if (count > top_n)
-      T64 = complete ? radix_threshold(lists, top_n, CAP, s_hist, s_misc, &n_sort)
-                     : radix_threshold(raw, top_n, CAP, s_hist, s_misc, &n_sort);
-    if (threadIdx.x == 0) s_misc[20] = 0;
-    __syncthreads();
-    if (complete) {
-      lists.template for_range<kSelThreads>(0, lists.start[kSubLists], [&](uint64_t key, bool valid) {
-        const bool take = valid && key >= T64;
-        const uint32_t slot = wave_append_slot(&s_misc[20], take);
-        if (take && slot < CAP) s_keys[slot] = key;
-      });
-    } else {
-      raw.for_each([&](uint64_t key) {
-        if (key >= T64) { const uint32_t p = atomicAdd(&s_misc[20], 1u); if (p < CAP) s_keys[p] = key; }
-      });
-    }
   }
-  stamp(1);
+  uint32_t n_total = 0, has_raw = 0;
+  for (int i = 0; i < kSelWaves; ++i) { n_total += s_misc[32 + i]; has_raw |= s_misc[48 + i]; }
+  n_total = __builtin_amdgcn_readfirstlane(n_total);
+  has_raw = __builtin_amdgcn_readfirstlane(has_raw);
+  // workgroups that take part: one per kKeysPerPart candidates and -- so that a wave has one span to fetch, with all of its
+  // loads in flight at once -- one per 16 spans, as long as there is anything to select from
+  uint32_t G = (n_total + kKeysPerPart - 1) / kKeysPerPart;
+  const uint32_t g_spans = n_total > sort_size_for(top_n) ? (spans + kSelWaves - 1) / kSelWaves : 1u;
+  const uint32_t g_min = (n_lists + kCntSlots - 1) / kCntSlots;              // a slice's lengths must fit s_cnt
+  G = G < g_spans ? g_spans : G;
+  G = G < g_min ? g_min : G;
+  G = G < 1u ? 1u : G;
+  if (has_raw || G > P) G = P;
+  if (part >= G) return;                                                   // (block-uniform)
+  stamp2(1, part == 0);
+  if (part == G - 1) stamp(0);
+  const uint32_t ns = part < spans ? (spans - part + G - 1) / G : 0u;
+  if (!direct) {
+    __syncthreads();
+    for (uint32_t i = tid; i < ns * kScanWaves; i += kSelThreads)
+      s_cnt[i] = seg_counts[(part + (i / kScanWaves) * G) * kScanWaves + (i % kScanWaves)];
+    __syncthreads();
+  }
+  // this slice's raw spans (a sub-list overflowed), collected once: the whole workgroup walks them (SliceSource::raw_span)
+  if (tid == 0) s_misc[28] = 0;
   __syncthreads();
+  if (has_raw) {
+    for (uint32_t k = tid; k < ns; k += kSelThreads) {
+      const uint32_t *c = s_cnt + (direct ? part + k * G : k) * kScanWaves;
+      if (c[0] == kListOverflow || c[1] == kListOverflow || c[2] == kListOverflow || c[3] == kListOverflow)
+        s_raw[atomicAdd(&s_misc[28], 1u)] = static_cast<uint16_t>(k);
+    }
+    __syncthreads();
+  }
+  const uint32_t n_raw = __builtin_amdgcn_readfirstlane(s_misc[28]);
+  const SliceSource<T, kLogits> slice{a.cand + L.key_off + static_cast<uint64_t>(b) * spans * kSpanCap, s_cnt, s_raw, n_raw, part, G, ns, direct,
+                                      cls_image, L.n, hw, L.channels_last, a.span_elems, a.aligned, a.by_channels, a.thresh, a.raw_lo, L.cls_bias};
+  // every candidate's key lies in [key(thresh, last index), key(1.0 | +inf, index 0)]; sigmoid outputs never exceed 1
+  const uint64_t k_lo = make_key(a.thresh, 0xffffffffu);
+  const uint64_t k_hi = kLogits ? make_key(1.0f, 0u) : ~0ull;
+
+  // gathers the keys >= T64 of `src` at the front of s_keys; returns how many (block-uniform)
+  auto gather = [&](const auto &src, uint64_t T64) -> uint32_t {
+    __syncthreads();
+    if (tid == 0) s_misc[20] = 0;
+    __syncthreads();
+    src.for_each([&](uint64_t key, bool valid) {
+      const bool take = valid && key >= T64;
+      const uint32_t slot = wave_append_slot(&s_misc[20], take);          // one LDS atomic per wave: 4096 on one word cost ~30 us
+      if (take && slot < static_cast<uint32_t>(CAP)) s_keys[slot] = key;
+    });
+    __syncthreads();
+    const uint32_t got = __builtin_amdgcn_readfirstlane(s_misc[20]);
+    return got < static_cast<uint32_t>(CAP) ? got : static_cast<uint32_t>(CAP);
+  };
+  // Exactly the min(top_n, all) best keys of `src` (of which `n_src` exist, if known: 0xffffffff otherwise) into s_keys,
+  // or -- tie-heavy inputs -- somewhat more (the LDS narrowing below finishes the job); returns how many.
+  auto select_into_lds = [&](const auto &src, uint32_t n_src) -> uint32_t {
+    if (n_src <= sort_size_for(top_n)) return gather(src, 0ull);          // one sort holds everything: order is irrelevant
+    const Split sp = select_threshold<Lds::copies>(src, top_n, CAP, sort_size_for(top_n), k_lo, k_hi, s_hist, s_misc, s_range);
+    stamp2(10, true);
+    if (sp.in_bin == 0 || sp.in_bin > kRankCap || top_n + sp.in_bin > static_cast<uint32_t>(CAP)) return gather(src, sp.T);
+    // the normal route: keys above the boundary bin go to the front of the sort buffer, the bin's own keys to its back;
+    // then every bin key counts the bin keys larger than itself (keys are unique: the counts are the ranks) and the
+    // `need` best land, already in order, behind the others -- exactly top_n keys, no further narrowing
+    __syncthreads();
+    if (tid == 0) { s_misc[20] = 0; s_misc[21] = 0; }
+    __syncthreads();
+    src.for_each([&](uint64_t key, bool valid) {
+      const bool above = valid && key > sp.bin_hi, inside = valid && !above && key >= sp.T;
+      const uint64_t m_a = __ballot(above), m_i = __ballot(inside);
+      if (!(m_a | m_i)) return;                                           // (wave-uniform)
+      const int lane = lane_id();
+      uint32_t base_a = 0, base_i = 0;
+      if (lane == 0) {
+        if (m_a) base_a = atomicAdd(&s_misc[20], static_cast<uint32_t>(__popcll(m_a)));
+        if (m_i) base_i = atomicAdd(&s_misc[21], static_cast<uint32_t>(__popcll(m_i)));
+      }
+      base_a = __shfl(base_a, 0, kWave);
+      base_i = __shfl(base_i, 0, kWave);
+      const uint64_t lt = (1ull << lane) - 1ull;
+      if (above) s_keys[base_a + __popcll(m_a & lt)] = key;
+      if (inside) s_keys[CAP - 1 - (base_i + __popcll(m_i & lt))] = key;
+    });
+    __syncthreads();
+    stamp2(11, true);
+    if (tid < sp.in_bin) {
+      const uint64_t mine = s_keys[CAP - 1 - tid];
+      uint32_t rank = 0;
+      for (uint32_t q = 0; q < sp.in_bin; ++q) rank += s_keys[CAP - 1 - q] > mine ? 1u : 0u;   // same address in every lane: broadcast
+      if (rank < sp.need) s_keys[sp.n_above + rank] = mine;
+    }
+    __syncthreads();
+    stamp2(12, true);
+    return sp.n_above + sp.need;
+  };
+
+  uint32_t n_sort;   // number of valid keys placed in s_keys
+  if (G == 1) {
+    n_sort = select_into_lds(slice, has_raw ? 0xffffffffu : n_total);
+  } else {
+    // tournament: this slice's keys -- its best CAP if it holds more -- go to the segment's survivor list; the workgroup
+    // that appends last selects among all of them.  (Any key of the segment's top_n is in its slice's top_n.)
+    uint32_t n_slice = 0;
+    for (uint32_t k = tid; k < ns; k += kSelThreads) {
+      const uint32_t *c = s_cnt + (direct ? part + k * G : k) * kScanWaves;
+      n_slice += c[0] + c[1] + c[2] + c[3];                               // (overflow markers: has_raw, the sum is not used)
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) n_slice += __shfl_xor(n_slice, d, kWave);
+    __syncthreads();
+    if (lane_id() == 0) s_misc[64 + (tid >> 6)] = n_slice;
+    __syncthreads();
+    n_slice = 0;
+    for (int i = 0; i < kSelWaves; ++i) n_slice += s_misc[64 + i];
+    n_slice = __builtin_amdgcn_readfirstlane(n_slice);
+    stamp2(2, part == 0);
+    uint64_t T64 = 0;
+    if (has_raw || n_slice > a.budget) T64 = select_threshold<Lds::copies>(slice, top_n, a.budget, a.budget, k_lo, k_hi, s_hist, s_misc, s_range).T;
+    stamp2(3, part == 0);
+    const uint32_t n_mine = gather(slice, T64);
+    stamp2(4, part == 0);
+    SelSeg &S = a.sel[seg];
+    uint64_t *surv = a.surv + L.surv_off + static_cast<uint64_t>(b) * P * a.budget;
+    if (tid == 0) s_misc[25] = n_mine ? atomicAdd(&S.surv_count, n_mine) : 0u;
+    __syncthreads();
+    const uint32_t g0 = s_misc[25];
+    // Publish: WRITE-THROUGH stores (agent-scope atomic stores: `sc1`), drained, then the ticket; the reader uses agent-scope
+    // loads.  A release / acquire fence pair here (`__threadfence()`) writes back and invalidates the XCD's whole L2: measured
+    // 40-90 us per segment with 2-8 workgroups taking part (profiles/r04_select_trace_fences.txt); MI355X_MICROARCH.md
+    // "publish-large" prices the same choice at 8.2 vs 3.0 us.
+    for (uint32_t i = tid; i < n_mine; i += kSelThreads)
+      __hip_atomic_store(surv + g0 + i, s_keys[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    stamp2(5, part == 0);
+    if (tid == 0) s_misc[26] = atomicAdd(&S.arrived, 1u);
+    __syncthreads();
+    stamp2(6, part == 0);
+    if (s_misc[26] != G - 1) return;                                       // (block-uniform) somebody else is last
+    stamp2(8, true);
+    if (tid == 0) s_misc[27] = __hip_atomic_load(&S.surv_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const FlatSource all{surv, static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(s_misc[27]))};
+    stamp2(9, true);
+    n_sort = select_into_lds(all, all.count);
+  }
+  const uint32_t k_out = n_sort < top_n ? n_sort : top_n;                 // fewer than top_n candidates: all of them are here
+  stamp(1);
   // Second stage, in LDS.  Sorting is the expensive part (measured: 1024 keys 7 us, 4096 keys 24 us)
   // while a radix pass over keys that are already LDS-resident costs ~3 us, so narrow the buffer down
   // to the smallest sortable size that still holds top_n (1024 for the default 1000) first.
@@ -832,10 +811,10 @@ __global__ __launch_bounds__(kSelThreads) void select_decode_kernel(const Decode
     uint64_t mine[CAP / kSelThreads];
 #pragma unroll
     for (int u = 0; u < CAP / kSelThreads; ++u) {
-      const uint32_t i = u * kSelThreads + threadIdx.x;
+      const uint32_t i = u * kSelThreads + tid;
       mine[u] = i < n_sort ? s_keys[i] : 0;
     }
-    if (threadIdx.x == 0) s_misc[20] = 0;
+    if (tid == 0) s_misc[20] = 0;
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < CAP / kSelThreads; ++u) {
@@ -847,7 +826,7 @@ __global__ __launch_bounds__(kSelThreads) void select_decode_kernel(const Decode
     __syncthreads();
   }
   stamp(2);
-  if (a.trace && threadIdx.x == 0) { a.trace[blockIdx.x * 8 + 5] = count; a.trace[blockIdx.x * 8 + 6] = n_sort; a.trace[blockIdx.x * 8 + 7] = complete; }
+  if (a.trace && tid == 0) { a.trace[seg * 8 + 5] = n_total; a.trace[seg * 8 + 6] = n_sort; a.trace[seg * 8 + 7] = (static_cast<unsigned long long>(G) << 1) | has_raw; }
   sort_keys_desc<CAP>(s_keys, n_sort);   // the first k_out are the answer
   stamp(3);
 
@@ -858,7 +837,7 @@ __global__ __launch_bounds__(kSelThreads) void select_decode_kernel(const Decode
   const typename T::storage *box_image = static_cast<const typename T::storage *>(L.box) + static_cast<uint64_t>(b) * A * NB * hw;
   const uint64_t out_row = static_cast<uint64_t>(b) * a.n_levels * top_n + static_cast<uint64_t>(l) * top_n;
 
-  for (uint32_t t = threadIdx.x; t < top_n; t += kSelThreads) {
+  for (uint32_t t = tid; t < top_n; t += kSelThreads) {
     float score = 0.0f, cls = 0.0f;
     float bx[NB];
 #pragma unroll
@@ -914,7 +893,7 @@ __global__ __launch_bounds__(kSelThreads) void select_decode_kernel(const Decode
   }
   if (a.run_valid) {
     __syncthreads();
-    if (threadIdx.x == 0) a.run_valid[static_cast<size_t>(b) * a.n_levels + l] = s_misc[22];
+    if (tid == 0) a.run_valid[static_cast<size_t>(b) * a.n_levels + l] = s_misc[22];
   }
   stamp(4);
 }

@@ -74,9 +74,12 @@ def test_detect_workspace_covers_decode_plus_candidates():
     dec = lib.odtk_decode_levels(4, 2, lv, 9, 80, _C.F32, 0, 0.05, 1000, None, 0, None, 0, None)
     det = lib.odtk_detect(4, 2, lv, 9, 80, _C.F32, 0, 0.05, 1000, 0.5, 100, None, None, 0, None)
     assert dec > 0 and det >= dec + 4 * 2000 * 6 * 4
-    # bf16 / fp16 logits and channels_last are first-class; the scratch does not depend on them
+    # bf16 / fp16 logits and channels_last are first-class; a 16-bit call needs no more scratch than the fp32 one (its spans
+    # are twice as long, so it has half as many candidate regions)
     lv[0].channels_last = 1
-    assert lib.odtk_decode_levels(4, 2, lv, 9, 80, _C.BF16, _C.FLAG_LOGITS, 0.05, 1000, None, 0, None, 0, None) == dec
+    half = lib.odtk_decode_levels(4, 2, lv, 9, 80, _C.BF16, _C.FLAG_LOGITS, 0.05, 1000, None, 0, None, 0, None)
+    assert 0 < half <= dec
+    assert lib.odtk_decode_levels(4, 2, lv, 9, 80, _C.F16, _C.FLAG_LOGITS, 0.05, 1000, None, 0, None, 0, None) == half
     assert lib.odtk_decode_levels(4, 2, lv, 9, 80, 7, 0, 0.05, 1000, None, 0, None, 0, None) == _C.ERR_UNSUPPORTED
     lv[0].channels_last = 2
     assert lib.odtk_decode_levels(4, 2, lv, 9, 80, _C.F32, 0, 0.05, 1000, None, 0, None, 0, None) == _C.ERR_INVALID

@@ -17,7 +17,7 @@ def test_no_kernel_uses_scratch():
     rows = {line[:78].strip(): line[78:].split() for line in table.splitlines()[1:] if len(line) > 80}
     # the kernels this is about exist under the names the table prints
     for name in ('nms_kernel<6, false, 1>', 'nms_kernel<6, false, 2>', 'nms_kernel<4, false, 0>', 'rotated_sup_matrix_kernel',
-                 'select_decode_kernel<6, BF16, true, 4096>', 'prefilter_scan_kernel<BF16, true>'):
+                 'select_decode_kernel<6, BF16, true, 4096>', 'prefilter_scan_kernel<BF16, true, true>'):
         assert name in rows, (name, sorted(rows)[:10])
     # 1024-thread workgroups: 128 registers per lane is the cap (4 waves per SIMD x 128 = the 512-entry file)
     for name in ('nms_kernel<6, false, 2>', 'nms_kernel<6, true, 2>', 'nms_kernel<4, false, 0>'):

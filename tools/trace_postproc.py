@@ -23,11 +23,12 @@ strides = [8, 16, 32, 64, 128]
 for s in strides: m.level_anchors(s)
 run = lambda: box.detect(cls, dl, strides, m.anchors, 0.05, 1000, 0.5, 100, ROT, logits=True)
 for _ in range(3): run()
-trace = torch.zeros(4096, dtype=torch.int64, device='cuda')
+trace = torch.zeros(16384, dtype=torch.int64, device='cuda')
 _C.library().odtk_debug_set_trace(trace.data_ptr())
 run(); torch.cuda.synchronize()
 _C.library().odtk_debug_set_trace(None)
-t = trace.cpu().view(-1, 8)
+t = trace.cpu()[:8192].view(-1, 8)
+fine = trace.cpu()[8192:8192 + 64 * 16].view(-1, 16)
 us = lambda a, b: (b - a).float() / 100.0
 print('select_decode phases (us): read+select | lds narrow | sort | decode   [per level, mean over 8 images]')
 for l in range(5):
@@ -35,6 +36,13 @@ for l in range(5):
     print('  P%d: %6.1f %6.1f %6.1f %6.1f   total %6.1f' % (l + 3, us(blk[:, 0], blk[:, 1]).mean(), us(blk[:, 1], blk[:, 2]).mean(),
           us(blk[:, 2], blk[:, 3]).mean(), us(blk[:, 3], blk[:, 4]).mean(), us(blk[:, 0], blk[:, 4]).mean()),
           'counts', blk[:, 5].tolist(), 'n_sort', blk[:, 6].tolist(), 'read+select per image', [round(float(v), 1) for v in us(blk[:, 0], blk[:, 1])])
+print('select_decode, finer (us from kernel entry of workgroup 0; image 0 of each level): counts read | slice summed | local threshold | local gather '
+      '| published | ticket || finisher: ticket | count read | threshold | split gather | ranked')
+for l in range(5):
+    r = fine[l * 8]
+    rel = lambda k: ('%6.1f' % ((int(r[k]) - int(r[0])) / 100.0)) if int(r[k]) else '     -'
+    print('  P%d: ' % (l + 3) + ' '.join(rel(k) for k in (1, 2, 3, 4, 5, 6)) + ' || ' + ' '.join(rel(k) for k in (8, 9, 10, 11, 12)),
+          ' G =', int(t[l * 8][7]) >> 1)
 n = t[64 + 8:64 + 16]
 print('nms phases (us): compact | select round 0 | sort | chunks   consumed/K')
 for b in range(8):
