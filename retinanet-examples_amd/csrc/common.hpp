@@ -50,6 +50,34 @@ __device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v) {
   return v;
 }
 
+// The same on the DPP network (row shifts + row broadcasts: six VALU instructions, no LDS crossbar round trip per step as
+// ds_bpermute-based shuffles pay): the sequence LLVM's atomic optimizer emits for gfx9 wave64 scans.
+__device__ __forceinline__ uint32_t wave_inclusive_sum_dpp(uint32_t v) {
+  v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x111, 0xf, 0xf, false));   // row_shr:1
+  v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x112, 0xf, 0xf, false));   // row_shr:2
+  v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x114, 0xf, 0xf, false));   // row_shr:4
+  v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x118, 0xf, 0xf, false));   // row_shr:8
+  v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x142, 0xa, 0xf, false));   // row_bcast:15 -> rows 1, 3
+  v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x143, 0xc, 0xf, false));   // row_bcast:31 -> rows 2, 3
+  return v;
+}
+// maximum of a 64-bit value over the wave (every lane gets it): inclusive max-scan on the DPP network, lane 63 holds the result
+__device__ __forceinline__ uint64_t wave_max_u64(uint64_t v) {
+#define ODTK_DPP_MAX_STEP(ctrl, rows)                                                                                         \
+  {                                                                                                                           \
+    const uint32_t lo_ = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(static_cast<uint32_t>(v)), ctrl, rows, 0xf, false)); \
+    const uint32_t hi_ = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(static_cast<uint32_t>(v >> 32)), ctrl, rows, 0xf, false)); \
+    const uint64_t p_ = (static_cast<uint64_t>(hi_) << 32) | lo_;                                                             \
+    v = p_ > v ? p_ : v;                                                                                                      \
+  }
+  ODTK_DPP_MAX_STEP(0x111, 0xf) ODTK_DPP_MAX_STEP(0x112, 0xf) ODTK_DPP_MAX_STEP(0x114, 0xf) ODTK_DPP_MAX_STEP(0x118, 0xf)
+  ODTK_DPP_MAX_STEP(0x142, 0xa) ODTK_DPP_MAX_STEP(0x143, 0xc)
+#undef ODTK_DPP_MAX_STEP
+  const uint32_t lo = __builtin_amdgcn_readlane(static_cast<uint32_t>(v), 63);
+  const uint32_t hi = __builtin_amdgcn_readlane(static_cast<uint32_t>(v >> 32), 63);
+  return (static_cast<uint64_t>(hi) << 32) | lo;
+}
+
 // Append slot for the lanes with `pred` in a list whose cursor is `counter` (LDS or global): ONE atomic per wave, issued by
 // the first participating lane, instead of one per element -- atomics on a single word serialise (1024 LDS atomics on
 // one cursor cost ~9 us).  Every lane of the wave must call it (ballot inside); the result is meaningful where pred holds.

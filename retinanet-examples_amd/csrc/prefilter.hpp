@@ -59,7 +59,7 @@ constexpr uint32_t kListOverflow = 0xffffffffu;  // sub-list length: "more than 
 struct SelSeg {
   uint32_t surv_count;     // keys appended to the segment's survivor list
   uint32_t arrived;        // workgroups that have appended theirs (ticket)
-  uint32_t pad_[2];
+  unsigned long long t_max;   // largest of the workgroups' local thresholds: a lower bound of the segment's top_n-th key
 };
 
 struct ScanLevel {
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(kScanThreads, (!kAligned ? 2 : sizeof(typename T::s
 
   if (s == 0 && tid == 0) {                                // this segment's select_decode state starts at zero
     SelSeg z;
-    z.surv_count = 0; z.arrived = 0; z.pad_[0] = 0; z.pad_[1] = 0;
+    z.surv_count = 0; z.arrived = 0; z.t_max = 0;
     a.sel[L.seg_base + b] = z;
   }
 

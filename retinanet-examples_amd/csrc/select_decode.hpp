@@ -41,7 +41,7 @@ constexpr int kRadixBits = 11;
 constexpr int kRadixBins = 1 << kRadixBits;
 constexpr uint32_t kKeysPerPart = 3072;         // candidates per workgroup: a slice then nearly always fits the sort buffer whole
 constexpr uint32_t kCntSlots = 2048;            // sub-list lengths a workgroup keeps in LDS (512 spans)
-constexpr uint32_t kSpansPerPart = 16;          // host: workgroups provided per segment = ceil(spans / this), <= kMaxParts
+constexpr uint32_t kSpansPerPart = 44;          // host: workgroups provided per segment = ceil(spans / this), <= kMaxParts
 constexpr uint32_t kMaxParts = 64;
 constexpr int kHistCopies = 4;                  // sub-histograms of select_threshold (standard kernel): lane l adds to copy l % 4
 
@@ -106,14 +106,17 @@ struct LdsSource {    // keys already gathered into LDS
   }
 };
 
-// A flat list of keys in global memory written by OTHER workgroups of this launch (the survivor list): read past this
-// CU's vector cache.  f(key, valid) is called the same number of times by every lane (ballots inside f are legal).
+// A flat list of keys in global memory written by OTHER workgroups of this launch (the survivor list): agent-scope loads
+// (`sc1`: past this XCD's L2 where it does not own the line; the writers stored write-through).  Sixteen loads in flight per
+// lane: 16 384 keys per round trip.  f(key, valid) is called the same number of times by every lane (ballots inside f are
+// legal).  (Hand-written `global_load_dwordx4 ... sc1` in inline asm would halve the instruction count, but the compiler
+// does not know that an asm statement's outputs arrive later: it copied -- and spilled -- them before the wait.)
 struct FlatSource {
   const uint64_t *keys;
   uint32_t count;
   template <typename F>
   __device__ __forceinline__ void for_each(F &&f) const {
-    constexpr int kLoads = 8;
+    constexpr int kLoads = 16;
     for (uint32_t i0 = 0; i0 < count; i0 += kLoads * kSelThreads) {
       uint64_t k[kLoads];
 #pragma unroll
@@ -123,6 +126,19 @@ struct FlatSource {
       }
 #pragma unroll
       for (int u = 0; u < kLoads; ++u) f(k[u], k[u] != 0);
+    }
+  }
+};
+
+// Keys in LDS, (key, valid) interface
+struct LdsFlat {
+  const uint64_t *keys;
+  uint32_t count;
+  template <typename F>
+  __device__ __forceinline__ void for_each(F &&f) const {
+    for (uint32_t i0 = 0; i0 < count; i0 += kSelThreads) {                 // (block-uniform trip count)
+      const uint32_t i = i0 + threadIdx.x;
+      f(i < count ? keys[i] : 0ull, i < count);
     }
   }
 };
@@ -184,23 +200,15 @@ struct SliceSource {
     if (aligned) {                                           // every image starts on a 16-byte boundary, spans too
       const vuint4 *src = reinterpret_cast<const vuint4 *>(static_cast<const typename T::storage *>(image) + lo);
       const uint32_t n_vec = (hi - lo) / kPer;
-      for (uint32_t q0 = 0; q0 < n_vec; q0 += 2 * kSelThreads) {
-        vuint4 v[2];
+      for (uint32_t q0 = 0; q0 < n_vec; q0 += kSelThreads) {            // (one vector per lane in flight: the rare route, registers matter more)
+        const uint32_t q = q0 + threadIdx.x;
+        const vuint4 v = q < n_vec ? src[q] : vuint4{0u, 0u, 0u, 0u};
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const uint32_t q = q0 + u * kSelThreads + threadIdx.x;
-          v[u] = q < n_vec ? src[q] : vuint4{0u, 0u, 0u, 0u};
-        }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const uint32_t q = q0 + u * kSelThreads + threadIdx.x;
-#pragma unroll
-          for (int e = 0; e < kPer; ++e) {
-            float x;
-            if constexpr (std::is_same_v<T, F32>) x = __uint_as_float(v[u][e]);
-            else x = storage_to_float<T>(static_cast<uint16_t>((v[u][e >> 1] >> (16 * (e & 1))) & 0xffffu));
-            raw_element(x, lo + q * kPer + e, q < n_vec, f);
-          }
+        for (int e = 0; e < kPer; ++e) {
+          float x;
+          if constexpr (std::is_same_v<T, F32>) x = __uint_as_float(v[e]);
+          else x = storage_to_float<T>(static_cast<uint16_t>((v[e >> 1] >> (16 * (e & 1))) & 0xffffu));
+          raw_element(x, lo + q * kPer + e, q < n_vec, f);
         }
       }
     } else {
@@ -222,12 +230,12 @@ struct SliceSource {
 
   template <typename F>
   __device__ __forceinline__ void for_each(F &&f) const {
-    constexpr int kGroup = 8;
+    constexpr int kGroup = 4;                                            // spans per trip (registers: 128 per lane is all a 1024-thread workgroup gets); 2 loads each: the first 64 keys of every sub-list
     const uint32_t wave = threadIdx.x >> 6, lane = static_cast<uint32_t>(lane_id());
     const uint32_t sub = lane >> 4, l16 = lane & 15u;
-    bool more = false;                                                   // a sub-list of mine holds more than 32 keys
+    bool more = false;                                                   // a sub-list of mine holds more than 64 keys
     for (uint32_t k0 = wave; k0 < ns; k0 += kSelWaves * kGroup) {        // (wave-uniform)
-      vuint4 kv[kGroup];
+      vuint4 kv[kGroup][2];
       uint32_t cc[kGroup];
 #pragma unroll
       for (int u = 0; u < kGroup; ++u) {
@@ -235,18 +243,26 @@ struct SliceSource {
         uint32_t c = k < ns ? s_cnt[cnt_index(k) + sub] : 0u;
         if (__ballot(c == kListOverflow)) c = 0;                         // one overflowed wave: the whole span is read raw (below)
         cc[u] = c;
-        more = more || c > 32u;
-        kv[u] = vuint4{0u, 0u, 0u, 0u};
-        if (2 * l16 < c)
-          kv[u] = *reinterpret_cast<const vuint4 *>(seg_keys + static_cast<uint64_t>(part + k * G) * kSpanCap + sub * kWaveStage + 2 * l16);
+        more = more || c > 64u;
+        const uint64_t *list = seg_keys + static_cast<uint64_t>(part + k * G) * kSpanCap + sub * kWaveStage;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          kv[u][h] = vuint4{0u, 0u, 0u, 0u};
+          if (32 * h + 2 * l16 < c) kv[u][h] = *reinterpret_cast<const vuint4 *>(list + 32 * h + 2 * l16);
+        }
       }
 #pragma unroll
       for (int u = 0; u < kGroup; ++u) {
-        f((static_cast<uint64_t>(kv[u][1]) << 32) | kv[u][0], 2 * l16 < cc[u]);
-        f((static_cast<uint64_t>(kv[u][3]) << 32) | kv[u][2], 2 * l16 + 1 < cc[u]);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const uint32_t i = 32 * h + 2 * l16;
+          if (h == 1 && !__ballot(i < cc[u])) continue;                  // (wave-uniform) nothing beyond 32 keys in this span
+          f((static_cast<uint64_t>(kv[u][h][1]) << 32) | kv[u][h][0], i < cc[u]);
+          f((static_cast<uint64_t>(kv[u][h][3]) << 32) | kv[u][h][2], i + 1 < cc[u]);
+        }
       }
     }
-    if (__ballot(more)) {                                                // (wave-uniform) dense inputs: what the first 32 slots did not cover
+    if (__ballot(more)) {                                                // (wave-uniform) dense inputs: what the first 64 slots did not cover
 #pragma unroll 1
       for (uint32_t k = wave; k < ns; k += kSelWaves) {
         uint32_t c = s_cnt[cnt_index(k) + sub];
@@ -256,15 +272,15 @@ struct SliceSource {
         cmax = max(cmax, static_cast<uint32_t>(__shfl_xor(cmax, 32, kWave)));
         cmax = __builtin_amdgcn_readfirstlane(cmax);
         const uint64_t *list = seg_keys + static_cast<uint64_t>(part + k * G) * kSpanCap + sub * kWaveStage;
-        for (uint32_t base = 32; base < cmax; base += 128) {             // 4 x 2 keys per lane in flight
-          vuint4 kk[4];
+        for (uint32_t base = 64; base < cmax; base += 64) {              // 2 x 2 keys per lane in flight
+          vuint4 kk[2];
 #pragma unroll
-          for (int v = 0; v < 4; ++v) {
+          for (int v = 0; v < 2; ++v) {
             const uint32_t i = base + 32 * v + 2 * l16;
             kk[v] = i < c ? *reinterpret_cast<const vuint4 *>(list + i) : vuint4{0u, 0u, 0u, 0u};
           }
 #pragma unroll
-          for (int v = 0; v < 4; ++v) {
+          for (int v = 0; v < 2; ++v) {
             const uint32_t i = base + 32 * v + 2 * l16;
             f((static_cast<uint64_t>(kk[v][1]) << 32) | kk[v][0], i < c);
             f((static_cast<uint64_t>(kk[v][3]) << 32) | kk[v][2], i + 1 < c);
@@ -369,6 +385,47 @@ __device__ __forceinline__ void sort_keys_desc(uint64_t *s_keys, uint32_t n_vali
     if (n_pad == 8 * kSelThreads) bitonic_sort_desc_regs<8>(s_keys);
     else bitonic_sort_desc_regs<16>(s_keys);
   }
+}
+
+// Sort of up to 1024 keys (s_buf[0 .. n_valid), one per thread), descending, unique keys.  A wave sorts its 64 keys in
+// registers (21 shuffle stages of the bitonic network); the sixteen runs are then MERGED BY RANK, four levels: a key's
+// place in the union of its run and the partner run is its place in its own run plus the number of partner keys above
+// it -- one binary search in LDS (keys are unique: no ties) -- instead of the 34 further compare-exchange stages of the
+// network, ten of them through LDS with a barrier each.  Measured: 7.7 us for the full network, see DESIGN.md.
+// s_buf must hold 2 * 1024 keys; returns where the sorted keys are (s_buf or s_buf + 1024).  Slots beyond n_valid are
+// padded with unique keys below every real one (a real key's score word is never 0).
+__device__ __forceinline__ const uint64_t *merge_sort_1024(uint64_t *s_buf, uint32_t n_valid) {
+  const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1);
+  uint64_t v = tid < n_valid ? s_buf[tid] : static_cast<uint64_t>(kSelThreads - tid);
+#pragma unroll
+  for (uint32_t k = 2; k <= static_cast<uint32_t>(kWave); k <<= 1) {
+#pragma unroll
+    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+      const uint64_t p = shfl_xor_u64(v, static_cast<int>(j));
+      const bool take_max = ((lane & j) == 0) == ((lane & k) == 0);   // lower element of a descending pair
+      v = take_max ? (v > p ? v : p) : (v < p ? v : p);
+    }
+  }
+  __syncthreads();                                         // every thread has read its key
+  uint64_t *src = s_buf, *dst = s_buf + kSelThreads;
+  src[tid] = v;
+  __syncthreads();
+  uint32_t g = tid;                                        // where this thread's key sits
+#pragma unroll
+  for (uint32_t R = kWave; R < static_cast<uint32_t>(kSelThreads); R <<= 1) {
+    const uint32_t run = g / R, p = g - run * R;
+    const uint64_t *other = src + (run ^ 1u) * R;          // the partner run, descending
+    uint32_t above = 0;                                    // partner keys above mine
+#pragma unroll
+    for (uint32_t step = R >> 1; step > 0; step >>= 1)
+      if (other[above + step - 1] > v) above += step;
+    above += other[above] > v ? 1u : 0u;
+    g = (run >> 1) * 2 * R + p + above;
+    dst[g] = v;
+    __syncthreads();
+    uint64_t *t = src; src = dst; dst = t;
+  }
+  return src;
 }
 
 // Given a histogram in s_hist (kRadixBins bins, REVERSED: bin 0 = largest digit) finds the bin in which the running
@@ -494,7 +551,7 @@ __device__ __forceinline__ void scan_boundary_total(const uint32_t *s_hist, uint
     h0 += s_hist[(2 * threadIdx.x) * kCopies + c];
     h1 += s_hist[(2 * threadIdx.x + 1) * kCopies + c];
   }
-  const uint32_t inc = wave_inclusive_sum(h0 + h1);
+  const uint32_t inc = wave_inclusive_sum_dpp(h0 + h1);
   const int w = threadIdx.x >> 6;
   if (lane_id() == kWave - 1) s_misc[w] = inc;
   if (threadIdx.x == 0) { s_misc[16] = 0; s_misc[17] = 0; s_misc[18] = 0; }
@@ -517,80 +574,102 @@ __device__ __forceinline__ void scan_boundary_total(const uint32_t *s_hist, uint
   __syncthreads();
 }
 
-// What a selection pass leaves: T = lower end of the boundary bin, [T, bin_hi] = the bin; n_above keys lie above it (all of
-// them wanted), in_bin inside it, of which the `need` largest are wanted: n_above + need = min(want, all keys).
-struct Split {
-  uint64_t T, bin_hi;
-  uint32_t n_above, in_bin, need;
+// State of a selection: the current key range [lo, hi] (both inclusive; T = lo is the threshold it stands for), `taken`
+// keys above it -- all of them wanted --, `in_bin` inside it, of which the `remaining` largest are wanted.
+struct SelState {
+  uint64_t lo, hi;
+  uint32_t remaining, taken, in_bin;
 };
 
-// Threshold over the keys of `src`, all of which lie inside [lo, hi] (both inclusive): on return #{key >= T} = n_above +
-// in_bin with  min(want, all) <= n_above + in_bin <= max_take  (want <= take_all <= max_take); a source of no more than
-// `take_all` keys is taken whole (T = lo, in_bin = 0).  Every pass histograms the current range in
-// 2048 equal bins and descends into the bin where the running count, from the top, crosses `want`; it stops as soon as
-// everything above that bin plus the bin itself fits max_take -- normally after ONE pass (a linear digit over the score
-// range separates what an 11-bit MSD digit cannot: fp32 scores of one image share their exponent bits).  From the second
-// pass on the range is clipped to the [smallest, largest] key seen inside it, so that keys which share all their score
-// bits (saturated inputs) are split on their index bits.  Per key the first pass costs ~10 instructions: ONE workgroup --
-// one CU, 64 lanes per clock -- pays for every instruction 23 000 times on a P3 segment.
-// Source: for_each(f(key, valid)), uniform call count per wave.  s_misc: [0..18] scan scratch; s_range: 2 words.
-// The histogram is kept as kCopies interleaved sub-histograms, lane l adding to copy l % kCopies: 16-bit scores put
-// thousands of keys into a handful of bins, and lanes of a wave that add to ONE LDS word are served one after the other
-// (measured: the pass over 22 000 bf16-score keys of a P3 segment ~9 us with one histogram).
-template <int kCopies, typename Source>
-__device__ __forceinline__ Split select_threshold(const Source &src, uint32_t want, uint32_t max_take, uint32_t take_all, uint64_t lo,
-                                                  uint64_t hi, uint32_t *s_hist, uint32_t *s_misc, unsigned long long *s_range) {
-  Split r;
-  uint32_t remaining = want, taken = 0, in_bin = 0;
-  bool first = true;
-  for (;;) {
-    const int sh = range_shift(lo, hi);
-    for (uint32_t i = threadIdx.x; i < kRadixBins * kCopies; i += kSelThreads) s_hist[i] = 0;
-    if (threadIdx.x < 2) s_range[threadIdx.x] = 0;
-    __syncthreads();
-    uint64_t my_max = 0, my_min_inv = 0;
-    const uint32_t my_copy = threadIdx.x & (kCopies - 1);
-    const bool track = !first;                              // (uniform) the first range holds every key: nothing to clip yet
-    src.for_each([&](uint64_t key, bool valid) {
-      if (valid && key >= lo && key <= hi) {
-        atomicAdd(&s_hist[((kRadixBins - 1) - static_cast<uint32_t>((key - lo) >> sh)) * kCopies + my_copy], 1u);   // ((hi - lo) >> sh < 2048)
-        if (track) {
-          my_max = key > my_max ? key : my_max;
-          my_min_inv = ~key > my_min_inv ? ~key : my_min_inv;
-        }
+// Histogram of the keys of `src` inside [lo, hi] over 2048 equal bins (reversed: bin 0 = largest keys), kept as kCopies
+// interleaved sub-histograms, lane l adding to copy l % kCopies: 16-bit scores put thousands of keys into a handful of bins, and
+// lanes of a wave that add to ONE LDS word are served one after the other (measured: the pass over the 22 000 bf16-score
+// keys of a P3 segment ~9 us with one histogram).  kTrack: also the smallest and the largest key inside the range (s_range).
+// Per key ~10 instructions: ONE workgroup -- one CU, 64 lanes per clock -- pays every instruction once per key.
+template <int kCopies>
+__device__ __forceinline__ void hist_clear(uint32_t *s_hist, unsigned long long *s_range) {
+  for (uint32_t i = threadIdx.x; i < kRadixBins * kCopies; i += kSelThreads) s_hist[i] = 0;
+  if (threadIdx.x < 2) s_range[threadIdx.x] = 0;
+}
+template <int kCopies>
+__device__ __forceinline__ void hist_add(uint32_t *s_hist, uint64_t key, uint64_t lo, int sh) {   // lo <= key <= hi
+  atomicAdd(&s_hist[((kRadixBins - 1) - static_cast<uint32_t>((key - lo) >> sh)) * kCopies + (threadIdx.x & (kCopies - 1))], 1u);
+}
+template <int kCopies, bool kTrack, typename Source>
+__device__ __forceinline__ void hist_pass(const Source &src, uint64_t lo, uint64_t hi, uint32_t *s_hist, unsigned long long *s_range) {
+  hist_clear<kCopies>(s_hist, s_range);
+  __syncthreads();
+  const int sh = range_shift(lo, hi);
+  uint64_t my_max = 0, my_min_inv = 0;
+  src.for_each([&](uint64_t key, bool valid) {
+    if (valid && key >= lo && key <= hi) {
+      hist_add<kCopies>(s_hist, key, lo, sh);
+      if (kTrack) {
+        my_max = key > my_max ? key : my_max;
+        my_min_inv = ~key > my_min_inv ? ~key : my_min_inv;
       }
-    });
-    if (track) {
-#pragma unroll
-      for (int d = 32; d > 0; d >>= 1) {
-        const uint64_t o1 = shfl_xor_u64(my_max, d), o2 = shfl_xor_u64(my_min_inv, d);
-        my_max = o1 > my_max ? o1 : my_max;
-        my_min_inv = o2 > my_min_inv ? o2 : my_min_inv;
-      }
-      if (lane_id() == 0 && my_max != 0) { atomicMax(&s_range[0], my_max); atomicMax(&s_range[1], my_min_inv); }
     }
-    __syncthreads();
-    const uint64_t kmax = track ? uniform_u64(s_range[0]) : hi, kmin = track ? ~uniform_u64(s_range[1]) : lo;
-    uint32_t rbin, above, total;
-    scan_boundary_total<kCopies>(s_hist, remaining, s_misc, &rbin, &above, &in_bin, &total);   // (barriers inside: s_range may be reset after it)
-    if (first && total <= take_all) {                       // few enough to take them all (want <= take_all <= max_take)
-      r.T = lo; r.bin_hi = hi; r.n_above = total; r.in_bin = 0; r.need = 0;
-      return r;
-    }
-    first = false;
-    const uint64_t digit = (kRadixBins - 1) - rbin;
-    const uint64_t span = sh ? ((1ull << sh) - 1ull) : 0ull;
-    const uint64_t nlo = lo + (digit << sh);
-    uint64_t nhi = nlo > ~0ull - span ? ~0ull : nlo + span;
-    nhi = nhi < hi ? nhi : hi;
-    lo = nlo > kmin ? nlo : kmin;                           // no key of the old range lies outside [kmin, kmax]
-    hi = nhi < kmax ? nhi : kmax;
-    remaining -= above;
-    taken += above;
-    if (taken + in_bin <= max_take || sh == 0 || lo >= hi) break;
+  });
+  if (kTrack) {
+    my_max = wave_max_u64(my_max);
+    my_min_inv = wave_max_u64(my_min_inv);
+    if (lane_id() == 0 && my_max != 0) { atomicMax(&s_range[0], my_max); atomicMax(&s_range[1], my_min_inv); }
   }
-  r.T = lo; r.bin_hi = hi; r.n_above = taken; r.in_bin = in_bin; r.need = remaining;
-  return r;
+  __syncthreads();
+}
+
+// Folds the histogram in s_hist -- of the keys inside [st.lo, st.hi] -- into the state: the bin where the running count,
+// from the top, crosses st.remaining becomes the new range.  The new range is clipped (a) to [kmin, kmax], the smallest and
+// largest key of the OLD range if known (0 / ~0 otherwise), and (b), when it lies inside ONE score word, to the index bits
+// that can occur (an index is < n_index): keys that share all their score bits -- every 16-bit score is such a plateau -- are
+// then split on their index bits by the very next pass.  Returns the histogram's total.  (block-uniform; ends with a barrier)
+template <int kCopies>
+__device__ __forceinline__ uint32_t advance_state(SelState &st, const uint32_t *s_hist, uint32_t *s_misc, uint32_t n_index, uint64_t kmin,
+                                                  uint64_t kmax) {
+  const int sh = range_shift(st.lo, st.hi);
+  uint32_t rbin, above, in_bin, total;
+  scan_boundary_total<kCopies>(s_hist, st.remaining, s_misc, &rbin, &above, &in_bin, &total);
+  const uint64_t digit = (kRadixBins - 1) - rbin;
+  const uint64_t span = sh ? ((1ull << sh) - 1ull) : 0ull;
+  uint64_t lo = st.lo + (digit << sh);
+  uint64_t hi = lo > ~0ull - span ? ~0ull : lo + span;
+  hi = hi < st.hi ? hi : st.hi;
+  lo = lo > kmin ? lo : kmin;
+  hi = hi < kmax ? hi : kmax;
+  if ((lo >> 32) == (hi >> 32)) {                                        // one score word: the low word is ~index, index < n_index
+    const uint64_t floor_lo = (lo & 0xffffffff00000000ull) | static_cast<uint32_t>(0u - n_index);
+    lo = lo > floor_lo ? lo : floor_lo;
+  }
+  st.lo = lo;
+  st.hi = hi;
+  st.remaining -= above;
+  st.taken += above;
+  st.in_bin = in_bin;
+  return total;
+}
+
+// Threshold over the keys of `src`, all of which lie inside [lo, hi] (both inclusive): on return #{key >= st.lo} = st.taken +
+// st.in_bin with  min(want, all) <= st.taken + st.in_bin <= max_take  (want <= take_all <= max_take); a source of no more
+// than `take_all` keys is taken whole (st.lo = lo, in_bin = 0).  Every pass histograms the current range and descends into
+// the boundary bin; it stops as soon as everything above that bin plus the bin itself fits max_take -- normally after ONE
+// pass (a linear digit over the score range separates what an 11-bit MSD digit cannot: fp32 scores of one image share
+// their exponent bits).  Source: for_each(f(key, valid)), uniform call count per wave.  s_misc: [0..18] scan scratch.
+template <int kCopies, typename Source>
+__device__ __forceinline__ SelState select_threshold(const Source &src, uint32_t want, uint32_t max_take, uint32_t take_all, uint64_t lo,
+                                                     uint64_t hi, uint32_t n_index, uint32_t *s_hist, uint32_t *s_misc,
+                                                     unsigned long long *s_range) {
+  SelState st{lo, hi, want, 0u, 0u};
+  hist_pass<kCopies, false>(src, st.lo, st.hi, s_hist, s_range);
+  int sh = range_shift(st.lo, st.hi);
+  const uint32_t total = advance_state<kCopies>(st, s_hist, s_misc, n_index, 0ull, ~0ull);
+  if (total <= take_all) return SelState{lo, hi, 0u, total, 0u};          // few enough to take them all
+  while (!(st.taken + st.in_bin <= max_take || sh == 0 || st.lo >= st.hi)) {
+    hist_pass<kCopies, true>(src, st.lo, st.hi, s_hist, s_range);
+    const uint64_t kmax = uniform_u64(s_range[0]), kmin = ~uniform_u64(s_range[1]);
+    sh = range_shift(st.lo, st.hi);
+    advance_state<kCopies>(st, s_hist, s_misc, n_index, kmin, kmax);       // (barriers inside: s_range may be reset after it)
+  }
+  return st;
 }
 
 // ---- the kernel ------------------------------------------------------------------------------
@@ -608,7 +687,6 @@ __global__ __launch_bounds__(kSelThreads) void select_decode_kernel(const Decode
   uint16_t *s_raw = reinterpret_cast<uint16_t *>(s_dyn_sel + Lds::raw);
   __shared__ uint32_t s_misc[96];
   __shared__ unsigned long long s_range[2];
-  constexpr uint32_t kRankCap = 1024;                      // keys of the boundary bin ranked by brute force (one per thread)
 
   int l = 0;
 #pragma unroll
@@ -654,12 +732,10 @@ __global__ __launch_bounds__(kSelThreads) void select_decode_kernel(const Decode
   for (int i = 0; i < kSelWaves; ++i) { n_total += s_misc[32 + i]; has_raw |= s_misc[48 + i]; }
   n_total = __builtin_amdgcn_readfirstlane(n_total);
   has_raw = __builtin_amdgcn_readfirstlane(has_raw);
-  // workgroups that take part: one per kKeysPerPart candidates and -- so that a wave has one span to fetch, with all of its
-  // loads in flight at once -- one per 16 spans, as long as there is anything to select from
+  // workgroups that take part: one per kKeysPerPart candidates (a slice then fits the sort buffer whole), all of them when
+  // raw spans have to be walked
   uint32_t G = (n_total + kKeysPerPart - 1) / kKeysPerPart;
-  const uint32_t g_spans = n_total > sort_size_for(top_n) ? (spans + kSelWaves - 1) / kSelWaves : 1u;
   const uint32_t g_min = (n_lists + kCntSlots - 1) / kCntSlots;              // a slice's lengths must fit s_cnt
-  G = G < g_spans ? g_spans : G;
   G = G < g_min ? g_min : G;
   G = G < 1u ? 1u : G;
   if (has_raw || G > P) G = P;
@@ -691,93 +767,108 @@ __global__ __launch_bounds__(kSelThreads) void select_decode_kernel(const Decode
   const uint64_t k_lo = make_key(a.thresh, 0xffffffffu);
   const uint64_t k_hi = kLogits ? make_key(1.0f, 0u) : ~0ull;
 
-  // gathers the keys >= T64 of `src` at the front of s_keys; returns how many (block-uniform)
+  // Gathers the keys >= T64 of `src` at the front of s_keys and -- in the same walk -- histograms them over [T64 | k_lo, k_hi]
+  // (s_hist: the first digit of whatever selection follows).  Returns how many there ARE (block-uniform; more than CAP: the
+  // buffer holds only the first CAP and the caller must narrow the source first).
   auto gather = [&](const auto &src, uint64_t T64) -> uint32_t {
+    const uint64_t h_lo = T64 > k_lo ? T64 : k_lo;
+    const int sh = range_shift(h_lo, k_hi);
     __syncthreads();
+    hist_clear<Lds::copies>(s_hist, s_range);
     if (tid == 0) s_misc[20] = 0;
     __syncthreads();
     src.for_each([&](uint64_t key, bool valid) {
       const bool take = valid && key >= T64;
       const uint32_t slot = wave_append_slot(&s_misc[20], take);          // one LDS atomic per wave: 4096 on one word cost ~30 us
-      if (take && slot < static_cast<uint32_t>(CAP)) s_keys[slot] = key;
+      if (take) {
+        hist_add<Lds::copies>(s_hist, key, h_lo, sh);
+        if (slot < static_cast<uint32_t>(CAP)) s_keys[slot] = key;
+      }
     });
     __syncthreads();
-    const uint32_t got = __builtin_amdgcn_readfirstlane(s_misc[20]);
+    return __builtin_amdgcn_readfirstlane(s_misc[20]);
+  };
+  // The n_have keys at the front of s_keys -- all >= h_lo, their histogram over [h_lo, k_hi] in s_hist (gather's) -- cut down
+  // IN LDS to the best `limit` or fewer (never fewer than top_n of them, if that many exist): further digits over keys that
+  // are already here, then an in-place compaction.  *T_out: the threshold that was applied (h_lo if nothing was cut).
+  auto narrow_in_lds = [&](uint32_t n_have, uint32_t limit, uint64_t h_lo, uint64_t *T_out) -> uint32_t {
+    *T_out = h_lo;
+    if (n_have <= limit) return n_have;
+    const LdsFlat in_lds{s_keys, n_have};
+    SelState st{h_lo > k_lo ? h_lo : k_lo, k_hi, top_n, 0u, 0u};
+    int sh = range_shift(st.lo, st.hi);
+    advance_state<Lds::copies>(st, s_hist, s_misc, L.n, 0ull, ~0ull);
+    while (!(st.taken + st.in_bin <= limit || sh == 0 || st.lo >= st.hi)) {
+      hist_pass<Lds::copies, true>(in_lds, st.lo, st.hi, s_hist, s_range);
+      const uint64_t kmax = uniform_u64(s_range[0]), kmin = ~uniform_u64(s_range[1]);
+      sh = range_shift(st.lo, st.hi);
+      advance_state<Lds::copies>(st, s_hist, s_misc, L.n, kmin, kmax);
+    }
+    *T_out = st.lo;
+    // in-place compaction, 4096 keys per round: every lane reads its four keys, barrier, survivors go to the front (slots
+    // below the round's first key: all of them read already)
+    if (tid == 0) s_misc[20] = 0;
+    for (uint32_t base = 0; base < n_have; base += 4 * kSelThreads) {
+      uint64_t mine[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint32_t i = base + u * kSelThreads + tid;
+        mine[u] = i < n_have ? s_keys[i] : 0;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const bool keep = mine[u] != 0 && mine[u] >= st.lo;
+        const uint32_t slot = wave_append_slot(&s_misc[20], keep);
+        if (keep) s_keys[slot] = mine[u];
+      }
+    }
+    __syncthreads();
+    return __builtin_amdgcn_readfirstlane(s_misc[20]);
+  };
+  // The best keys of `src` into s_keys (+ their histogram, as gather leaves it): those >= T_known if they fit the buffer,
+  // otherwise those at or above a threshold found by histogram passes over the source itself.  *h_lo: the gather threshold.
+  // direct = false: the source is known to hold more than the buffer (or raw spans, whose walk is not worth a trial).
+  auto fetch = [&](const auto &src, uint64_t T_known, bool direct, uint64_t *h_lo) -> uint32_t {
+    *h_lo = T_known;
+    uint32_t got = 0;
+    if (direct) {
+      got = gather(src, T_known);
+      if (got <= static_cast<uint32_t>(CAP)) return got;
+    }
+    const SelState st = select_threshold<Lds::copies>(src, top_n, CAP, CAP, k_lo, k_hi, L.n, s_hist, s_misc, s_range);
+    *h_lo = st.lo;
+    got = gather(src, st.lo);
     return got < static_cast<uint32_t>(CAP) ? got : static_cast<uint32_t>(CAP);
   };
-  // Exactly the min(top_n, all) best keys of `src` (of which `n_src` exist, if known: 0xffffffff otherwise) into s_keys,
-  // or -- tie-heavy inputs -- somewhat more (the LDS narrowing below finishes the job); returns how many.
-  auto select_into_lds = [&](const auto &src, uint32_t n_src) -> uint32_t {
-    if (n_src <= sort_size_for(top_n)) return gather(src, 0ull);          // one sort holds everything: order is irrelevant
-    const Split sp = select_threshold<Lds::copies>(src, top_n, CAP, sort_size_for(top_n), k_lo, k_hi, s_hist, s_misc, s_range);
-    stamp2(10, true);
-    if (sp.in_bin == 0 || sp.in_bin > kRankCap || top_n + sp.in_bin > static_cast<uint32_t>(CAP)) return gather(src, sp.T);
-    // the normal route: keys above the boundary bin go to the front of the sort buffer, the bin's own keys to its back;
-    // then every bin key counts the bin keys larger than itself (keys are unique: the counts are the ranks) and the
-    // `need` best land, already in order, behind the others -- exactly top_n keys, no further narrowing
-    __syncthreads();
-    if (tid == 0) { s_misc[20] = 0; s_misc[21] = 0; }
-    __syncthreads();
-    src.for_each([&](uint64_t key, bool valid) {
-      const bool above = valid && key > sp.bin_hi, inside = valid && !above && key >= sp.T;
-      const uint64_t m_a = __ballot(above), m_i = __ballot(inside);
-      if (!(m_a | m_i)) return;                                           // (wave-uniform)
-      const int lane = lane_id();
-      uint32_t base_a = 0, base_i = 0;
-      if (lane == 0) {
-        if (m_a) base_a = atomicAdd(&s_misc[20], static_cast<uint32_t>(__popcll(m_a)));
-        if (m_i) base_i = atomicAdd(&s_misc[21], static_cast<uint32_t>(__popcll(m_i)));
-      }
-      base_a = __shfl(base_a, 0, kWave);
-      base_i = __shfl(base_i, 0, kWave);
-      const uint64_t lt = (1ull << lane) - 1ull;
-      if (above) s_keys[base_a + __popcll(m_a & lt)] = key;
-      if (inside) s_keys[CAP - 1 - (base_i + __popcll(m_i & lt))] = key;
-    });
-    __syncthreads();
-    stamp2(11, true);
-    if (tid < sp.in_bin) {
-      const uint64_t mine = s_keys[CAP - 1 - tid];
-      uint32_t rank = 0;
-      for (uint32_t q = 0; q < sp.in_bin; ++q) rank += s_keys[CAP - 1 - q] > mine ? 1u : 0u;   // same address in every lane: broadcast
-      if (rank < sp.need) s_keys[sp.n_above + rank] = mine;
-    }
-    __syncthreads();
-    stamp2(12, true);
-    return sp.n_above + sp.need;
-  };
 
+  const uint32_t sort_size = sort_size_for(top_n);
   uint32_t n_sort;   // number of valid keys placed in s_keys
+  uint64_t h_lo;     // ... all of them >= h_lo, their histogram over [max(h_lo, k_lo), k_hi] in s_hist
   if (G == 1) {
-    n_sort = select_into_lds(slice, has_raw ? 0xffffffffu : n_total);
+    n_sort = fetch(slice, 0ull, !has_raw && n_total <= static_cast<uint32_t>(CAP), &h_lo);
+    stamp2(4, true);
   } else {
-    // tournament: this slice's keys -- its best CAP if it holds more -- go to the segment's survivor list; the workgroup
-    // that appends last selects among all of them.  (Any key of the segment's top_n is in its slice's top_n.)
-    uint32_t n_slice = 0;
-    for (uint32_t k = tid; k < ns; k += kSelThreads) {
-      const uint32_t *c = s_cnt + (direct ? part + k * G : k) * kScanWaves;
-      n_slice += c[0] + c[1] + c[2] + c[3];                               // (overflow markers: has_raw, the sum is not used)
-    }
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) n_slice += __shfl_xor(n_slice, d, kWave);
-    __syncthreads();
-    if (lane_id() == 0) s_misc[64 + (tid >> 6)] = n_slice;
-    __syncthreads();
-    n_slice = 0;
-    for (int i = 0; i < kSelWaves; ++i) n_slice += s_misc[64 + i];
-    n_slice = __builtin_amdgcn_readfirstlane(n_slice);
+    // Tournament: this slice's best keys -- top_n of them or a few more -- go to the segment's survivor list; the workgroup
+    // that appends last selects among all of them.  (Any key of the segment's top_n is in its slice's top_n.)  The slice is
+    // sized to fit the sort buffer (kKeysPerPart): fetched once, cut down in LDS.  Every workgroup also publishes the
+    // threshold it cut at: the LARGEST of them is a lower bound of the segment's top_n-th key (that workgroup alone holds
+    // top_n keys at or above it), so the finisher fetches only the survivors above it -- no histogram pass over all of them.
+    uint32_t n_mine = fetch(slice, 0ull, !has_raw, &h_lo);
     stamp2(2, part == 0);
-    uint64_t T64 = 0;
-    if (has_raw || n_slice > a.budget) T64 = select_threshold<Lds::copies>(slice, top_n, a.budget, a.budget, k_lo, k_hi, s_hist, s_misc, s_range).T;
-    stamp2(3, part == 0);
-    const uint32_t n_mine = gather(slice, T64);
+    const uint32_t publish = 2 * sort_size < a.budget ? 2 * sort_size : a.budget;   // >= top_n
+    uint64_t T_mine;
+    n_mine = narrow_in_lds(n_mine, publish, h_lo, &T_mine);
     stamp2(4, part == 0);
     SelSeg &S = a.sel[seg];
     uint64_t *surv = a.surv + L.surv_off + static_cast<uint64_t>(b) * P * a.budget;
-    if (tid == 0) s_misc[25] = n_mine ? atomicAdd(&S.surv_count, n_mine) : 0u;
+    if (tid == 0) {
+      s_misc[25] = n_mine ? atomicAdd(&S.surv_count, n_mine) : 0u;
+      if (n_mine >= top_n) s_misc[29] = static_cast<uint32_t>(atomicMax(&S.t_max, T_mine));   // (returning: drained before the ticket)
+    }
     __syncthreads();
     const uint32_t g0 = s_misc[25];
-    // Publish: WRITE-THROUGH stores (agent-scope atomic stores: `sc1`), drained, then the ticket; the reader uses agent-scope
+    // Publish: WRITE-THROUGH stores (agent-scope atomic stores: `sc1`), drained, then the ticket; the reader uses `sc1`
     // loads.  A release / acquire fence pair here (`__threadfence()`) writes back and invalidates the XCD's whole L2: measured
     // 40-90 us per segment with 2-8 workgroups taking part (profiles/r04_select_trace_fences.txt); MI355X_MICROARCH.md
     // "publish-large" prices the same choice at 8.2 vs 3.0 us.
@@ -791,43 +882,28 @@ __global__ __launch_bounds__(kSelThreads) void select_decode_kernel(const Decode
     stamp2(6, part == 0);
     if (s_misc[26] != G - 1) return;                                       // (block-uniform) somebody else is last
     stamp2(8, true);
-    if (tid == 0) s_misc[27] = __hip_atomic_load(&S.surv_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) {
+      s_misc[27] = __hip_atomic_load(&S.surv_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_range[0] = __hip_atomic_load(&S.t_max, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     __syncthreads();
     const FlatSource all{surv, static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(s_misc[27]))};
+    const uint64_t T_lb = uniform_u64(s_range[0]);
     stamp2(9, true);
-    n_sort = select_into_lds(all, all.count);
+    n_sort = fetch(all, T_lb, true, &h_lo);
+    stamp2(10, true);
   }
   const uint32_t k_out = n_sort < top_n ? n_sort : top_n;                 // fewer than top_n candidates: all of them are here
   stamp(1);
-  // Second stage, in LDS.  Sorting is the expensive part (measured: 1024 keys 7 us, 4096 keys 24 us)
-  // while a radix pass over keys that are already LDS-resident costs ~3 us, so narrow the buffer down
-  // to the smallest sortable size that still holds top_n (1024 for the default 1000) first.
-  const uint32_t sort_size = sort_size_for(top_n);
-  if (n_sort > sort_size) {
-    uint32_t n_keep = n_sort;
-    const LdsSource in_lds{s_keys, n_sort};
-    const uint64_t T2 = radix_threshold(in_lds, top_n, sort_size, s_hist, s_misc, &n_keep);
-    // in-place compaction: every lane reads its keys (<= 4), barrier, survivors go to the front
-    uint64_t mine[CAP / kSelThreads];
-#pragma unroll
-    for (int u = 0; u < CAP / kSelThreads; ++u) {
-      const uint32_t i = u * kSelThreads + tid;
-      mine[u] = i < n_sort ? s_keys[i] : 0;
-    }
-    if (tid == 0) s_misc[20] = 0;
-    __syncthreads();
-#pragma unroll
-    for (int u = 0; u < CAP / kSelThreads; ++u) {
-      const bool keep = mine[u] != 0 && mine[u] >= T2;
-      const uint32_t slot = wave_append_slot(&s_misc[20], keep);
-      if (keep) s_keys[slot] = mine[u];
-    }
-    n_sort = n_keep;
-    __syncthreads();
-  }
+  // Sorting is the expensive part, a histogram pass over keys that are already LDS-resident is cheap: cut the buffer down to
+  // the smallest sortable size that still holds top_n (1024 for the default 1000) first.
+  uint64_t T_final;
+  n_sort = narrow_in_lds(n_sort, sort_size, h_lo, &T_final);
   stamp(2);
   if (a.trace && tid == 0) { a.trace[seg * 8 + 5] = n_total; a.trace[seg * 8 + 6] = n_sort; a.trace[seg * 8 + 7] = (static_cast<unsigned long long>(G) << 1) | has_raw; }
-  sort_keys_desc<CAP>(s_keys, n_sort);   // the first k_out are the answer
+  const uint64_t *sorted = s_keys;                                       // the first k_out are the answer
+  if (sort_size == static_cast<uint32_t>(kSelThreads)) sorted = merge_sort_1024(s_keys, n_sort);
+  else sort_keys_desc<CAP>(s_keys, n_sort);
   stamp(3);
 
   // ---- decode + write this segment's slice of the concatenated outputs ----
@@ -844,7 +920,7 @@ __global__ __launch_bounds__(kSelThreads) void select_decode_kernel(const Decode
     for (int k = 0; k < NB; ++k) bx[k] = 0.0f;
     int32_t index = -1;
     if (t < k_out) {
-      const uint64_t key = s_keys[t];
+      const uint64_t key = sorted[t];
       const uint32_t i = key_index(key);
       index = static_cast<int32_t>(i);
       const uint32_t pix = i % hw;

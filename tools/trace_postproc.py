@@ -36,12 +36,12 @@ for l in range(5):
     print('  P%d: %6.1f %6.1f %6.1f %6.1f   total %6.1f' % (l + 3, us(blk[:, 0], blk[:, 1]).mean(), us(blk[:, 1], blk[:, 2]).mean(),
           us(blk[:, 2], blk[:, 3]).mean(), us(blk[:, 3], blk[:, 4]).mean(), us(blk[:, 0], blk[:, 4]).mean()),
           'counts', blk[:, 5].tolist(), 'n_sort', blk[:, 6].tolist(), 'read+select per image', [round(float(v), 1) for v in us(blk[:, 0], blk[:, 1])])
-print('select_decode, finer (us from kernel entry of workgroup 0; image 0 of each level): counts read | slice summed | local threshold | local gather '
-      '| published | ticket || finisher: ticket | count read | threshold | split gather | ranked')
+print('select_decode, finer (us from kernel entry of workgroup 0; image 0 of each level): counts read | slice fetched | (refetched) | narrowed '
+      '| published | ticket || finisher: ticket | count read | survivors fetched')
 for l in range(5):
     r = fine[l * 8]
     rel = lambda k: ('%6.1f' % ((int(r[k]) - int(r[0])) / 100.0)) if int(r[k]) else '     -'
-    print('  P%d: ' % (l + 3) + ' '.join(rel(k) for k in (1, 2, 3, 4, 5, 6)) + ' || ' + ' '.join(rel(k) for k in (8, 9, 10, 11, 12)),
+    print('  P%d: ' % (l + 3) + ' '.join(rel(k) for k in (1, 2, 3, 4, 5, 6)) + ' || ' + ' '.join(rel(k) for k in (8, 9, 10)),
           ' G =', int(t[l * 8][7]) >> 1)
 n = t[64 + 8:64 + 16]
 print('nms phases (us): compact | select round 0 | sort | chunks   consumed/K')
