@@ -59,7 +59,8 @@ constexpr uint32_t kListOverflow = 0xffffffffu;  // sub-list length: "more than 
 struct SelSeg {
   uint32_t surv_count;     // keys appended to the segment's survivor list
   uint32_t arrived;        // workgroups that have appended theirs (ticket)
-  unsigned long long t_max;   // largest of the workgroups' local thresholds: a lower bound of the segment's top_n-th key
+  uint32_t pad_[2];
+  uint32_t hist[1 << 11];  // histogram (2048 equal bins of the key range, reversed) of the keys on the survivor list
 };
 
 struct ScanLevel {
@@ -225,10 +226,12 @@ __global__ __launch_bounds__(kScanThreads, (!kAligned ? 2 : sizeof(typename T::s
   const float raw_thr = kLogits ? a.raw_lo : a.thresh;
   const typename T::storage *span_ptr = static_cast<const typename T::storage *>(L.cls) + (static_cast<uint64_t>(b) * n + r0);
 
-  if (s == 0 && tid == 0) {                                // this segment's select_decode state starts at zero
-    SelSeg z;
-    z.surv_count = 0; z.arrived = 0; z.t_max = 0;
-    a.sel[L.seg_base + b] = z;
+  if (s == 0) {                                            // this segment's select_decode state starts at zero
+    SelSeg *S = a.sel + (L.seg_base + b);
+    uint4 *h = reinterpret_cast<uint4 *>(S->hist) + 2 * tid;   // 2048 words = 256 threads x 2 x 16 bytes
+    h[0] = make_uint4(0u, 0u, 0u, 0u);
+    h[1] = make_uint4(0u, 0u, 0u, 0u);
+    if (tid == 0) { S->surv_count = 0; S->arrived = 0; S->pad_[0] = 0; S->pad_[1] = 0; }
   }
 
   // With a bias the logit of element r is raw[r] + bias[r % channels] (channels_last, channels % kPer == 0, checked by

@@ -108,8 +108,9 @@ struct LdsSource {    // keys already gathered into LDS
 
 // A flat list of keys in global memory written by OTHER workgroups of this launch (the survivor list): agent-scope loads
 // (`sc1`: past this XCD's L2 where it does not own the line; the writers stored write-through).  Sixteen loads in flight per
-// lane: 16 384 keys per round trip.  f(key, valid) is called the same number of times by every lane (ballots inside f are
-// legal).  (Hand-written `global_load_dwordx4 ... sc1` in inline asm would halve the instruction count, but the compiler
+// lane: 16 384 keys per round trip.  Sources hand their keys over in BATCHES, f(keys[N], valid[N]) -- one call per load round,
+// made by every lane of a wave together (ballots inside f are legal): a consumer that appends to a list then takes ONE LDS
+// atomic per wave and round instead of one per key.  (Hand-written `global_load_dwordx4 ... sc1` in inline asm would halve the instruction count, but the compiler
 // does not know that an asm statement's outputs arrive later: it copied -- and spilled -- them before the wait.)
 struct FlatSource {
   const uint64_t *keys;
@@ -119,26 +120,34 @@ struct FlatSource {
     constexpr int kLoads = 16;
     for (uint32_t i0 = 0; i0 < count; i0 += kLoads * kSelThreads) {
       uint64_t k[kLoads];
+      bool v[kLoads];
 #pragma unroll
       for (int u = 0; u < kLoads; ++u) {
         const uint32_t i = i0 + u * kSelThreads + threadIdx.x;
-        k[u] = i < count ? __hip_atomic_load(keys + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;   // 0 is not a key
+        v[u] = i < count;
+        k[u] = v[u] ? __hip_atomic_load(keys + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
       }
-#pragma unroll
-      for (int u = 0; u < kLoads; ++u) f(k[u], k[u] != 0);
+      f(k, v);
     }
   }
 };
 
-// Keys in LDS, (key, valid) interface
+// Keys in LDS
 struct LdsFlat {
   const uint64_t *keys;
   uint32_t count;
   template <typename F>
   __device__ __forceinline__ void for_each(F &&f) const {
-    for (uint32_t i0 = 0; i0 < count; i0 += kSelThreads) {                 // (block-uniform trip count)
-      const uint32_t i = i0 + threadIdx.x;
-      f(i < count ? keys[i] : 0ull, i < count);
+    for (uint32_t i0 = 0; i0 < count; i0 += 4 * kSelThreads) {             // (block-uniform trip count)
+      uint64_t k[4];
+      bool v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint32_t i = i0 + u * kSelThreads + threadIdx.x;
+        v[u] = i < count;
+        k[u] = v[u] ? keys[i] : 0ull;
+      }
+      f(k, v);
     }
   }
 };
@@ -151,8 +160,8 @@ struct LdsFlat {
 //               rolled loop that a wave enters only if one of its sub-lists needs it.
 //   raw spans : (collected once per workgroup in `s_raw`) walked by the WHOLE workgroup, 16-byte vector loads, keys
 //               rebuilt on the fly behind the prefilter's own conservative raw-domain test.
-// f(key, valid): same number of calls in every lane of a wave (ballots inside f are legal).  for_each must be called by
-// all threads of the workgroup.
+// f(keys[N], valid[N]): one call per load round, made by every lane of a wave together (ballots inside f are legal).
+// for_each must be called by all threads of the workgroup.
 template <typename T, bool kLogits>
 struct SliceSource {
   const uint64_t *seg_keys;      // span 0 of this segment in the candidate pool
@@ -189,7 +198,9 @@ struct SliceSource {
         key = make_key(s, i);
       }
     }
-    f(key, take);
+    const uint64_t k1[1] = {key};
+    const bool v1[1] = {take};
+    f(k1, v1);
   }
 
   template <typename F>
@@ -230,7 +241,7 @@ struct SliceSource {
 
   template <typename F>
   __device__ __forceinline__ void for_each(F &&f) const {
-    constexpr int kGroup = 4;                                            // spans per trip (registers: 128 per lane is all a 1024-thread workgroup gets); 2 loads each: the first 64 keys of every sub-list
+    constexpr int kGroup = 4;                                            // spans per trip; 2 loads each: the first 64 keys of every sub-list
     const uint32_t wave = threadIdx.x >> 6, lane = static_cast<uint32_t>(lane_id());
     const uint32_t sub = lane >> 4, l16 = lane & 15u;
     bool more = false;                                                   // a sub-list of mine holds more than 64 keys
@@ -251,16 +262,20 @@ struct SliceSource {
           if (32 * h + 2 * l16 < c) kv[u][h] = *reinterpret_cast<const vuint4 *>(list + 32 * h + 2 * l16);
         }
       }
+      uint64_t key[4 * kGroup];
+      bool val[4 * kGroup];
 #pragma unroll
       for (int u = 0; u < kGroup; ++u) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const uint32_t i = 32 * h + 2 * l16;
-          if (h == 1 && !__ballot(i < cc[u])) continue;                  // (wave-uniform) nothing beyond 32 keys in this span
-          f((static_cast<uint64_t>(kv[u][h][1]) << 32) | kv[u][h][0], i < cc[u]);
-          f((static_cast<uint64_t>(kv[u][h][3]) << 32) | kv[u][h][2], i + 1 < cc[u]);
+          key[4 * u + 2 * h] = (static_cast<uint64_t>(kv[u][h][1]) << 32) | kv[u][h][0];
+          key[4 * u + 2 * h + 1] = (static_cast<uint64_t>(kv[u][h][3]) << 32) | kv[u][h][2];
+          val[4 * u + 2 * h] = i < cc[u];
+          val[4 * u + 2 * h + 1] = i + 1 < cc[u];
         }
       }
+      f(key, val);
     }
     if (__ballot(more)) {                                                // (wave-uniform) dense inputs: what the first 64 slots did not cover
 #pragma unroll 1
@@ -279,12 +294,17 @@ struct SliceSource {
             const uint32_t i = base + 32 * v + 2 * l16;
             kk[v] = i < c ? *reinterpret_cast<const vuint4 *>(list + i) : vuint4{0u, 0u, 0u, 0u};
           }
+          uint64_t key[4];
+          bool val[4];
 #pragma unroll
           for (int v = 0; v < 2; ++v) {
             const uint32_t i = base + 32 * v + 2 * l16;
-            f((static_cast<uint64_t>(kk[v][1]) << 32) | kk[v][0], i < c);
-            f((static_cast<uint64_t>(kk[v][3]) << 32) | kk[v][2], i + 1 < c);
+            key[2 * v] = (static_cast<uint64_t>(kk[v][1]) << 32) | kk[v][0];
+            key[2 * v + 1] = (static_cast<uint64_t>(kk[v][3]) << 32) | kk[v][2];
+            val[2 * v] = i < c;
+            val[2 * v + 1] = i + 1 < c;
           }
+          f(key, val);
         }
       }
     }
@@ -428,6 +448,55 @@ __device__ __forceinline__ const uint64_t *merge_sort_1024(uint64_t *s_buf, uint
   return src;
 }
 
+// The same for up to 2048 keys, two per thread (the two wave-local networks and the two binary searches of a level are
+// independent chains: their shuffle / LDS latencies overlap).  s_buf must hold 2 * 2048 keys; five merge levels.
+__device__ __forceinline__ const uint64_t *merge_sort_2048(uint64_t *s_buf, uint32_t n_valid) {
+  const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1);
+  uint64_t v[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const uint32_t i = tid + h * kSelThreads;
+    v[h] = i < n_valid ? s_buf[i] : static_cast<uint64_t>(2 * kSelThreads - i);
+  }
+#pragma unroll
+  for (uint32_t k = 2; k <= static_cast<uint32_t>(kWave); k <<= 1) {
+#pragma unroll
+    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+      const bool take_max = ((lane & j) == 0) == ((lane & k) == 0);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const uint64_t p = shfl_xor_u64(v[h], static_cast<int>(j));
+        v[h] = take_max ? (v[h] > p ? v[h] : p) : (v[h] < p ? v[h] : p);
+      }
+    }
+  }
+  __syncthreads();                                         // every thread has read its keys
+  uint64_t *src = s_buf, *dst = s_buf + 2 * kSelThreads;
+  uint32_t g[2] = {tid, tid + static_cast<uint32_t>(kSelThreads)};
+  src[g[0]] = v[0];
+  src[g[1]] = v[1];
+  __syncthreads();
+#pragma unroll
+  for (uint32_t R = kWave; R < 2u * kSelThreads; R <<= 1) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const uint32_t run = g[h] / R, p = g[h] - run * R;
+      const uint64_t *other = src + (run ^ 1u) * R;
+      uint32_t above = 0;
+#pragma unroll
+      for (uint32_t step = R >> 1; step > 0; step >>= 1)
+        if (other[above + step - 1] > v[h]) above += step;
+      above += other[above] > v[h] ? 1u : 0u;
+      g[h] = (run >> 1) * 2 * R + p + above;
+    }
+    dst[g[0]] = v[0];
+    dst[g[1]] = v[1];
+    __syncthreads();
+    uint64_t *t = src; src = dst; dst = t;
+  }
+  return src;
+}
+
 // Given a histogram in s_hist (kRadixBins bins, REVERSED: bin 0 = largest digit) finds the bin in which the running
 // count (from the largest digit down) crosses `remaining`.  All threads return the same (bin, count above it, count
 // inside it).  s_misc: [0..15] wave totals, [16..18] result.  Ends with a barrier; s_hist may be reused afterwards.
@@ -562,8 +631,7 @@ __device__ __forceinline__ void scan_boundary_total(const uint32_t *s_hist, uint
     if (i < w) woff += t;
     all += t;
   }
-  const uint32_t excl = woff + inc - (h0 + h1);
-  __syncthreads();                                         // (the zeroing of [16..18] above is ordered before these writes)
+  const uint32_t excl = woff + inc - (h0 + h1);            // (the zeroing of [16..18] lies before the barrier above)
   if (excl < remaining && remaining <= excl + h0) { s_misc[16] = 2 * threadIdx.x; s_misc[17] = excl; s_misc[18] = h0; }
   else if (excl + h0 < remaining && remaining <= excl + h0 + h1) { s_misc[16] = 2 * threadIdx.x + 1; s_misc[17] = excl + h0; s_misc[18] = h1; }
   __syncthreads();
@@ -601,12 +669,16 @@ __device__ __forceinline__ void hist_pass(const Source &src, uint64_t lo, uint64
   __syncthreads();
   const int sh = range_shift(lo, hi);
   uint64_t my_max = 0, my_min_inv = 0;
-  src.for_each([&](uint64_t key, bool valid) {
-    if (valid && key >= lo && key <= hi) {
-      hist_add<kCopies>(s_hist, key, lo, sh);
-      if (kTrack) {
-        my_max = key > my_max ? key : my_max;
-        my_min_inv = ~key > my_min_inv ? ~key : my_min_inv;
+  src.for_each([&](const auto &key, const auto &valid) {
+    constexpr int N = static_cast<int>(sizeof(valid) / sizeof(valid[0]));
+#pragma unroll
+    for (int u = 0; u < N; ++u) {
+      if (valid[u] && key[u] >= lo && key[u] <= hi) {
+        hist_add<kCopies>(s_hist, key[u], lo, sh);
+        if (kTrack) {
+          my_max = key[u] > my_max ? key[u] : my_max;
+          my_min_inv = ~key[u] > my_min_inv ? ~key[u] : my_min_inv;
+        }
       }
     }
   });
@@ -777,12 +849,28 @@ __global__ __launch_bounds__(kSelThreads) void select_decode_kernel(const Decode
     hist_clear<Lds::copies>(s_hist, s_range);
     if (tid == 0) s_misc[20] = 0;
     __syncthreads();
-    src.for_each([&](uint64_t key, bool valid) {
-      const bool take = valid && key >= T64;
-      const uint32_t slot = wave_append_slot(&s_misc[20], take);          // one LDS atomic per wave: 4096 on one word cost ~30 us
-      if (take) {
-        hist_add<Lds::copies>(s_hist, key, h_lo, sh);
-        if (slot < static_cast<uint32_t>(CAP)) s_keys[slot] = key;
+    src.for_each([&](const auto &key, const auto &valid) {
+      constexpr int N = static_cast<int>(sizeof(valid) / sizeof(valid[0]));
+      // ONE LDS atomic per wave and batch (a returning atomic per key: ~150 clk each on the critical path)
+      uint64_t m[N];
+      uint32_t tot = 0;
+#pragma unroll
+      for (int u = 0; u < N; ++u) {
+        m[u] = __ballot(valid[u] && key[u] >= T64);
+        tot += static_cast<uint32_t>(__popcll(m[u]));
+      }
+      if (!tot) return;                                                   // (wave-uniform)
+      uint32_t base = 0;
+      if (lane_id() == 0) base = atomicAdd(&s_misc[20], tot);
+      base = __builtin_amdgcn_readfirstlane(base);
+#pragma unroll
+      for (int u = 0; u < N; ++u) {
+        if (valid[u] && key[u] >= T64) {
+          hist_add<Lds::copies>(s_hist, key[u], h_lo, sh);
+          const uint32_t slot = base + __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m[u] >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m[u]), 0u));
+          if (slot < static_cast<uint32_t>(CAP)) s_keys[slot] = key[u];
+        }
+        base += static_cast<uint32_t>(__popcll(m[u]));
       }
     });
     __syncthreads();
@@ -791,20 +879,23 @@ __global__ __launch_bounds__(kSelThreads) void select_decode_kernel(const Decode
   // The n_have keys at the front of s_keys -- all >= h_lo, their histogram over [h_lo, k_hi] in s_hist (gather's) -- cut down
   // IN LDS to the best `limit` or fewer (never fewer than top_n of them, if that many exist): further digits over keys that
   // are already here, then an in-place compaction.  *T_out: the threshold that was applied (h_lo if nothing was cut).
-  auto narrow_in_lds = [&](uint32_t n_have, uint32_t limit, uint64_t h_lo, uint64_t *T_out) -> uint32_t {
-    *T_out = h_lo;
+  // *first_bins: s_hist still holds the first digit and the keys kept are exactly those of its bins [0, *first_bins); 0: it
+  // does not (further digits were needed).
+  auto narrow_in_lds = [&](uint32_t n_have, uint32_t limit, uint64_t h_lo, uint32_t *first_bins) -> uint32_t {
+    *first_bins = kRadixBins;
     if (n_have <= limit) return n_have;
     const LdsFlat in_lds{s_keys, n_have};
     SelState st{h_lo > k_lo ? h_lo : k_lo, k_hi, top_n, 0u, 0u};
     int sh = range_shift(st.lo, st.hi);
     advance_state<Lds::copies>(st, s_hist, s_misc, L.n, 0ull, ~0ull);
+    *first_bins = (kRadixBins - 1) - static_cast<uint32_t>((st.lo - (h_lo > k_lo ? h_lo : k_lo)) >> sh) + 1;   // bins down to the boundary bin
     while (!(st.taken + st.in_bin <= limit || sh == 0 || st.lo >= st.hi)) {
+      *first_bins = 0;
       hist_pass<Lds::copies, true>(in_lds, st.lo, st.hi, s_hist, s_range);
       const uint64_t kmax = uniform_u64(s_range[0]), kmin = ~uniform_u64(s_range[1]);
       sh = range_shift(st.lo, st.hi);
       advance_state<Lds::copies>(st, s_hist, s_misc, L.n, kmin, kmax);
     }
-    *T_out = st.lo;
     // in-place compaction, 4096 keys per round: every lane reads its four keys, barrier, survivors go to the front (slots
     // below the round's first key: all of them read already)
     if (tid == 0) s_misc[20] = 0;
@@ -849,22 +940,30 @@ __global__ __launch_bounds__(kSelThreads) void select_decode_kernel(const Decode
     n_sort = fetch(slice, 0ull, !has_raw && n_total <= static_cast<uint32_t>(CAP), &h_lo);
     stamp2(4, true);
   } else {
-    // Tournament: this slice's best keys -- top_n of them or a few more -- go to the segment's survivor list; the workgroup
-    // that appends last selects among all of them.  (Any key of the segment's top_n is in its slice's top_n.)  The slice is
-    // sized to fit the sort buffer (kKeysPerPart): fetched once, cut down in LDS.  Every workgroup also publishes the
-    // threshold it cut at: the LARGEST of them is a lower bound of the segment's top_n-th key (that workgroup alone holds
-    // top_n keys at or above it), so the finisher fetches only the survivors above it -- no histogram pass over all of them.
+    // Tournament: this slice's best keys -- top_n of them or a few more -- go to the segment's survivor list, their
+    // histogram (first digit: 2048 bins of [k_lo, k_hi]) is added to the segment's; the workgroup that arrives last finds the
+    // threshold in the segment's histogram and fetches only the survivors at or above it -- no pass over all of them.
+    // (Any key of the segment's top_n is in its slice's top_n.)  The slice is sized to fit the sort buffer (kKeysPerPart):
+    // fetched once, cut down in LDS.
     uint32_t n_mine = fetch(slice, 0ull, !has_raw, &h_lo);
     stamp2(2, part == 0);
     const uint32_t publish = 2 * sort_size < a.budget ? 2 * sort_size : a.budget;   // >= top_n
-    uint64_t T_mine;
-    n_mine = narrow_in_lds(n_mine, publish, h_lo, &T_mine);
+    uint32_t first_bins;
+    n_mine = narrow_in_lds(n_mine, publish, h_lo, &first_bins);
+    if (h_lo > k_lo || first_bins == 0) {                                  // (rare) s_hist is not the first digit of what is left: redo it
+      const LdsFlat mine{s_keys, n_mine};
+      hist_pass<Lds::copies, false>(mine, k_lo, k_hi, s_hist, s_range);
+      first_bins = kRadixBins;
+    }
     stamp2(4, part == 0);
     SelSeg &S = a.sel[seg];
     uint64_t *surv = a.surv + L.surv_off + static_cast<uint64_t>(b) * P * a.budget;
-    if (tid == 0) {
-      s_misc[25] = n_mine ? atomicAdd(&S.surv_count, n_mine) : 0u;
-      if (n_mine >= top_n) s_misc[29] = static_cast<uint32_t>(atomicMax(&S.t_max, T_mine));   // (returning: drained before the ticket)
+    if (tid == 0) s_misc[25] = n_mine ? atomicAdd(&S.surv_count, n_mine) : 0u;
+    for (uint32_t i = tid; i < first_bins; i += kSelThreads) {
+      uint32_t c = 0;
+#pragma unroll
+      for (int q = 0; q < Lds::copies; ++q) c += s_hist[i * Lds::copies + q];
+      if (c) atomicAdd(&S.hist[i], c);
     }
     __syncthreads();
     const uint32_t g0 = s_misc[25];
@@ -874,7 +973,7 @@ __global__ __launch_bounds__(kSelThreads) void select_decode_kernel(const Decode
     // "publish-large" prices the same choice at 8.2 vs 3.0 us.
     for (uint32_t i = tid; i < n_mine; i += kSelThreads)
       __hip_atomic_store(surv + g0 + i, s_keys[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // (the histogram's atomics too)
     __syncthreads();
     stamp2(5, part == 0);
     if (tid == 0) s_misc[26] = atomicAdd(&S.arrived, 1u);
@@ -882,27 +981,33 @@ __global__ __launch_bounds__(kSelThreads) void select_decode_kernel(const Decode
     stamp2(6, part == 0);
     if (s_misc[26] != G - 1) return;                                       // (block-uniform) somebody else is last
     stamp2(8, true);
-    if (tid == 0) {
-      s_misc[27] = __hip_atomic_load(&S.surv_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      s_range[0] = __hip_atomic_load(&S.t_max, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) s_misc[27] = __hip_atomic_load(&S.surv_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (uint32_t i = tid; i < kRadixBins; i += kSelThreads) {
+      s_hist[i * Lds::copies] = __hip_atomic_load(&S.hist[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+      for (int q = 1; q < Lds::copies; ++q) s_hist[i * Lds::copies + q] = 0;
     }
     __syncthreads();
     const FlatSource all{surv, static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(s_misc[27]))};
-    const uint64_t T_lb = uniform_u64(s_range[0]);
+    SelState st{k_lo, k_hi, top_n, 0u, 0u};
+    advance_state<Lds::copies>(st, s_hist, s_misc, L.n, 0ull, ~0ull);
     stamp2(9, true);
-    n_sort = fetch(all, T_lb, true, &h_lo);
+    n_sort = fetch(all, all.count > sort_size ? st.lo : 0ull, true, &h_lo);
     stamp2(10, true);
   }
   const uint32_t k_out = n_sort < top_n ? n_sort : top_n;                 // fewer than top_n candidates: all of them are here
   stamp(1);
   // Sorting is the expensive part, a histogram pass over keys that are already LDS-resident is cheap: cut the buffer down to
   // the smallest sortable size that still holds top_n (1024 for the default 1000) first.
-  uint64_t T_final;
-  n_sort = narrow_in_lds(n_sort, sort_size, h_lo, &T_final);
+  // (up to 2048 keys the rank-merge sort takes them as they are: two per thread)
+  const uint32_t sort_limit = sort_size <= 2u * kSelThreads ? 2u * kSelThreads : sort_size;
+  uint32_t unused_bins;
+  n_sort = narrow_in_lds(n_sort, sort_limit, h_lo, &unused_bins);
   stamp(2);
   if (a.trace && tid == 0) { a.trace[seg * 8 + 5] = n_total; a.trace[seg * 8 + 6] = n_sort; a.trace[seg * 8 + 7] = (static_cast<unsigned long long>(G) << 1) | has_raw; }
   const uint64_t *sorted = s_keys;                                       // the first k_out are the answer
-  if (sort_size == static_cast<uint32_t>(kSelThreads)) sorted = merge_sort_1024(s_keys, n_sort);
+  if (n_sort <= static_cast<uint32_t>(kSelThreads)) sorted = merge_sort_1024(s_keys, n_sort);
+  else if (n_sort <= 2u * kSelThreads) sorted = merge_sort_2048(s_keys, n_sort);
   else sort_keys_desc<CAP>(s_keys, n_sort);
   stamp(3);
 
