@@ -519,14 +519,20 @@ struct LossTuning {
 // [16-bit heads, fp32 heads][forward with atomics, backward, forward through a workspace] = threads, logit workgroups per
 // CU and level, vectors per trip, box workgroups per level; measured with tools/loss_probe.py (profiles/r03_loss_probe.txt)
 enum { kLossFwd = 0, kLossBwd = 1, kLossFwdWs = 2 };
+std::mutex g_loss_tuning_mu;
 LossTuning g_loss_tuning[2][3] = {{{512, 1, 2, 64}, {256, 4, 1, 256}, {256, 4, 1, 256}},
                                   {{512, 1, 4, 64}, {1024, 16, 2, 1024}, {256, 4, 1, 256}}};
+
+LossTuning loss_tuning_snapshot(int dtype, int which) {
+  std::lock_guard<std::mutex> lock(g_loss_tuning_mu);
+  return g_loss_tuning[dtype == ODTK_F32][which];
+}
 
 // fills the kernel arguments of one level; returns the number of workgroups it wants (0 on error, *rc set)
 unsigned retina_loss_fill(odtk::LossArgs &la, int which, const void *cls, const void *box, const float *depth,
                           const float *box_target, int batch, int A, int C, int height, int width, int nb, int dtype,
                           int channels_last, float alpha, float gamma, float beta, double *sums, const float *g_cls,
-                          const float *g_box, void *dcls, void *dbox, int *rc) {
+                          const float *g_box, void *dcls, void *dbox, const LossTuning &t, int *rc) {
   const bool backward = which == kLossBwd;
   *rc = ODTK_ERR_INVALID;
   if (!cls || !box || !depth || !box_target || batch <= 0 || A <= 0 || C <= 0 || height <= 0 || width <= 0 || nb <= 0) return 0;
@@ -546,7 +552,6 @@ unsigned retina_loss_fill(odtk::LossArgs &la, int which, const void *cls, const 
   la.by_hw = odtk::fastdiv_make(la.hw);
   la.by_classes = odtk::fastdiv_make(C);
   la.by_anchors = odtk::fastdiv_make(A);
-  const LossTuning &t = g_loss_tuning[dtype == ODTK_F32][which];
   const unsigned threads = t.threads, unroll = t.unroll;
   const unsigned per = dtype == ODTK_F32 ? 4u : 8u;
   // at least two trips of `unroll` vectors per lane where the level is large enough
@@ -568,8 +573,7 @@ unsigned retina_loss_fill(odtk::LossArgs &la, int which, const void *cls, const 
 }
 
 template <typename T, bool kBackward>
-void retina_loss_dispatch(const odtk::LossLevelsArgs &la, unsigned total, int which, hipStream_t stream) {
-  const LossTuning &t = g_loss_tuning[std::is_same_v<T, odtk::F32>][which];
+void retina_loss_dispatch(const odtk::LossLevelsArgs &la, unsigned total, const LossTuning &t, hipStream_t stream) {
   const dim3 grid(total), block(t.threads);
   switch (t.unroll) {
     case 1: timed_launch(ODTK_KERNEL_LOSS, odtk::retina_loss_kernel<T, kBackward, 1>, grid, block, 0, stream, la); break;
@@ -582,10 +586,14 @@ void retina_loss_dispatch(const odtk::LossLevelsArgs &la, unsigned total, int wh
 // reduce launch writes `sums`).  With partial == nullptr and kLossFwdWs: returns the number of workgroups (size query).
 int retina_loss_levels_launch(int which, int n_levels, const odtk_loss_level_t *levels, int batch, int A, int C, int nb,
                               int dtype, float alpha, float gamma, float beta, double *sums, const float *g_cls,
-                              const float *g_box, double *partial, bool query, hipStream_t stream) {
+                              const float *g_box, double *partial, bool query, hipStream_t stream,
+                              const LossTuning *tuning = nullptr) {
   if (n_levels <= 0 || n_levels > ODTK_MAX_LEVELS || !levels) return ODTK_ERR_INVALID;
   if (dtype != ODTK_F32 && dtype != ODTK_BF16 && dtype != ODTK_F16) return ODTK_ERR_UNSUPPORTED;
   const bool backward = which == kLossBwd;
+  // ONE snapshot of the launch shape per call: the size query and the launch of the workspace form must agree even if
+  // odtk_debug_loss_tuning runs on another thread in between
+  const LossTuning t = tuning ? *tuning : loss_tuning_snapshot(dtype, which);
   odtk::LossLevelsArgs la;
   std::memset(&la, 0, sizeof la);
   la.n_levels = n_levels;
@@ -595,7 +603,7 @@ int retina_loss_levels_launch(int which, int n_levels, const odtk_loss_level_t *
     const unsigned blocks = retina_loss_fill(la.lv[l], which, levels[l].cls, levels[l].box, levels[l].depth, levels[l].box_target,
                                              batch, A, C, levels[l].height, levels[l].width, nb, dtype, levels[l].channels_last,
                                              alpha, gamma, beta, sums ? sums + 3 * l : nullptr, g_cls ? g_cls + l : nullptr,
-                                             g_box ? g_box + l : nullptr, levels[l].dcls, levels[l].dbox, &rc);
+                                             g_box ? g_box + l : nullptr, levels[l].dcls, levels[l].dbox, t, &rc);
     if (rc != ODTK_OK) return rc;
     la.lv[l].partial = which == kLossFwdWs ? partial : nullptr;
     la.block_begin[l] = total;
@@ -603,9 +611,9 @@ int retina_loss_levels_launch(int which, int n_levels, const odtk_loss_level_t *
   }
   for (int l = n_levels; l <= ODTK_MAX_LEVELS; ++l) la.block_begin[l] = total;
   if (query) return static_cast<int>(total);
-  if (dtype == ODTK_F32) backward ? retina_loss_dispatch<odtk::F32, true>(la, total, which, stream) : retina_loss_dispatch<odtk::F32, false>(la, total, which, stream);
-  else if (dtype == ODTK_BF16) backward ? retina_loss_dispatch<odtk::BF16, true>(la, total, which, stream) : retina_loss_dispatch<odtk::BF16, false>(la, total, which, stream);
-  else backward ? retina_loss_dispatch<odtk::F16, true>(la, total, which, stream) : retina_loss_dispatch<odtk::F16, false>(la, total, which, stream);
+  if (dtype == ODTK_F32) backward ? retina_loss_dispatch<odtk::F32, true>(la, total, t, stream) : retina_loss_dispatch<odtk::F32, false>(la, total, t, stream);
+  else if (dtype == ODTK_BF16) backward ? retina_loss_dispatch<odtk::BF16, true>(la, total, t, stream) : retina_loss_dispatch<odtk::BF16, false>(la, total, t, stream);
+  else backward ? retina_loss_dispatch<odtk::F16, true>(la, total, t, stream) : retina_loss_dispatch<odtk::F16, false>(la, total, t, stream);
   ODTK_HIP_TRY(hipGetLastError());
   if (which == kLossFwdWs) {
     odtk::LossReduceArgs ra;
@@ -672,6 +680,7 @@ int odtk_debug_loss_tuning(int which, int fp32_heads, int threads, int blocks_pe
   if (which < 0 || which > 2 || threads < 64 || threads > odtk::kLossMaxThreads || threads % 64 || blocks_per_cu < 1 ||
       blocks_per_cu > 64 || (unroll != 1 && unroll != 2 && unroll != 4) || box_blocks < 1 || box_blocks > 16384)
     return ODTK_ERR_INVALID;
+  std::lock_guard<std::mutex> lock(g_loss_tuning_mu);
   g_loss_tuning[fp32_heads != 0][which] = LossTuning{threads, blocks_per_cu, unroll, box_blocks};
   return ODTK_OK;
 }
@@ -864,8 +873,10 @@ int odtk_retina_loss_levels_forward_ws(int n_levels, const odtk_loss_level_t *le
                                        int num_classes, int box_params, int dtype, float alpha, float gamma, float beta,
                                        double *sums, void *workspace, size_t workspace_size, void *stream) {
   if (n_levels <= 0 || n_levels > ODTK_MAX_LEVELS) return ODTK_ERR_INVALID;
+  if (dtype != ODTK_F32 && dtype != ODTK_BF16 && dtype != ODTK_F16) return ODTK_ERR_UNSUPPORTED;
+  const LossTuning t = loss_tuning_snapshot(dtype, kLossFwdWs);
   const int blocks = retina_loss_levels_launch(kLossFwdWs, n_levels, levels, batch_size, num_anchors, num_classes, box_params,
-                                               dtype, alpha, gamma, beta, nullptr, nullptr, nullptr, nullptr, true, nullptr);
+                                               dtype, alpha, gamma, beta, nullptr, nullptr, nullptr, nullptr, true, nullptr, &t);
   if (blocks < 0) return blocks;
   const size_t need = (static_cast<size_t>(blocks) * 3 * sizeof(double) + 255) & ~static_cast<size_t>(255);
   if (!workspace) return static_cast<int>(need);                       // two-phase convention of the reference's plugins
@@ -874,7 +885,7 @@ int odtk_retina_loss_levels_forward_ws(int n_levels, const odtk_loss_level_t *le
   if (reinterpret_cast<uintptr_t>(workspace) & 7u) return ODTK_ERR_INVALID;
   return retina_loss_levels_launch(kLossFwdWs, n_levels, levels, batch_size, num_anchors, num_classes, box_params, dtype, alpha,
                                    gamma, beta, sums, nullptr, nullptr, static_cast<double *>(workspace), false,
-                                   static_cast<hipStream_t>(stream));
+                                   static_cast<hipStream_t>(stream), &t);
 }
 
 int odtk_retina_loss_levels_backward(int n_levels, const odtk_loss_level_t *levels, int batch_size, int num_anchors,

@@ -18,6 +18,7 @@ else raises.  Work is only ENQUEUED on torch's current HIP stream -- no host syn
 (the reference blocks the host once per image per level, csrc/cuda/decode.cu:103).
 """
 import ctypes
+import threading
 import os
 
 import torch
@@ -162,6 +163,7 @@ def _ptrs(tensors):
 
 
 _workspaces = {}
+_workspaces_lock = threading.Lock()      # several host threads may enqueue on their own streams at once (include/odtk_hip.h)
 
 
 def _workspace(device, nbytes):
@@ -175,10 +177,11 @@ def _workspace(device, nbytes):
     if torch.cuda.is_current_stream_capturing():
         return torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device), stream.cuda_stream
     key = (device.index, stream.cuda_stream)
-    ws = _workspaces.get(key)
-    if ws is None or ws.numel() < nbytes:
-        ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)
-        _workspaces[key] = ws
+    with _workspaces_lock:
+        ws = _workspaces.get(key)
+        if ws is None or ws.numel() < nbytes:
+            ws = torch.empty(max(nbytes, 256), dtype=torch.uint8, device=device)
+            _workspaces[key] = ws
     return ws, stream.cuda_stream
 
 
@@ -354,8 +357,8 @@ def decode_levels(cls_heads, box_heads, anchors_list, strides, score_thresh, top
 
 def detect(cls_heads, box_heads, anchors_list, strides, score_thresh, top_n, nms_thresh, detections_per_im,
            rotated=False, logits=False, cls_bias=None, box_bias=None):
-    """decode_levels + nms back to back (the whole of odtk/model.py:140-165): six launches (rotated boxes: eight to ten),
-    no host synchronisation, one workspace."""
+    """decode_levels + nms back to back (the whole of odtk/model.py:140-165): three launches -- prefilter, select + decode, nms
+    -- (rotated boxes: five to seven), no host synchronisation, one workspace."""
     lib = library()
     nb = 6 if rotated else 4
     arr, keep, batch, num_anchors, num_classes, dtype = _levels(cls_heads, box_heads, anchors_list, strides, nb,
