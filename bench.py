@@ -21,6 +21,8 @@ Extra objects on the line:
                   (include/odtk_hip.h odtk_profile_*), inside the timed region.
   latency_bound-- the two latency-bound post-processing launches (select_decode, nms) against their
                   serial-chain lower bounds.
+  epilogue_roofline -- the engine's own HBM-bound epilogue kernels (bias_act, the stem's pool pass, the FPN upsampling):
+                  algorithmic bytes per step / their time per step, dispatch timestamps, three untimed steps.
   conv_roofline-- whole-pipeline view: conv FLOP/s achieved vs the dense bf16 MFMA peak.
   cpu_baseline -- the reference's pure-PyTorch CPU path on the host cores (rank 0, N=1 only, bounded
                   sample): `postproc` = decode x5 + nms of the pinned oracle restatement of odtk/box.py on
@@ -297,6 +299,8 @@ def other_configs(args, rank, local_rank, world, dev):
     run('config 4: ResNet101FPN bf16 inference bs 16', lambda: run_infer(leg_args(args, backbone='ResNet101FPN', batch=16), rank, world, dev))
     run('config 5: ResNet50FPN --rotated-bbox bf16 inference bs 8', lambda: run_infer(leg_args(args, rotated_bbox=True), rank, world, dev))
     run('config 5 with a unit (sin, cos) head bias', lambda: run_infer(leg_args(args, rotated_bbox=True, unit_rotation=True), rank, world, dev))
+    # the precision `odtk infer` runs by default (fp16 autocast, as the reference's mixed precision)
+    run('config 2 in fp16: ResNet50FPN fp16 inference bs 8', lambda: run_infer(leg_args(args, dtype='fp16'), rank, world, dev))
     run('config 3 (per-GPU share): ResNet50FPN fp32 training, 2 images per GPU',
         lambda: run_train(leg_args(args, mode='train', batch=2, dtype='fp32'), rank, local_rank, world, dev))
     run('batch-1 latency: ResNet50FPN bf16', lambda: run_latency(leg_args(args, batch=1), dev))
@@ -405,8 +409,8 @@ def run_infer(args, rank, world, dev):
 
     # time only the three post-processing launches inside the timed region (6 event records per step);
     # the ~110 epilogue launches per step are timed in a separate, untimed pass below
-    post = ('prefilter_scan_kernel', 'select_hist_kernel', 'select_filter_kernel', 'select_decode_kernel', 'nms_kernel',
-            'nms_first_round_kernel', 'rotated_sup_matrix_kernel')   # (the last two: rotated boxes only, three launches)
+    post = ('prefilter_scan_kernel', 'select_decode_kernel', 'nms_kernel',
+            'nms_first_round_kernel', 'rotated_sup_matrix_kernel')   # (the last two: rotated boxes only, five launches)
     post = tuple(k for k in post if k in _C.KERNEL_NAMES)
     _C.profile_enable(True, post)
     _C.profile_collect()
@@ -416,13 +420,38 @@ def run_infer(args, rank, world, dev):
     _C.profile_enable(False)
     prof = _C.profile_collect()
     eager = None
+    epilogue_roofline, marker_timed = None, None
     if rank == 0:
-        _C.profile_enable(True, ('bias_act_kernel', 'gemm_bias_act'))
+        # the engine's own epilogue kernels (dispatch timestamps, like the post-processing launches) and their algorithmic
+        # bytes (every element read once and written once, + the skip input), three untimed steps
+        epi = ('bias_act_kernel', 'bias_act_maxpool_kernel', 'upsample_nearest2x_kernel')
+        _C.traffic_bytes.clear()
+        _C.traffic_count = True
+        _C.profile_enable(True, epi + ('gemm_bias_act',))
+        _C.profile_collect()
         for _ in range(3):
             step()
         torch.cuda.synchronize()
         _C.profile_enable(False)
-        prof.update({k: v for k, v in _C.profile_collect().items() if k in ('bias_act_kernel', 'gemm_bias_act')})
+        _C.traffic_count = False
+        extra = _C.profile_collect()
+        prof.update({k: v for k, v in extra.items() if k in epi})
+        epilogue_roofline = {}
+        for k in epi:
+            ms_k, n_k = extra[k]
+            if n_k:
+                nbytes = _C.traffic_bytes.get(k, 0) / 3.0
+                gbs = nbytes / (ms_k / 3.0 * 1e-3) / 1e9
+                epilogue_roofline[k] = {'launches_per_step': n_k // 3, 'us_per_step': round(ms_k / 3.0 * 1e3, 1),
+                                        'alg_bytes_per_step': int(nbytes), 'bound': 'hbm', 'achieved': round(gbs, 1),
+                                        'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(gbs / HBM_PEAK_GBS, 4)}
+        # hipBLASLt launches its own kernels: the library can only put marker packets around the call, and a marker pair
+        # includes the dispatch latency on both sides -- NOT comparable with the dispatch-timestamp figures in `kernels`
+        ms_g, n_g = extra['gemm_bias_act']
+        if n_g:
+            marker_timed = {'gemm_bias_act': {'avg_us': round(ms_g / n_g * 1e3, 2), 'launches': n_g,
+                                              'note': 'event markers around the hipBLASLt call (dispatch latency included); '
+                                                      "the kernels' own times are in profiles/ (rocprofv3 --kernel-trace)"}}
         if fuse_graph and world == 1 and not args.no_eager_leg:
             # the same Model.forward with fused_graph = False (eager nn.Module graph under autocast + the same HIP
             # post-processing): the A/B of what routing eval through the engine buys
@@ -458,7 +487,7 @@ def run_infer(args, rank, world, dev):
     # HBM traffic per launch comes from PMC passes (cannot be collected live next to the timing):
     # profiles/r03_pmc_traffic.json (tools/profile_round.sh), quoted only when the workload matches the profiled one
     traffic, traffic_src = None, None
-    for name in ('r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
+    for name in ('r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
         try:
             pmc = json.load(open(os.path.join(ROOT, 'profiles', name)))
             key = 'bf16_logits_channels_last' if (model.fused_postprocess and bytes_per_score == 2) else 'fp32_scores_nchw'
@@ -489,12 +518,13 @@ def run_infer(args, rank, world, dev):
                                        'model': '%d kept boxes x %d clk (LDS read + dependent IoU chain + ballot/readlane) at %.1f GHz'
                                                 % (model.detections, NMS_CLK_PER_KEPT, CLOCK_GHZ),
                                        'ratio': round(nms_us / lb, 1)}
-    sel = [k for k in ('select_hist_kernel', 'select_filter_kernel', 'select_decode_kernel') if k in kernels]
+    sel = [k for k in ('select_decode_kernel',) if k in kernels]
     if sel:
         total = sum(kernels[k]['avg_us'] * kernels[k]['launches'] for k in sel) / kernels['select_decode_kernel']['launches']
         latency_bound['select'] = {'us_per_step': round(total, 2), 'kernels': sel, 'lower_bound_us': 4.0,
-                                   'model': 'one pass over the candidate keys out of L2 (~1 us) + one 1024-key bitonic sort '
-                                            '(55 dependent stages, ~3 us)', 'ratio': round(total / 4.0, 1)}
+                                   'model': 'one pass over the candidate keys out of L2 (~1 us) + one sort of the 1024 selected '
+                                            'keys (~3 us); the same bound as in rounds 2-3, when the selection was three launches',
+                                   'ratio': round(total / 4.0, 1)}
     conv_tflops = flops_img * (value / world) / 1e12
     conv_roofline = {'bound': 'mfma', 'achieved': round(conv_tflops, 1), 'peak': MFMA_BF16_PEAK_TFLOPS,
                      'unit': 'TFLOP/s', 'frac': round(conv_tflops / MFMA_BF16_PEAK_TFLOPS, 4),
@@ -601,6 +631,7 @@ def run_infer(args, rank, world, dev):
                        'graph': 'BN folded into conv weights + HIP bias/skip/ReLU epilogue + 1x1 convs as fused GEMMs' if fuse_graph
                                 else 'eager nn.Module under autocast'},
             'roofline': roofline, 'latency_bound': latency_bound, 'conv_roofline': conv_roofline, 'kernels': kernels,
+            'epilogue_roofline': epilogue_roofline, 'marker_timed': marker_timed,
             'candidates_per_image_per_level': candidates,
             'spec_candidates_per_image_per_level': SPEC_CANDIDATES if (args.height, args.width) == (800, 1280) and not args.rotated_bbox else None,
             'eager': eager,

@@ -204,6 +204,15 @@ int odtk_bias_act_maxpool(const void *y, const float *bias, void *out, int batch
                           int channels, int dtype, int relu, void *stream);
 
 /*
+ * odtk_upsample_nearest2x -- out[b][y][x][c] = x[b][y / 2][x / 2][c] for a channels_last activation (the FPN's top-down path,
+ * reference odtk/backbones/fpn.py:45-61: F.interpolate(., scale_factor=2)).  x: device [batch, height, width, channels], out:
+ * device [batch, 2*height, 2*width, channels], both of `dtype`, 16-byte aligned, channels * sizeof(dtype) a multiple of 16.
+ * A plain stream (bytes are copied, never decoded): bit-identical to torch's nearest interpolation.
+ */
+int odtk_upsample_nearest2x(const void *x, void *out, int batch_size, int height, int width, int channels, int dtype,
+                            void *stream);
+
+/*
  * odtk_gemm_bias_act -- 1x1 (pointwise) convolution of a channels_last activation as ONE GEMM with
  * the whole epilogue fused:
  *     y[p][o] = act( sum_c x[p][c] * w[o][c] + bias[o] (+ residual[p][o]) ),   act = ReLU if relu != 0
@@ -320,14 +329,15 @@ int odtk_retina_loss_levels_backward(int n_levels, const odtk_loss_level_t *leve
  * While enabled, a kernel launch of this library carries a hipEvent pair (asynchronous -- still no
  * host synchronisation): the post-processing, target and loss kernels hand the pair to the launch
  * itself (hipExtLaunchKernelGGL), so the two events hold the dispatch's own begin / end timestamps --
- * the figures rocprofv3's kernel trace reports; the epilogue / GEMM entry points record the pair around
- * the call.  odtk_profile_collect waits for the recorded events, accumulates per-kernel elapsed
+ * the figures rocprofv3's kernel trace reports -- and so do, since round 4, the epilogue kernels (bias_act, the stem's
+ * pool pass, the upsampling); only odtk_gemm_bias_act, whose kernels hipBLASLt launches itself, records the pair around
+ * the call (marker packets: the dispatch latency is inside the figure on both sides).  odtk_profile_collect waits for the recorded events, accumulates per-kernel elapsed
  * milliseconds and launch counts, and clears the pool.  Kernel ids: */
 #define ODTK_KERNEL_PREFILTER 0   /* prefilter_scan_kernel                         */
 #define ODTK_KERNEL_SELECT    1   /* select_decode_kernel                          */
 #define ODTK_KERNEL_NMS       2   /* nms_kernel                                    */
 #define ODTK_KERNEL_IOU       3   /* iou_pairs_kernel                              */
-#define ODTK_KERNEL_EPILOGUE  4   /* bias_act_kernel                               */
+#define ODTK_KERNEL_EPILOGUE  4   /* bias_act_kernel (+ its scalar tail form)      */
 #define ODTK_KERNEL_TARGETS   5   /* snap_to_anchors_kernel                        */
 #define ODTK_KERNEL_GEMM      6   /* hipBLASLt kernels behind odtk_gemm_bias_act    */
 #define ODTK_KERNEL_LOSS      7   /* retina_loss_kernel (forward and backward)      */
@@ -335,7 +345,9 @@ int odtk_retina_loss_levels_backward(int n_levels, const odtk_loss_level_t *leve
 #define ODTK_KERNEL_SELFILTER 9   /* (rounds 2-3: the selection's filter launch; no longer launched, id kept)    */
 #define ODTK_KERNEL_NMS_ORDER 10  /* nms_kernel, stage 1 (rotated: the first round in order)   */
 #define ODTK_KERNEL_NMS_MATRIX 11 /* rotated_sup_matrix_kernel (rotated: pairwise suppression) */
-#define ODTK_KERNEL_COUNT     12
+#define ODTK_KERNEL_POOL      12  /* bias_act_maxpool_kernel (the stem's bias + ReLU + max-pool pass)  */
+#define ODTK_KERNEL_UPSAMPLE  13  /* upsample_nearest2x_kernel                                         */
+#define ODTK_KERNEL_COUNT     14
 /* on: 0 = off, otherwise a bit mask of kernel ids (1 << ODTK_KERNEL_*), -1 = all.  An event pair
  * is a queue marker before and after the kernel: cheap for the 3 post-processing launches of a step,
  * measurably NOT free for the ~110 epilogue launches (about 10 % of an 8.7 ms step), so time those

@@ -175,4 +175,23 @@ __global__ __launch_bounds__(256) void bias_act_maxpool_kernel(const uint16_t *_
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Nearest-neighbour 2x upsampling of a channels_last activation: out[b][y][x][c] = in[b][y / 2][x / 2][c] -- the FPN's
+// top-down path (reference odtk/backbones/fpn.py:45-61: F.interpolate(p5, scale_factor=2) added to lateral4(c4), and the
+// same one level down).  torch's upsample_nearest2d kernel + the channels_last copy behind it ran at 0.65 TB/s (125 us per
+// step for 100 MB of traffic, profiles/r03_bench_steady_kernel_stats.txt); this is a plain stream: one thread = one output
+// pixel x 16 bytes of channels, the four fine pixels of a coarse one read the same 16 bytes (L2 / TCP hits), every access
+// coalesced.  HBM-bound: sizeof(T) x (input + 4 x input) per element.  Any storage type: bytes are copied, never decoded.
+__global__ __launch_bounds__(256) void upsample_nearest2x_kernel(const vuint4 *__restrict__ in, vuint4 *__restrict__ out, uint32_t h,
+                                                                 uint32_t w, uint32_t groups, uint32_t total, const FastDiv by_groups,
+                                                                 const FastDiv by_wo, const FastDiv by_ho) {
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {   // total < 2^32 - grid (checked by the host)
+    uint32_t g, ox, oy;
+    uint32_t p = fastdivmod(i, by_groups, &g);
+    p = fastdivmod(p, by_wo, &ox);
+    const uint32_t b = fastdivmod(p, by_ho, &oy);
+    out[i] = in[((static_cast<uint64_t>(b) * h + (oy >> 1)) * w + (ox >> 1)) * groups + g];
+  }
+}
+
 }  // namespace odtk

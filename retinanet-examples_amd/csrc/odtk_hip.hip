@@ -135,6 +135,16 @@ int scan_image_major() {
   return v;
 }
 
+// Tiles per prefilter workgroup for 16-bit inputs (ODTK_SCAN_SPAN = 1, 2 or 4; A/B measurements)
+uint32_t scan_span_tiles() {
+  static const uint32_t v = [] {
+    const char *e = std::getenv("ODTK_SCAN_SPAN");
+    const int x = e ? std::atoi(e) : 2;
+    return static_cast<uint32_t>(x == 1 || x == 4 ? x : 2);
+  }();
+  return v;
+}
+
 // Workspace of a decode call: [segment state | sub-list lengths | candidate pool: kSpanCap keys per span | survivor lists].
 // A span = 1 (fp32) or 2 (16-bit) tiles of 16 384 scores of ONE image; its four prefilter waves own kWaveStage keys each, so
 // no list can overflow into another and nothing is reserved at run time.  A wave with more raw hits than that marks its
@@ -143,7 +153,7 @@ int decode_layout(int batch, int n_levels, const odtk_level_t *levels, int A, in
   size_t off = 0;
   out->sel_off = off;
   off += align_up(sizeof(odtk::SelSeg) * static_cast<size_t>(batch) * n_levels);
-  out->span_tiles = dtype == ODTK_F32 ? 1u : static_cast<uint32_t>(odtk::kMaxSpanTiles);
+  out->span_tiles = dtype == ODTK_F32 ? 1u : scan_span_tiles();
   out->span_elems = out->span_tiles * odtk::kTile;
   out->budget = sort_cap_for(top_n);                       // keys a workgroup of the tournament route passes on: one sort buffer
   size_t lists = 0;
@@ -472,7 +482,6 @@ int nms_impl(int batch, const void *const *inputs, void *const *outputs, int n_o
 template <typename T, bool kRes, bool kRelu>
 int bias_act_launch(void *y, const float *bias, const void *res, uint64_t n, uint32_t channels, hipStream_t stream) {
   constexpr int per = T::kPerLoad;
-  KernelTimer t(ODTK_KERNEL_EPILOGUE, stream);
   uint64_t done = 0;
   if (channels % per == 0 && n / per >= 256) {
     // fast form: grid stride (blocks * 256 lanes) must be a multiple of the row length in vectors
@@ -484,8 +493,8 @@ int bias_act_launch(void *y, const float *bias, const void *res, uint64_t n, uin
     uint64_t blocks = (n_vec + 256ull * 4 - 1) / (256ull * 4);          // ~4 vectors per lane
     if (blocks > 256 * 16) blocks = 256 * 16;                            // <= 16 workgroups per CU
     blocks = (blocks + unit - 1) / unit * unit;
-    hipLaunchKernelGGL((odtk::bias_act_kernel<T, kRes, kRelu>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0,
-                       stream, y, bias, res, n_vec, vpr);
+    timed_launch(ODTK_KERNEL_EPILOGUE, odtk::bias_act_kernel<T, kRes, kRelu>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0,
+                 stream, y, bias, res, n_vec, vpr);
     done = n_vec * per;
   }
   if (done < n) {
@@ -906,7 +915,6 @@ int odtk_bias_act_maxpool(const void *y, const float *bias, void *out, int batch
   uint64_t blocks = (work + 255) / 256;
   if (blocks > 256 * 32) blocks = 256 * 32;                              // grid-stride beyond 32 workgroups per CU
   hipStream_t s = static_cast<hipStream_t>(stream);
-  KernelTimer t(ODTK_KERNEL_EPILOGUE, s);
   const uint16_t *in = static_cast<const uint16_t *>(y);
   uint16_t *o = static_cast<uint16_t *>(out);
   odtk::PoolDivisors dv;
@@ -915,14 +923,34 @@ int odtk_bias_act_maxpool(const void *y, const float *bias, void *out, int batch
   dv.ho = odtk::fastdiv_make(ho);
   const bool small = work < (1ull << 32);
 #define ODTK_POOL_(T, R, S)                                                                                             \
-  hipLaunchKernelGGL((odtk::bias_act_maxpool_kernel<T, R, S>), dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, in, \
-                     bias, o, static_cast<uint32_t>(batch_size), static_cast<uint32_t>(height),                       \
-                     static_cast<uint32_t>(width), static_cast<uint32_t>(channels), ho, wo, dv)
+  timed_launch(ODTK_KERNEL_POOL, odtk::bias_act_maxpool_kernel<T, R, S>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, s, in, \
+               bias, o, static_cast<uint32_t>(batch_size), static_cast<uint32_t>(height),                             \
+               static_cast<uint32_t>(width), static_cast<uint32_t>(channels), ho, wo, dv)
 #define ODTK_POOL(T, R) do { if (small) ODTK_POOL_(T, R, true); else ODTK_POOL_(T, R, false); } while (0)
   if (dtype == ODTK_BF16) { if (relu) ODTK_POOL(odtk::BF16, true); else ODTK_POOL(odtk::BF16, false); }
   else { if (relu) ODTK_POOL(odtk::F16, true); else ODTK_POOL(odtk::F16, false); }
 #undef ODTK_POOL_
 #undef ODTK_POOL
+  ODTK_HIP_TRY(hipGetLastError());
+  return ODTK_OK;
+}
+
+int odtk_upsample_nearest2x(const void *x, void *out, int batch_size, int height, int width, int channels, int dtype,
+                            void *stream) {
+  if (!x || !out || batch_size <= 0 || height <= 0 || width <= 0 || channels <= 0) return ODTK_ERR_INVALID;
+  if (dtype != ODTK_F32 && dtype != ODTK_BF16 && dtype != ODTK_F16) return ODTK_ERR_UNSUPPORTED;
+  const unsigned long long row_bytes = 1ull * channels * (dtype == ODTK_F32 ? 4 : 2);
+  if (row_bytes % 16) return ODTK_ERR_UNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 15u) return ODTK_ERR_INVALID;
+  const unsigned long long groups = row_bytes / 16;
+  const unsigned long long total = 4ull * batch_size * height * width * groups;
+  if (total > 0xf0000000ull) return ODTK_ERR_INVALID;
+  unsigned long long blocks = (total + 256ull * 4 - 1) / (256ull * 4);           // ~4 vectors per lane
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  timed_launch(ODTK_KERNEL_UPSAMPLE, odtk::upsample_nearest2x_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), 0,
+               static_cast<hipStream_t>(stream), static_cast<const odtk::vuint4 *>(x), static_cast<odtk::vuint4 *>(out),
+               static_cast<uint32_t>(height), static_cast<uint32_t>(width), static_cast<uint32_t>(groups), static_cast<uint32_t>(total),
+               odtk::fastdiv_make(static_cast<uint32_t>(groups)), odtk::fastdiv_make(2u * width), odtk::fastdiv_make(2u * height));
   ODTK_HIP_TRY(hipGetLastError());
   return ODTK_OK;
 }

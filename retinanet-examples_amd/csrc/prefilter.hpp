@@ -50,7 +50,7 @@ typedef uint32_t vuint4 __attribute__((ext_vector_type(4)));
 constexpr int kScanThreads = 256;
 constexpr int kScanWaves = kScanThreads / kWave;
 constexpr int kTile = 16384;                     // elements per tile (64 per lane)
-constexpr int kMaxSpanTiles = 2;                 // tiles per workgroup: 2 for 16-bit inputs (measured 57.4 -> 52.4 us), 1 for fp32
+constexpr int kMaxSpanTiles = 4;                 // most tiles per workgroup (a 16-bit staged offset); the launch uses 2 for 16-bit inputs, 1 for fp32 (measured)
 constexpr int kWaveStage = 512;                  // raw hits a wave stages in LDS = keys its sub-list holds (6.25 % of its elements)
 constexpr int kSpanCap = kScanWaves * kWaveStage;   // keys of a span's region in the candidate pool
 constexpr uint32_t kListOverflow = 0xffffffffu;  // sub-list length: "more than kWaveStage raw hits, read the span's raw scores"
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(kScanThreads, (!kAligned ? 2 : sizeof(typename T::s
   constexpr bool k16 = sizeof(typename T::storage) == 2;
   constexpr int kPer = T::kPerLoad;                        // elements per 16-byte load
   constexpr int kVec = kTile / (kScanThreads * kPer);      // loads per lane per tile: 16 (f32) or 8 (16-bit)
-  // staged hit: 16-bit types (raw bits << 15) | span offset (a span has <= 2^15 elements) in 4 bytes; fp32 (bits << 32) | offset
+  // staged hit: 16-bit types (raw bits << 16) | span offset (a span has <= 2^16 elements) in 4 bytes; fp32 (bits << 32) | offset
   using stage_t = std::conditional_t<k16, uint32_t, uint64_t>;
   __shared__ stage_t s_stage[kSpanCap];                    // [wave][kWaveStage]: every wave stages and drains its own region
   // head bias folded in (ScanLevel::bias): per-channel float thresholds, 8 per group of 8 consecutive channels: [0..3] for
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(kScanThreads, (!kAligned ? 2 : sizeof(typename T::s
               if constexpr (k16) {
                 const uint32_t w = v[u][e >> 1];
                 const uint32_t bits = (e & 1) ? (w >> 16) : (w & 0xffffu);
-                my_stage[pos] = (bits << 15) | off;
+                my_stage[pos] = (bits << 16) | off;
               } else {
                 my_stage[pos] = (static_cast<uint64_t>(v[u][e]) << 32) | off;
               }
@@ -388,8 +388,8 @@ __global__ __launch_bounds__(kScanThreads, (!kAligned ? 2 : sizeof(typename T::s
         float raw;
         if constexpr (k16) {
           const uint32_t ent = my_stage[i];
-          off = ent & 0x7fffu;
-          raw = storage_to_float<T>(static_cast<uint16_t>(ent >> 15));
+          off = ent & 0xffffu;
+          raw = storage_to_float<T>(static_cast<uint16_t>(ent >> 16));
         } else {
           const uint64_t ent = my_stage[i];
           off = static_cast<uint32_t>(ent);

@@ -95,6 +95,8 @@ _SIGNATURES = {
     'odtk_debug_loss_tuning': (ctypes.c_int, [ctypes.c_int] * 6),
     'odtk_bias_act_maxpool': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
                                              ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    'odtk_upsample_nearest2x': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                               ctypes.c_int, ctypes.c_void_p]),
     'odtk_gemm_init': (ctypes.c_int, [ctypes.c_char_p]),
     'odtk_gemm_bias_act': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                           ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
@@ -104,7 +106,17 @@ _SIGNATURES = {
 
 KERNEL_NAMES = ('prefilter_scan_kernel', 'select_decode_kernel', 'nms_kernel', 'iou_pairs_kernel', 'bias_act_kernel',
                 'snap_to_anchors_kernel', 'gemm_bias_act', 'retina_loss_kernel', 'select_hist_kernel', 'select_filter_kernel',
-                'nms_first_round_kernel', 'rotated_sup_matrix_kernel')
+                'nms_first_round_kernel', 'rotated_sup_matrix_kernel', 'bias_act_maxpool_kernel', 'upsample_nearest2x_kernel')
+# HBM bytes the epilogue entry points move, per kernel name, while `traffic_count` is on (bench.py's epilogue_roofline: the
+# algorithmic bytes of every call -- each element read once and written once, + the skip input -- divided by the kernel time)
+traffic_count = False
+traffic_bytes = {}
+
+
+def _count(name, nbytes):
+    if traffic_count:
+        traffic_bytes[name] = traffic_bytes.get(name, 0) + int(nbytes)
+
 
 _lib = None
 
@@ -587,6 +599,7 @@ def bias_act_(y, bias, residual=None, relu=True):
         stream = torch.cuda.current_stream(y.device).cuda_stream
         _check(library().odtk_bias_act(y.data_ptr(), bias.data_ptr(), residual.data_ptr() if residual is not None else None,
                                        n * h * w, c, _DTYPES[y.dtype], 1 if relu else 0, stream), 'bias_act')
+    _count('bias_act_kernel', y.numel() * y.element_size() * (3 if residual is not None else 2))
     return y
 
 
@@ -605,6 +618,23 @@ def bias_act_maxpool(y, bias, relu=True):
         stream = torch.cuda.current_stream(y.device).cuda_stream
         _check(library().odtk_bias_act_maxpool(y.data_ptr(), bias.data_ptr(), out.data_ptr(), n, h, w, c, _DTYPES[y.dtype],
                                                1 if relu else 0, stream), 'bias_act_maxpool')
+    _count('bias_act_maxpool_kernel', (y.numel() + out.numel()) * y.element_size())
+    return out
+
+
+def upsample2x(x):
+    """Nearest-neighbour 2x upsampling of a channels_last CUDA activation (the FPN's top-down path); bit-identical to
+    F.interpolate(x, scale_factor=2) in channels_last.  One HIP stream kernel instead of torch's upsample + layout copy."""
+    if not x.is_cuda or x.dim() != 4 or x.dtype not in _DTYPES:
+        raise RuntimeError('upsample2x: x must be a 4-d CUDA tensor of float32/bfloat16/float16')
+    n, c, h, w = x.shape
+    if not x.is_contiguous(memory_format=torch.channels_last) or (c * x.element_size()) % 16:
+        raise RuntimeError('upsample2x: x must be channels_last with channels * element size a multiple of 16 bytes')
+    out = torch.empty((n, c, 2 * h, 2 * w), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    with torch.cuda.device(x.device):
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        _check(library().odtk_upsample_nearest2x(x.data_ptr(), out.data_ptr(), n, h, w, c, _DTYPES[x.dtype], stream), 'upsample2x')
+    _count('upsample_nearest2x_kernel', (x.numel() + out.numel()) * x.element_size())
     return out
 
 

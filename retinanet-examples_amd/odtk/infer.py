@@ -141,8 +141,9 @@ def infer(model, path, detections_file, resize, max_size, batch_size, mixed_prec
     arguments.  Returns `COCOeval.stats` (mAP first) when ground truth was given, None when nothing was
     detected, 0 otherwise (and on the ranks other than the master), as the reference does.
 
-    `mixed_precision` on a GPU = bf16 autocast, which routes `Model.forward` to the bf16 engine (the reference
-    only implements it through apex O2, fp16).  `with_apex` / `use_dali` name dependencies the north star
+    `mixed_precision` on a GPU = fp16 autocast, like the reference's (apex O2 / torch.cuda.amp, infer.py:54-58), which
+    routes `Model.forward` to the fp16 BN-folded engine (measured AP against the fp32 pipeline: 0.995-1.000, the bf16
+    engine 0.963-0.988; profiles/r04_bf16_ablation.txt).  `with_apex` / `use_dali` name dependencies the north star
     drops: asking for them is an error, not a silent fallback."""
     from .cocoeval import COCOeval
     from .data import DataIterator, RotatedDataIterator

@@ -44,6 +44,27 @@ def test_bias_act_matches_torch(dtype, shape):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16, torch.float32], ids=['bf16', 'fp16', 'fp32'])
+@pytest.mark.parametrize('shape', [(2, 256, 25, 40), (1, 256, 13, 20), (3, 8, 1, 1), (2, 64, 7, 5)], ids=lambda s: 'x'.join(map(str, s)))
+def test_upsample2x_matches_torch_nearest(dtype, shape):
+    """The FPN's top-down upsampling (reference fpn.py:45-61) as one HIP stream kernel: bytes are copied, so it equals
+    F.interpolate(scale_factor=2) bit for bit (NaN payloads included); unsupported layouts raise."""
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(*shape, generator=g).cuda().to(dtype).contiguous(memory_format=torch.channels_last)
+    x.permute(0, 2, 3, 1).reshape(-1)[::97] = float('nan')             # (a view: channels_last storage is NHWC-contiguous)
+    out = _C.upsample2x(x)
+    ref = F.interpolate(x, scale_factor=2)
+    assert out.shape == ref.shape and out.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(out.view(torch.int16 if dtype != torch.float32 else torch.int32), ref.contiguous(memory_format=torch.channels_last).view(
+        torch.int16 if dtype != torch.float32 else torch.int32))
+    if shape[2] * shape[3] > 1:
+        with pytest.raises(RuntimeError):
+            _C.upsample2x(x.contiguous())                              # NCHW
+    with pytest.raises(RuntimeError):
+        _C.upsample2x(torch.zeros(1, 3, 4, 4, device='cuda', dtype=dtype).contiguous(memory_format=torch.channels_last))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('backbone', ['ResNet18FPN', 'ResNet50FPN'])
 def test_fused_graph_matches_eager_fp32(backbone):
     torch.manual_seed(0)
