@@ -126,7 +126,7 @@ def run_train(args, rank, local_rank, world, dev):
     model.fused_loss = not args.no_fused_loss
     scaler = torch.amp.GradScaler('cuda', enabled=amp_dtype == torch.float16) if amp_dtype == torch.float16 else None
     source = T.SyntheticBatches(per_gpu * world, args.height, args.width, classes=80, max_boxes=20, seed=0, rank=rank,
-                                world=world, device='cpu')
+                                world=world, device='cpu', rotated=args.rotated_bbox)
     batches = []
     for _ in range(4):                                       # a small device-resident pool (no PCIe in the timed region)
         d, t = source.batch()
@@ -186,7 +186,8 @@ def run_train(args, rank, local_rank, world, dev):
         images = per_gpu * world * args.steps
         grad_bytes = sum(p.numel() * 4 for p in model.parameters() if p.requires_grad)
         line = {
-            'metric': 'images/sec training (fwd + FocalLoss/SmoothL1 + bwd + SGD), %s %dpx, %d img/GPU' % (short_name(args.backbone), args.height, per_gpu),
+            'metric': 'images/sec training (fwd + FocalLoss/SmoothL1 + bwd + SGD), %s%s %dpx, %d img/GPU' % (
+                short_name(args.backbone), ' --rotated-bbox' if args.rotated_bbox else '', args.height, per_gpu),
             'value': round(images / elapsed, 2), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype,
@@ -303,6 +304,8 @@ def other_configs(args, rank, local_rank, world, dev):
     run('config 2 in fp16: ResNet50FPN fp16 inference bs 8', lambda: run_infer(leg_args(args, dtype='fp16'), rank, world, dev))
     run('config 3 (per-GPU share): ResNet50FPN fp32 training, 2 images per GPU',
         lambda: run_train(leg_args(args, mode='train', batch=2, dtype='fp32'), rank, local_rank, world, dev))
+    run('config 3 with --rotated-bbox (per-GPU share): fused rotated target assignment',
+        lambda: run_train(leg_args(args, mode='train', batch=2, dtype='fp32', rotated_bbox=True), rank, local_rank, world, dev))
     run('batch-1 latency: ResNet50FPN bf16', lambda: run_latency(leg_args(args, batch=1), dev))
     return legs
 

@@ -266,6 +266,27 @@ int odtk_snap_to_anchors_levels(int batch_size, const float *targets, int n_max,
                                 float iou_background, float iou_foreground, void *stream);
 
 /*
+ * odtk_snap_to_anchors_rotated_levels -- the same assignment for ROTATED boxes (reference odtk/box.py:192-252, whose overlap is
+ * the pairwise polygon IoU csrc/cuda/nms_iou.cu:324-387), all pyramid levels of the batch in ONE launch: no [27*H*W, N] IoU
+ * matrix, no per-image host loop.  The ground truth arrives as the reference's `rotate_boxes` leaves it (utils.py:33-82):
+ *   gt_axis   float32 [batch, n_max, 6] = (x1, y1, x2, y2, sin, cos)      gt_quads  float32 [batch, n_max, 8] ordered corners
+ *   gt_class  float32 [batch, n_max], rows with class < 0 are padding
+ * and per level DEVICE tables of the anchors (generate_anchors_rotated: axis form [A, 4] and quads [A, 8]):
+ *   cls_target [batch, A, C, H, W] (or NULL)   box_target [batch, A, 6, H, W]   depth [batch, A, 1, H, W]
+ */
+typedef struct odtk_snap_rot_level {
+  const float *anchors_axis;  /* DEVICE float[4*num_anchors] */
+  const float *anchors_quads; /* DEVICE float[8*num_anchors] */
+  float *cls_target;          /* or NULL */
+  float *box_target;
+  float *depth;
+  int32_t height, width, stride, pad_;
+} odtk_snap_rot_level_t;
+int odtk_snap_to_anchors_rotated_levels(int batch_size, const float *gt_axis, const float *gt_quads, const float *gt_class,
+                                        int n_max, int n_levels, const odtk_snap_rot_level_t *levels, int num_anchors,
+                                        int num_classes, float iou_background, float iou_foreground, void *stream);
+
+/*
  * odtk_retina_loss_forward / odtk_retina_loss_backward -- fused, masked FocalLoss + SmoothL1 reduction of ONE
  * pyramid level for the whole batch (the step after target assignment in training).
  * Replaces, per level, reference odtk/model.py:193-209 + odtk/loss.py:13-31 (focal loss, smooth-L1, the two

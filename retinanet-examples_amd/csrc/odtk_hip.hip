@@ -846,6 +846,39 @@ int odtk_snap_to_anchors_levels(int batch_size, const float *targets, int n_max,
   return ODTK_OK;
 }
 
+int odtk_snap_to_anchors_rotated_levels(int batch_size, const float *gt_axis, const float *gt_quads, const float *gt_class,
+                                        int n_max, int n_levels, const odtk_snap_rot_level_t *levels, int num_anchors,
+                                        int num_classes, float iou_background, float iou_foreground, void *stream) {
+  if (batch_size <= 0 || n_max < 0 || n_levels <= 0 || n_levels > ODTK_MAX_LEVELS || !levels || num_anchors <= 0 ||
+      num_classes <= 0 || (n_max > 0 && (!gt_axis || !gt_quads || !gt_class)))
+    return ODTK_ERR_INVALID;
+  odtk::SnapRotLevelsArgs la;
+  std::memset(&la, 0, sizeof la);
+  la.n_levels = n_levels;
+  unsigned total = 0;
+  for (int l = 0; l < n_levels; ++l) {
+    const odtk_snap_rot_level_t &lv = levels[l];
+    if (!lv.anchors_axis || !lv.anchors_quads || !lv.box_target || !lv.depth || lv.height <= 0 || lv.width <= 0) return ODTK_ERR_INVALID;
+    odtk::SnapRotArgs &sa = la.lv[l];
+    sa.gt_axis = gt_axis; sa.gt_quads = gt_quads; sa.gt_class = gt_class;
+    sa.anchors_axis = lv.anchors_axis; sa.anchors_rot = lv.anchors_quads;
+    sa.cls_target = lv.cls_target; sa.box_target = lv.box_target; sa.depth = lv.depth;
+    sa.n_max = n_max; sa.num_anchors = num_anchors; sa.num_classes = num_classes;
+    sa.height = lv.height; sa.width = lv.width;
+    sa.stride = static_cast<float>(lv.stride);
+    sa.iou_bg = iou_background; sa.iou_fg = iou_foreground;
+    la.block_begin[l] = total;
+    const long long cells = 1ll * num_anchors * lv.height * lv.width;
+    if (cells > 0x7fffffffll) return ODTK_ERR_INVALID;
+    total += static_cast<unsigned>((cells + odtk::kSnapThreads - 1) / odtk::kSnapThreads);
+  }
+  for (int l = n_levels; l <= ODTK_MAX_LEVELS; ++l) la.block_begin[l] = total;
+  timed_launch(ODTK_KERNEL_TARGETS, odtk::snap_to_anchors_rotated_levels_kernel, dim3(total, batch_size), dim3(odtk::kSnapThreads), 0,
+               static_cast<hipStream_t>(stream), la);
+  ODTK_HIP_TRY(hipGetLastError());
+  return ODTK_OK;
+}
+
 int odtk_retina_loss_forward(const void *cls, const void *box, const float *depth, const float *box_target,
                              int batch_size, int num_anchors, int num_classes, int height, int width, int box_params,
                              int dtype, int channels_last, float alpha, float gamma, float beta, double *sums,

@@ -50,6 +50,13 @@ class SnapLevel(ctypes.Structure):
                 ('pad_', ctypes.c_int32)]
 
 
+class SnapRotLevel(ctypes.Structure):
+    """odtk_snap_rot_level_t"""
+    _fields_ = [('anchors_axis', ctypes.c_void_p), ('anchors_quads', ctypes.c_void_p), ('cls_target', ctypes.c_void_p),
+                ('box_target', ctypes.c_void_p), ('depth', ctypes.c_void_p), ('height', ctypes.c_int32), ('width', ctypes.c_int32),
+                ('stride', ctypes.c_int32), ('pad_', ctypes.c_int32)]
+
+
 class Level(ctypes.Structure):
     """odtk_level_t"""
     _fields_ = [('cls', _vp), ('box', _vp), ('height', ctypes.c_int32), ('width', ctypes.c_int32),
@@ -95,6 +102,9 @@ _SIGNATURES = {
     'odtk_debug_loss_tuning': (ctypes.c_int, [ctypes.c_int] * 6),
     'odtk_bias_act_maxpool': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
                                              ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    'odtk_snap_to_anchors_rotated_levels': (ctypes.c_int, [ctypes.c_int, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int,
+                                                           ctypes.POINTER(SnapRotLevel), ctypes.c_int, ctypes.c_int, ctypes.c_float,
+                                                           ctypes.c_float, _vp]),
     'odtk_upsample_nearest2x': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                ctypes.c_int, ctypes.c_void_p]),
     'odtk_gemm_init': (ctypes.c_int, [ctypes.c_char_p]),
@@ -414,6 +424,49 @@ def snap_to_anchors(targets, anchors, num_classes, height, width, stride, iou_ba
                                               depth.data_ptr(), stream),
                'snap_to_anchors')
     return cls, box_t, depth
+
+
+def snap_to_anchors_rotated_levels(gt_axis, gt_quads, gt_class, anchors_list, num_classes, sizes, strides, iou_background,
+                                   iou_foreground, want_cls_target=True):
+    """Rotated target assignment (reference box.py:192-252) for every pyramid level of the batch in ONE launch.
+    gt_axis [B, N, 6], gt_quads [B, N, 8], gt_class [B, N] (< 0: padding) float32 CUDA -- the reference's `rotate_boxes` output;
+    anchors_list: per level (axis [A, 4], quads [A, 8]) float32 CUDA tensors; sizes: per level (H, W).
+    -> lists (cls_targets or Nones, box_targets [B, A, 6, H, W], depths)."""
+    for t, name, last in ((gt_axis, 'gt_axis', 6), (gt_quads, 'gt_quads', 8)):
+        _check_input(t, name)
+        if t.dim() != 3 or t.shape[2] != last:
+            raise RuntimeError('%s must be [B, N, %d]' % (name, last))
+    _check_input(gt_class, 'gt_class')
+    n = len(anchors_list)
+    if not (n == len(sizes) == len(strides)) or n == 0 or n > MAX_LEVELS:
+        raise RuntimeError('snap_to_anchors_rotated_levels: need 1..%d levels with matching lists' % MAX_LEVELS)
+    b, n_max = gt_axis.shape[0], gt_axis.shape[1]
+    if gt_quads.shape[:2] != (b, n_max) or tuple(gt_class.shape) != (b, n_max):
+        raise RuntimeError('snap_to_anchors_rotated_levels: gt_axis / gt_quads / gt_class disagree')
+    dev = gt_axis.device
+    arr = (SnapRotLevel * n)()
+    cls_t, box_t, depth_t = [], [], []
+    a = None
+    with torch.cuda.device(dev):
+        for i, ((axis, quads), (h, w), s) in enumerate(zip(anchors_list, sizes, strides)):
+            _check_input(axis, 'anchors (axis form)')
+            _check_input(quads, 'anchors (quads)')
+            if a is None:
+                a = axis.shape[0]
+            if tuple(axis.shape) != (a, 4) or tuple(quads.shape) != (a, 8):
+                raise RuntimeError('snap_to_anchors_rotated_levels: every level needs [A, 4] and [A, 8] anchor tables')
+            cls_t.append(torch.empty((b, a, num_classes, h, w), dtype=torch.float32, device=dev) if want_cls_target else None)
+            box_t.append(torch.empty((b, a, 6, h, w), dtype=torch.float32, device=dev))
+            depth_t.append(torch.empty((b, a, 1, h, w), dtype=torch.float32, device=dev))
+            arr[i].anchors_axis, arr[i].anchors_quads = axis.data_ptr(), quads.data_ptr()
+            arr[i].cls_target = cls_t[-1].data_ptr() if want_cls_target else None
+            arr[i].box_target, arr[i].depth = box_t[-1].data_ptr(), depth_t[-1].data_ptr()
+            arr[i].height, arr[i].width, arr[i].stride = int(h), int(w), int(s)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _check(library().odtk_snap_to_anchors_rotated_levels(b, gt_axis.data_ptr(), gt_quads.data_ptr(), gt_class.data_ptr(), n_max, n,
+                                                             arr, a, int(num_classes), float(iou_background), float(iou_foreground),
+                                                             stream), 'snap_to_anchors_rotated_levels')
+    return cls_t, box_t, depth_t
 
 
 def snap_to_anchors_levels(targets, anchors_list, num_classes, sizes, strides, iou_background, iou_foreground,

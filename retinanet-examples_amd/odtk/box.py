@@ -239,6 +239,34 @@ def snap_to_anchors_rotated(boxes, size, stride, anchors, num_classes, device, a
                                  anchor_ious, box2delta_rotated)
 
 
+_ROTATED_ANCHOR_TABLES = {}
+
+
+def snap_to_anchors_rotated_levels(targets, sizes, strides, anchors_list, num_classes, anchor_ious, want_cls_target=True):
+    """snap_to_anchors_rotated for every image and every pyramid level in ONE fused HIP launch (GPU only; csrc/targets.hpp):
+    no [27*H*W, N] IoU matrix, no per-image loop.  targets [B, N, 6] = (x, y, w, h, theta, class), class = -1 rows are padding
+    (reference data.py format); anchors_list: per level the (axis, rotated) pair of generate_anchors_rotated; sizes: per level
+    (H, W) of the head tensors.  The few per-box torch ops of the reference's `rotate_boxes` (cos / sin, corner ordering) run
+    once for the whole batch.  -> lists (cls_targets | Nones, box_targets [B, A, 6, H, W], depths [B, A, 1, H, W])."""
+    _require_gpu(targets, 'snap_to_anchors_rotated_levels')
+    targets = targets.float()
+    b, n, _ = targets.shape
+    flat = targets.reshape(b * n, 6)
+    axis, quads = rotate_boxes(flat[:, :5])
+    tables = []
+    for (anchors_axis, anchors_rotated), s in zip(anchors_list, strides):
+        key = (targets.device, anchors_axis.data_ptr(), anchors_rotated.data_ptr())
+        hit = _ROTATED_ANCHOR_TABLES.get(key)
+        if hit is None:                                           # device copies of the (tiny) anchor tables, made once
+            hit = (anchors_axis.to(targets.device, torch.float32).contiguous(), anchors_rotated.to(targets.device, torch.float32).contiguous(),
+                   anchors_axis, anchors_rotated)                  # (the host tensors are kept alive: their addresses are the key)
+            _ROTATED_ANCHOR_TABLES[key] = hit
+        tables.append(hit[:2])
+    return _C.snap_to_anchors_rotated_levels(axis.view(b, n, 6).contiguous(), quads.view(b, n, 8).contiguous(), flat[:, 5].reshape(b, n).contiguous(),
+                                             tables, num_classes, [(int(h), int(w)) for h, w in sizes], [int(s) for s in strides],
+                                             anchor_ious[0], anchor_ious[1], want_cls_target)
+
+
 def _require_gpu(t, what):
     if not t.is_cuda:
         raise RuntimeError('odtk.box.%s: tensors must be on the GPU (only the axis-aligned decode / nms have a '

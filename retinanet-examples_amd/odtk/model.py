@@ -280,9 +280,10 @@ class Model(nn.Module):
         if self.fused_loss and cls_heads[0].is_cuda:
             # targets of every level (ONE HIP launch for all of them; the class map is implied by depth and not even built), then focal
             # + smooth-L1 + masks + sums of ALL levels in one HIP pass -- and one more in backward (csrc/loss.hpp)
-            if not self.rotated_bbox and len(cls_heads) <= box_ops.MAX_LEVELS_PER_CALL:
+            if len(cls_heads) <= box_ops.MAX_LEVELS_PER_CALL:
                 strides = [x.shape[-1] / c.shape[-1] for c in cls_heads]
-                _, box_targets, depths = box_ops.snap_to_anchors_levels(
+                assign = box_ops.snap_to_anchors_rotated_levels if self.rotated_bbox else box_ops.snap_to_anchors_levels
+                _, box_targets, depths = assign(
                     targets, [tuple(c.shape[-2:]) for c in cls_heads], strides, [self.level_anchors(s) for s in strides],
                     self.classes, self.anchor_ious, want_cls_target=False)
             else:

@@ -34,12 +34,12 @@ class SyntheticBatches:
     [N, 5] table of x, y, w, h, class, padded with -1 rows), sharded by rank."""
 
     def __init__(self, batch, height, width, classes=80, max_boxes=20, seed=0, rank=0, world=1, device='cpu',
-                 length=1 << 30):
+                 length=1 << 30, rotated=False):
         if batch % world:
             raise RuntimeError('Batch size should be a multiple of the number of GPUs')
         self.per_rank, self.h, self.w, self.classes, self.max_boxes = batch // world, height, width, classes, max_boxes
         self.gen = torch.Generator().manual_seed(seed * 1009 + rank)
-        self.device, self.length = device, length
+        self.device, self.length, self.rotated = device, length, rotated   # rotated: [N, 6] rows x, y, w, h, theta, class
 
     def __len__(self):
         return self.length
@@ -51,12 +51,17 @@ class SyntheticBatches:
     def batch(self):
         g, b = self.gen, self.per_rank
         data = torch.randn(b, 3, self.h, self.w, generator=g)
-        target = torch.full((b, self.max_boxes, 5), -1.0)
+        target = torch.full((b, self.max_boxes, 6 if self.rotated else 5), -1.0)
         for i in range(b):
             n = int(torch.randint(1, self.max_boxes + 1, (1,), generator=g))
             wh = torch.rand(n, 2, generator=g) * torch.tensor([min(400., self.w * .8) - 32, min(400., self.h * .8) - 32]) + 32
             xy = torch.rand(n, 2, generator=g) * (torch.tensor([float(self.w), float(self.h)]) - wh)
-            target[i, :n] = torch.cat([xy, wh, torch.randint(0, self.classes, (n, 1), generator=g).float()], 1)
+            cls = torch.randint(0, self.classes, (n, 1), generator=g).float()
+            if self.rotated:
+                theta = (torch.rand(n, 1, generator=g) - 0.5) * 1.0472        # +- 30 degrees
+                target[i, :n] = torch.cat([xy, wh, theta, cls], 1)
+            else:
+                target[i, :n] = torch.cat([xy, wh, cls], 1)
         return data.to(self.device), target.to(self.device)
 
 

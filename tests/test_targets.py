@@ -280,3 +280,58 @@ def test_snap_to_anchors_rotated_on_gpu_matches_reference_fixture(path):
     assert np.array_equal(_bits(out[0].cpu().numpy()), _bits(g['cls_target']))
     assert np.array_equal(_bits(out[2].cpu().numpy()), _bits(g['depth']))
     assert np.allclose(out[1].cpu().numpy(), g['box_target'], rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('path', SNAPROT, ids=os.path.basename)
+def test_fused_rotated_assignment_matches_reference_fixture(path):
+    """SURVEY 8(f2), rotated: ONE HIP launch for all levels and images (csrc/targets.hpp: polygon IoU per anchor cell with a
+    distance reject in front of the clip, arg-max, deltas, depth, class map -- no [27*H*W, N] IoU matrix) against the
+    reference's own snap_to_anchors_rotated output: class map and depth bit for bit, deltas up to the GPU's log().  Image 1
+    of the batch has no boxes (all padding rows): zeros, as the reference returns for an empty target."""
+    g, boxes, size, stride, anchors, classes, ious = _rotated_case(path)
+    n = boxes.shape[0]
+    targets = torch.full((2, n + 3, 6), -1.0)
+    targets[0, :n] = boxes
+    if n:                                                       # padding rows in between are skipped, order is kept
+        targets[0, n + 1] = boxes[n - 1]
+        targets[0, n - 1] = -1.0
+    h, w = int(size[1] / stride), int(size[0] / stride)
+    cls_t, box_t, depth = box.snap_to_anchors_rotated_levels(targets.cuda(), [(h, w)], [stride], [anchors], classes, ious)
+    assert np.array_equal(_bits(cls_t[0][0].cpu().numpy()), _bits(g['cls_target']))
+    assert np.array_equal(_bits(depth[0][0].cpu().numpy()), _bits(g['depth']))
+    assert np.allclose(box_t[0][0].cpu().numpy(), g['box_target'], rtol=1e-5, atol=1e-5)
+    for t in (cls_t[0][1], box_t[0][1], depth[0][1]):
+        assert not t.any()
+    # without the class map (what the fused loss asks for)
+    none, box2, depth2 = box.snap_to_anchors_rotated_levels(targets.cuda(), [(h, w)], [stride], [anchors], classes, ious, want_cls_target=False)
+    assert none[0] is None and torch.equal(box2[0], box_t[0]) and torch.equal(depth2[0], depth[0])
+
+
+@pytest.mark.gpu
+def test_fused_rotated_assignment_equals_the_per_image_path_on_every_level():
+    """All levels of a 256 x 320 image, two images with different box counts, boxes large and small, at the borders and far
+    outside: the fused launch equals the per-image path (HIP iou op over ALL pairs + torch), i.e. the distance reject never
+    changes a value."""
+    gen = torch.Generator().manual_seed(23)
+    strides = [8, 16, 32, 64, 128]
+    size = (320, 256)
+    anchors = [box.generate_anchors_rotated(s, RATIOS, SCALES, ANGLES) for s in strides]
+    sizes = [(-(-size[1] // s), -(-size[0] // s)) for s in strides]
+    n = 11
+    xy = torch.rand(2, n, 2, generator=gen) * torch.tensor([size[0] * 1.2, size[1] * 1.2]) - 30
+    wh = torch.cat([torch.rand(2, n, 1, generator=gen) * 200 + 2, torch.rand(2, n, 1, generator=gen) * 120 + 2], 2)
+    theta = (torch.rand(2, n, 1, generator=gen) - 0.5) * 3.0
+    cls = torch.randint(0, 20, (2, n, 1), generator=gen).float()
+    targets = torch.cat([xy, wh, theta, cls], 2)
+    targets[1, 6:] = -1.0
+    cls_t, box_t, depth = box.snap_to_anchors_rotated_levels(targets.cuda(), sizes, strides, anchors, 20, [0.4, 0.5])
+    hits = 0
+    for lvl, (s, (h, w)) in enumerate(zip(strides, sizes)):
+        for b in range(2):
+            t = targets[b][targets[b][:, -1] > -1]
+            ref = box.snap_to_anchors_rotated(t.cuda(), [w * s, h * s], s, anchors[lvl], 20, 'cuda', [0.4, 0.5])
+            assert torch.equal(cls_t[lvl][b], ref[0]) and torch.equal(depth[lvl][b], ref[2]), (lvl, b)
+            assert torch.allclose(box_t[lvl][b], ref[1], rtol=1e-5, atol=1e-5), (lvl, b)
+            hits += int((ref[2] > 0).sum())
+    assert hits > 20
