@@ -198,9 +198,19 @@ def run_train(args, rank, local_rank, world, dev):
                        'global_batch': per_gpu * world, 'parallelism': 'ddp x%d (RCCL all-reduce, 25 MB buckets, overlapped)' % world,
                        'gradient_bytes_per_step': grad_bytes},
             'exposed_allreduce_ms': exposed, 'hip_kernels': hip_kernels,
-            'loss': {'focal': round(float(both[0]), 5), 'box': round(float(both[1]), 5)},
+            'loss': {'focal': round(float(both[0]), 5), 'box': round(float(both[1]), 5),
+                     'first_step': [round(float(v), 5) for v in losses[0]],
+                     'note': None if (float(both[0]) == float(both[0]) and float(both[1]) == float(both[1])) else
+                     "non-finite after %d SGD steps from the reference's random init on random targets (model.py:121-122 puts the class prior "
+                     'on the box head: box loss starts at ~28); throughput is what this leg measures' % len(losses)},
         }
     return line
+
+
+def default_workload(args):
+    """The configuration the committed profiles were taken on (BASELINE configs[1])."""
+    return (args.backbone == 'ResNet50FPN' and args.batch == 8 and (args.height, args.width) == (800, 1280) and args.dtype == 'bf16'
+            and not args.rotated_bbox and not args.no_fuse and args.postproc == 'fused')
 
 
 def short_name(backbone):
@@ -425,12 +435,17 @@ def run_infer(args, rank, world, dev):
     eager = None
     epilogue_roofline, marker_timed = None, None
     if rank == 0:
-        # the engine's own epilogue kernels (dispatch timestamps, like the post-processing launches) and their algorithmic
-        # bytes (every element read once and written once, + the skip input), three untimed steps
+        # The engine's own epilogue kernels.  Their algorithmic bytes (every element read once and written once, + the skip
+        # input) are counted live over three untimed steps.  Their TIME cannot be taken live: an event pair handed to a launch
+        # is stamped when the packet reaches the head of its queue, and an epilogue sits behind a long convolution -- the pair
+        # then includes the predecessor's tail and cache write-back (13.6-17.8 us per bias_act launch where rocprofv3's kernel
+        # trace of the same command measures 9.15; the post-processing launches, which follow short kernels, agree with it to
+        # 0.5 %).  So the time comes from the committed rocprofv3 summary of THIS command (tools/profile_round.sh ->
+        # profiles/r04_bench_steady_kernel_stats.csv), quoted only when the workload is the profiled one -- like `traffic`.
         epi = ('bias_act_kernel', 'bias_act_maxpool_kernel', 'upsample_nearest2x_kernel')
         _C.traffic_bytes.clear()
         _C.traffic_count = True
-        _C.profile_enable(True, epi + ('gemm_bias_act',))
+        _C.profile_enable(True, ('gemm_bias_act',))
         _C.profile_collect()
         for _ in range(3):
             step()
@@ -438,16 +453,32 @@ def run_infer(args, rank, world, dev):
         _C.profile_enable(False)
         _C.traffic_count = False
         extra = _C.profile_collect()
-        prof.update({k: v for k, v in extra.items() if k in epi})
+        profiled = {}
+        stats = os.path.join(ROOT, 'profiles', 'r04_bench_steady_kernel_stats.csv')
+        if default_workload(args) and os.path.isfile(stats):
+            import csv
+            rows = list(csv.reader(open(stats)))[1:]
+            steps_profiled = next((int(r[1]) for r in rows if 'prefilter_scan_kernel' in r[0]), 0)
+            for r in rows:
+                for k in epi:
+                    if k in r[0] and steps_profiled:
+                        calls, total_ns = profiled.get(k, (0, 0))
+                        profiled[k] = (calls + int(r[1]), total_ns + int(r[2]))
+            profiled = {k: (c / steps_profiled, t / steps_profiled * 1e-3) for k, (c, t) in profiled.items()}
         epilogue_roofline = {}
         for k in epi:
-            ms_k, n_k = extra[k]
-            if n_k:
-                nbytes = _C.traffic_bytes.get(k, 0) / 3.0
-                gbs = nbytes / (ms_k / 3.0 * 1e-3) / 1e9
-                epilogue_roofline[k] = {'launches_per_step': n_k // 3, 'us_per_step': round(ms_k / 3.0 * 1e3, 1),
-                                        'alg_bytes_per_step': int(nbytes), 'bound': 'hbm', 'achieved': round(gbs, 1),
-                                        'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(gbs / HBM_PEAK_GBS, 4)}
+            nbytes = _C.traffic_bytes.get(k, 0) / 3.0
+            if not nbytes:
+                continue
+            entry = {'alg_bytes_per_step': int(nbytes), 'bound': 'hbm', 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'us_per_step': None,
+                     'achieved': None, 'frac': None, 'time_source': None}
+            if k in profiled:
+                calls, us = profiled[k]
+                gbs = nbytes / (us * 1e-6) / 1e9
+                entry.update({'launches_per_step': round(calls, 1), 'us_per_step': round(us, 1), 'achieved': round(gbs, 1),
+                              'frac': round(gbs / HBM_PEAK_GBS, 4),
+                              'time_source': 'profiles/r04_bench_steady_kernel_stats.csv (rocprofv3 --kernel-trace --stats of this command)'})
+            epilogue_roofline[k] = entry
         # hipBLASLt launches its own kernels: the library can only put marker packets around the call, and a marker pair
         # includes the dispatch latency on both sides -- NOT comparable with the dispatch-timestamp figures in `kernels`
         ms_g, n_g = extra['gemm_bias_act']

@@ -18,7 +18,7 @@ SCALES = [4 * 2 ** (i / 3) for i in range(3)]
 
 def test_every_declared_symbol_is_exported():
     header = open(os.path.join(ROOT, 'include', 'odtk_hip.h')).read()
-    declared = set(re.findall(r'\b(odtk_[a-z_]+)\s*\(', header))
+    declared = set(re.findall(r'\b(odtk_[a-z0-9_]+)\s*\(', header))
     assert {'odtk_decode', 'odtk_decode_rotate', 'odtk_nms', 'odtk_nms_rotate', 'odtk_iou',
             'odtk_decode_levels', 'odtk_nms_ex', 'odtk_detect'} <= declared
     lib = _C.library()

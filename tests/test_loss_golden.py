@@ -51,8 +51,9 @@ def test_product_torch_loss_reproduces_the_reference(path):
     assert float(fg) == float(g['sums32'][2])
     for got, k in ((c, 0), (b, 1)):
         want32, want64 = float(g['sums32'][k]), float(g['sums64'][k])
-        assert abs(float(got) - want32) <= 2e-7 * abs(want32) + 1e-30, (k, float(got), want32)     # same expressions: fp32 rounding
-        assert abs(float(got) - want64) <= 3e-6 * abs(want64) + 1e-30
+        got = float(got.detach())
+        assert abs(got - want32) <= 2e-7 * abs(want32) + 1e-30, (k, got, want32)     # same expressions: fp32 rounding
+        assert abs(got - want64) <= 3e-6 * abs(want64) + 1e-30
     (c * float(g['g'][0]) + b * float(g['g'][1])).backward()
     for mine, ref in ((cls_head.grad, g['dcls']), (box_head.grad, g['dbox'])):
         ref = torch.from_numpy(ref)
