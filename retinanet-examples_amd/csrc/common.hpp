@@ -117,10 +117,4 @@ __device__ __forceinline__ uint64_t uniform_u64(uint64_t v) {
 template <typename T>
 __device__ __forceinline__ T *uniform_ptr(T *p) { return reinterpret_cast<T *>(uniform_u64(reinterpret_cast<uint64_t>(p))); }
 
-// Zero fill of a 16-byte aligned region (workspace counters / selection state), grid-stride.
-__global__ __launch_bounds__(256) void clear_kernel(uint4 *p, size_t n) {
-  const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
-  for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = make_uint4(0u, 0u, 0u, 0u);
-}
-
 }  // namespace odtk
