@@ -143,7 +143,18 @@ typedef struct odtk_level {
    *   box_bias  DEVICE float32 [A*nb]: delta = float(box) + box_bias[a*nb + k] in fp32. */
   const float *cls_bias;
   const float *box_bias;
+  /* Optional (may be NULL), with cls_bias: the prefilter's per-channel threshold table for THIS cls_bias, score_thresh and
+   * dtype, prepared once by odtk_prefilter_thresholds (an engine does it when it folds its weights).  Without it every
+   * workgroup of the prefilter derives the table from cls_bias before its first load.  The table carries what it was made
+   * for; one made for another threshold / dtype / channel count is ignored.  A table made from OTHER bias values is the
+   * caller's bug (remake it whenever cls_bias changes). */
+  const float *cls_thresholds;
 } odtk_level_t;
+
+/* odtk_prefilter_thresholds -- fills `table` (DEVICE, 16-byte aligned, ODTK_THRESHOLD_TABLE_FLOATS(channels) floats) for
+ * odtk_level_t::cls_thresholds.  cls_bias: DEVICE float32 [channels]; dtype: ODTK_BF16 / ODTK_F16; channels % 8 == 0. */
+#define ODTK_THRESHOLD_TABLE_FLOATS(channels) ((size_t)(channels) + 8)
+int odtk_prefilter_thresholds(const float *cls_bias, int channels, int dtype, float score_thresh, float *table, void *stream);
 
 /*
  * odtk_decode_levels -- ALL pyramid levels x whole batch in one enqueue (2 kernel launches: prefilter,

@@ -243,6 +243,7 @@ int decode_levels_impl(int batch, int n_levels, const odtk_level_t *levels, int 
         return ODTK_ERR_UNSUPPORTED;
       scan_lds = align_up(static_cast<size_t>(A) * C * sizeof(float));
       if (scan_lds > 48 * 1024) return ODTK_ERR_UNSUPPORTED;
+      if (reinterpret_cast<uintptr_t>(levels[l].cls_thresholds) & 15u) return ODTK_ERR_INVALID;
     }
   }
 
@@ -282,6 +283,7 @@ int decode_levels_impl(int batch, int n_levels, const odtk_level_t *levels, int 
     sa.lv[l].channels_last = static_cast<uint32_t>(levels[l].channels_last);
     sa.lv[l].by_channels = odtk::fastdiv_make(static_cast<uint32_t>(A) * C);
     sa.lv[l].bias = levels[l].cls_bias;
+    sa.lv[l].table = levels[l].cls_bias ? levels[l].cls_thresholds : nullptr;
     if (static_cast<unsigned long long>(scan_blocks) + 1ull * batch * lay.spans[l] > 0x7fffffffull) return ODTK_ERR_INVALID;
     scan_blocks += static_cast<uint32_t>(batch) * lay.spans[l];
 
@@ -964,6 +966,23 @@ int odtk_bias_act_maxpool(const void *y, const float *bias, void *out, int batch
   else { if (relu) ODTK_POOL(odtk::F16, true); else ODTK_POOL(odtk::F16, false); }
 #undef ODTK_POOL_
 #undef ODTK_POOL
+  ODTK_HIP_TRY(hipGetLastError());
+  return ODTK_OK;
+}
+
+int odtk_prefilter_thresholds(const float *cls_bias, int channels, int dtype, float score_thresh, float *table, void *stream) {
+  if (!cls_bias || !table || channels <= 0 || channels % 8 != 0) return ODTK_ERR_INVALID;
+  if (dtype != ODTK_BF16 && dtype != ODTK_F16) return ODTK_ERR_UNSUPPORTED;
+  if (reinterpret_cast<uintptr_t>(table) & 15u) return ODTK_ERR_INVALID;
+  const float raw_thr = logit_lower_bound(score_thresh);
+  const unsigned blocks = (static_cast<unsigned>(channels) + 255u) / 256u;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (dtype == ODTK_BF16)
+    hipLaunchKernelGGL(odtk::prefilter_table_kernel<odtk::BF16>, dim3(blocks), dim3(256), 0, s, cls_bias, static_cast<uint32_t>(channels), raw_thr,
+                       static_cast<uint32_t>(dtype), table);
+  else
+    hipLaunchKernelGGL(odtk::prefilter_table_kernel<odtk::F16>, dim3(blocks), dim3(256), 0, s, cls_bias, static_cast<uint32_t>(channels), raw_thr,
+                       static_cast<uint32_t>(dtype), table);
   ODTK_HIP_TRY(hipGetLastError());
   return ODTK_OK;
 }

@@ -76,6 +76,7 @@ struct ScanLevel {
   uint32_t channels_last;
   FastDiv by_channels;
   const float *bias;     // kLogits + channels_last only: per-channel bias of the head's last conv (null: none)
+  const float *table;    // with bias: the threshold table prepared by odtk_prefilter_thresholds, or null
 };
 
 struct ScanArgs {
@@ -188,6 +189,31 @@ __device__ __forceinline__ void scan_thresholds(float t, float *lo, float *hi) {
   }
 }
 
+// The threshold table of a level: 8 header words (word 0: a key of what the table was made for -- raw-domain threshold, dtype,
+// channel count --, the rest padding) then, per group of 8 consecutive channels, the 8 floats a lane compares one 16-byte load against: [0..3] for the
+// low halves of its four dwords (even channels), [4..7] for the high halves (odd channels).
+constexpr uint32_t kTableMagic = 0x4f44544bu;    // "ODTK"
+constexpr int kTableHeader = 8;
+__host__ __device__ inline uint32_t table_key(uint32_t raw_thr_bits, uint32_t dtype, uint32_t channels) {
+  return kTableMagic ^ raw_thr_bits ^ (dtype << 28) ^ (channels * 0x9e3779b1u);
+}
+
+template <typename T>
+__device__ __forceinline__ void table_entry(float raw_thr, float bias_c, uint32_t c, float *body) {
+  float lo, hi;
+  scan_thresholds<T>(raw_thr - bias_c - (1e-3f + 1e-6f * fabsf(bias_c)), &lo, &hi);   // margin >> fp32 rounding of raw + b
+  const uint32_t e = c & 7u;
+  body[(c & ~7u) + (e >> 1) + ((e & 1u) ? 4u : 0u)] = (e & 1u) ? hi : lo;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void prefilter_table_kernel(const float *__restrict__ bias, uint32_t channels, float raw_thr,
+                                                              uint32_t dtype, float *__restrict__ table) {
+  const uint32_t c = blockIdx.x * 256u + threadIdx.x;
+  if (c < channels) table_entry<T>(raw_thr, bias[c], c, table + kTableHeader);
+  if (c < static_cast<uint32_t>(kTableHeader)) table[c] = __uint_as_float(c == 0 ? table_key(__float_as_uint(raw_thr), dtype, channels) : 0u);
+}
+
 // launch bounds: >= 8 waves/SIMD for the 16-bit forms (64 VGPRs), >= 6 for fp32 (80 VGPRs): more workgroups in their
 // load phase while others drain (measured bf16 52.6 -> 48.4 us).  The element-load form (odd shapes) is not held to it.
 template <typename T, bool kLogits, bool kAligned>
@@ -239,17 +265,13 @@ __global__ __launch_bounds__(kScanThreads, (!kAligned ? 2 : sizeof(typename T::s
   // per-channel threshold that a lane fetches with two 16-byte LDS reads per load.
   // (16-bit dtypes only; the host rejects the fp32 combination)
   const float *bias = (kLogits && k16) ? L.bias : nullptr;   // block-uniform
-  if (bias) {
-    // (built BEFORE the tile's loads are issued: memory operations return in order, so a table load issued behind them
-    // would wait for the whole tile -- measured in round 1, and again as 8 B of scratch at the 64-register bound in round 4)
-    for (uint32_t c = tid; c < L.channels; c += kScanThreads) {
-      const float bc = bias[c];
-      float lo, hi;
-      scan_thresholds<T>(raw_thr - bc - (1e-3f + 1e-6f * fabsf(bc)), &lo, &hi);   // margin >> fp32 rounding of raw + b
-      const uint32_t e = c & 7u;
-      s_thr[(c & ~7u) + (e >> 1) + ((e & 1u) ? 4u : 0u)] = (e & 1u) ? hi : lo;
-    }
-  }
+  // The table comes (a) ready-made from the caller (up to 1024 channels): its header and one 16-byte load per lane are issued
+  // IN FRONT of the tile's loads, checked and written to LDS while those are in flight --, or (b) is built here from the
+  // bias, before the tile's loads are issued (memory operations return in order: a bias load issued behind them would wait
+  // for the whole tile -- measured in round 1, and again as 8 B of scratch at the 64-register bound in round 4).
+  const bool tbl_pending = bias && L.table && L.channels <= 4u * kScanThreads;   // (block-uniform: kernel arguments only)
+  if (bias && !tbl_pending)
+    for (uint32_t c = tid; c < L.channels; c += kScanThreads) table_entry<T>(raw_thr, bias[c], c, s_thr);
   float u_lo = raw_thr, u_hi = raw_thr;                    // without a bias: one threshold pair for every channel
   if constexpr (k16) scan_thresholds<T>(raw_thr, &u_lo, &u_hi);
 
@@ -263,8 +285,15 @@ __global__ __launch_bounds__(kScanThreads, (!kAligned ? 2 : sizeof(typename T::s
     if (tile_off >= span_len) break;
     const uint32_t tile_len = span_len - tile_off < static_cast<uint32_t>(kTile) ? span_len - tile_off : kTile;
 
+    // (a ready-made table: header + this lane's 16 bytes, issued in front of the tile's loads -- inside the iteration, so that
+    // the wait-count pass orders them against the tile's loads instead of draining everything at the loop's entry)
+    vuint4 tbl = vuint4{0u, 0u, 0u, 0u};
+    uint32_t hdr = 0;
+    if (t == 0 && tbl_pending) {
+      hdr = *reinterpret_cast<const uint32_t *>(L.table);  // what the table was made for: checked once it has arrived
+      if (static_cast<uint32_t>(tid) < L.channels / 4) tbl = *(reinterpret_cast<const vuint4 *>(L.table + kTableHeader) + tid);
+    }
     // issue all loads first (kVec x 16 B per lane, lane-contiguous => fully coalesced).  Padding: a large negative
-    // finite value (it fails every sensible threshold; the drain drops whatever it does not fail by its offset)
     constexpr uint32_t kPadWord = k16 ? 0xff7fff7fu : 0xff7fffffu;
     vuint4 v[kVec];
     if constexpr (kAligned) {
@@ -300,7 +329,21 @@ __global__ __launch_bounds__(kScanThreads, (!kAligned ? 2 : sizeof(typename T::s
         }
       }
     }
-    if (t == 0) __syncthreads();                           // the threshold table is visible; overlaps the load latency
+    if (t == 0) {
+      if (tbl_pending) {
+        const bool ready = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(hdr)) ==
+                           table_key(__float_as_uint(raw_thr), std::is_same_v<T, BF16> ? ODTK_BF16 : ODTK_F16, L.channels);
+        // A table made for something else (another threshold / dtype / channel count: the caller's doing) is replaced by
+        // thresholds that EVERY element passes (-inf; NaN for bf16's `!(w < t)` form): the waves overflow their stage, mark
+        // their sub-lists kListOverflow and select_decode re-reads the raw scores -- slow, and exact.
+        if (!ready) {
+          const uint32_t pass = (std::is_same_v<T, BF16> && (tid & 1)) ? 0x7fc00000u : 0xff800000u;   // (odd vectors: the high halves)
+          tbl = vuint4{pass, pass, pass, pass};
+        }
+        if (static_cast<uint32_t>(tid) < L.channels / 4) *(reinterpret_cast<vuint4 *>(s_thr) + tid) = tbl;
+      }
+      __syncthreads();                                     // the threshold table is visible; overlaps the load latency
+    }
 
     // channel group (kPer consecutive channels) of the lane's load u: (first group of the tile + u*256 + tid) mod G
     uint32_t g = 0, g_step = 0, G = 1;

@@ -61,7 +61,7 @@ class Level(ctypes.Structure):
     """odtk_level_t"""
     _fields_ = [('cls', _vp), ('box', _vp), ('height', ctypes.c_int32), ('width', ctypes.c_int32),
                 ('stride', ctypes.c_int32), ('channels_last', ctypes.c_int32), ('anchors', _fp),
-                ('cls_bias', _vp), ('box_bias', _vp)]
+                ('cls_bias', _vp), ('box_bias', _vp), ('cls_thresholds', _vp)]
 
 
 _SIGNATURES = {
@@ -105,6 +105,7 @@ _SIGNATURES = {
     'odtk_snap_to_anchors_rotated_levels': (ctypes.c_int, [ctypes.c_int, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int,
                                                            ctypes.POINTER(SnapRotLevel), ctypes.c_int, ctypes.c_int, ctypes.c_float,
                                                            ctypes.c_float, _vp]),
+    'odtk_prefilter_thresholds': (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_float, _vp, _vp]),
     'odtk_upsample_nearest2x': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                ctypes.c_int, ctypes.c_void_p]),
     'odtk_gemm_init': (ctypes.c_int, [ctypes.c_char_p]),
@@ -299,7 +300,24 @@ def _layout(t, name):
     raise RuntimeError('%s must be contiguous (NCHW or channels_last)' % name)
 
 
-def _levels(cls_heads, box_heads, anchors_list, strides, nb, cls_bias=None, box_bias=None):
+def prefilter_thresholds(cls_bias, dtype, score_thresh):
+    """The prefilter's per-channel threshold table for `cls_bias` (float32 CUDA vector [A*C], A*C % 8 == 0), a 16-bit head
+    dtype and a score threshold: made ONCE (an engine: when it folds its weights) and handed to decode_levels / detect as
+    `cls_thresholds`, so that the ~3750 workgroups of the prefilter load 2880 ready bytes instead of deriving them from the
+    bias before their first load.  A table made for other parameters is detected and not used."""
+    if not cls_bias.is_cuda or cls_bias.dtype != torch.float32 or not cls_bias.is_contiguous() or cls_bias.numel() % 8:
+        raise RuntimeError('prefilter_thresholds: cls_bias must be a contiguous float32 CUDA vector whose length is a multiple of 8')
+    if dtype not in (torch.bfloat16, torch.float16):
+        raise RuntimeError('prefilter_thresholds: 16-bit head dtypes only')
+    table = torch.empty(cls_bias.numel() + 8, dtype=torch.float32, device=cls_bias.device)
+    with torch.cuda.device(cls_bias.device):
+        stream = torch.cuda.current_stream(cls_bias.device).cuda_stream
+        _check(library().odtk_prefilter_thresholds(cls_bias.data_ptr(), cls_bias.numel(), _DTYPES[dtype], float(score_thresh),
+                                                   table.data_ptr(), stream), 'prefilter_thresholds')
+    return table
+
+
+def _levels(cls_heads, box_heads, anchors_list, strides, nb, cls_bias=None, box_bias=None, cls_thresholds=None):
     """Fill the odtk_level_t table.  Head tensors are taken AS THE CONVOLUTION WROTE THEM: float32 /
     bfloat16 / float16, NCHW or channels_last -- no .float(), no .contiguous() (reference
     model.py:160, box.py:263 make both copies)."""
@@ -334,7 +352,8 @@ def _levels(cls_heads, box_heads, anchors_list, strides, nb, cls_bias=None, box_
         arr[i].stride = int(s)
         arr[i].channels_last = lay
         arr[i].anchors = ctypes.cast(carr, _fp)
-        for name, bias, width in (('cls_bias', cls_bias, c.shape[1]), ('box_bias', box_bias, b.shape[1])):
+        for name, bias, width in (('cls_bias', cls_bias, c.shape[1]), ('box_bias', box_bias, b.shape[1]),
+                                  ('cls_thresholds', cls_thresholds if cls_bias is not None else None, c.shape[1] + 8)):
             if bias is None:
                 continue
             t = bias[i] if isinstance(bias, (list, tuple)) else bias      # one tensor shared by all levels, or a list
@@ -349,7 +368,7 @@ def _levels(cls_heads, box_heads, anchors_list, strides, nb, cls_bias=None, box_
 
 
 def decode_levels(cls_heads, box_heads, anchors_list, strides, score_thresh, top_n, rotated=False,
-                  return_indices=False, logits=False, cls_bias=None, box_bias=None):
+                  return_indices=False, logits=False, cls_bias=None, box_bias=None, cls_thresholds=None):
     """All levels x whole batch in one enqueue; returns tensors already in the layout of
     `torch.cat(per_level, 1)` (odtk/model.py:164): [B, L*top_n], [B, L*top_n, nb], [B, L*top_n].
     logits=True: cls_heads hold raw logits and the sigmoid is fused into the prefilter.
@@ -358,7 +377,7 @@ def decode_levels(cls_heads, box_heads, anchors_list, strides, score_thresh, top
     lib = library()
     nb = 6 if rotated else 4
     arr, keep, batch, num_anchors, num_classes, dtype = _levels(cls_heads, box_heads, anchors_list, strides, nb,
-                                                                cls_bias, box_bias)
+                                                                cls_bias, box_bias, cls_thresholds)
     dev = cls_heads[0].device
     n = len(cls_heads)
     with torch.cuda.device(dev):
@@ -378,13 +397,13 @@ def decode_levels(cls_heads, box_heads, anchors_list, strides, score_thresh, top
 
 
 def detect(cls_heads, box_heads, anchors_list, strides, score_thresh, top_n, nms_thresh, detections_per_im,
-           rotated=False, logits=False, cls_bias=None, box_bias=None):
+           rotated=False, logits=False, cls_bias=None, box_bias=None, cls_thresholds=None):
     """decode_levels + nms back to back (the whole of odtk/model.py:140-165): three launches -- prefilter, select + decode, nms
     -- (rotated boxes: five to seven), no host synchronisation, one workspace."""
     lib = library()
     nb = 6 if rotated else 4
     arr, keep, batch, num_anchors, num_classes, dtype = _levels(cls_heads, box_heads, anchors_list, strides, nb,
-                                                                cls_bias, box_bias)
+                                                                cls_bias, box_bias, cls_thresholds)
     dev = cls_heads[0].device
     n = len(cls_heads)
     with torch.cuda.device(dev):

@@ -401,10 +401,11 @@ def decode_levels(cls_heads, box_heads, strides, threshold, top_n, anchors_per_s
 
 
 def detect(cls_heads, box_heads, strides, anchors_per_stride, threshold=0.05, top_n=1000, nms=0.5,
-           ndetections=100, rotated=False, logits=False, cls_bias=None, box_bias=None):
+           ndetections=100, rotated=False, logits=False, cls_bias=None, box_bias=None, cls_thresholds=None):
     """sigmoid (logits=True) + decode of all levels + nms: the whole inference post-processing of the
-    reference (model.py:140-165) in one enqueue of six launches (rotated: eight to ten), reading the head tensors in place.
-    cls_bias / box_bias: the heads' last-conv biases, added inside the kernels (see _C.decode_levels)."""
+    reference (model.py:140-165) in one enqueue of three launches (rotated: five to seven), reading the head tensors in place.
+    cls_bias / box_bias: the heads' last-conv biases, added inside the kernels (see _C.decode_levels); cls_thresholds: the
+    prefilter's threshold table for that cls_bias, made once by _C.prefilter_thresholds (optional)."""
     anchors = [anchors_per_stride[s][0] if rotated else anchors_per_stride[s] for s in strides]
     for t in cls_heads:
         _require_gpu(t, 'detect')
@@ -422,4 +423,4 @@ def detect(cls_heads, box_heads, strides, anchors_per_stride, threshold=0.05, to
                                           cls_bias=bias_of(cls_bias, lo, hi), box_bias=bias_of(box_bias, lo, hi)))
         return _C.nms(*[torch.cat(t, 1) for t in zip(*parts)], nms, ndetections, rotated)
     return _C.detect([p[0] for p in pairs], [p[1] for p in pairs], anchors, strides, threshold, top_n, nms,
-                     ndetections, rotated, logits=logits, cls_bias=cls_bias, box_bias=box_bias)
+                     ndetections, rotated, logits=logits, cls_bias=cls_bias, box_bias=box_bias, cls_thresholds=cls_thresholds)

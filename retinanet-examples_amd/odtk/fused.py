@@ -23,6 +23,8 @@ Measured on MI355X those passes cost more than the convolutions between them.  H
 `FusedRetinaNet(model)` is a drop-in for `model.eval()` inference: same outputs up to the rounding of
 the folded weights (tests/test_gpu_fused_model.py).
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -147,6 +149,7 @@ class FusedRetinaNet(nn.Module):
         self._streams = None
         self.tower_plan = 0
         self._graphs = {}                                               # input geometry -> (hipGraph, static input, outputs)
+        self._thresholds = {}                                           # score threshold -> the prefilter's table for cls_head[-1].bias
         self.max_graphs = 8
 
     def features(self, x):
@@ -280,5 +283,14 @@ class FusedRetinaNet(nn.Module):
         strides = [x.shape[-1] // c.shape[-1] for c in cls_heads]
         for s in strides:
             m.level_anchors(s)
+        table = None
+        if fold and cls_bias.is_cuda and not os.environ.get('ODTK_NO_THRESHOLD_TABLE'):
+            # the prefilter's per-channel threshold table: made once per (threshold, state of the bias vector); a capture
+            # finds the one its eager warm-up passes made (without: the kernels derive the thresholds themselves)
+            key = (float(m.threshold), cls_bias.data_ptr(), cls_bias._version)
+            table = self._thresholds.get(key)
+            if table is None and not torch.cuda.is_current_stream_capturing():
+                self._thresholds.clear()
+                table = self._thresholds[key] = _C.prefilter_thresholds(cls_bias, self.dtype, m.threshold)
         return box_ops.detect(cls_heads, box_heads, strides, m.anchors, m.threshold, m.top_n, m.nms, m.detections,
-                              m.rotated_bbox, logits=True, cls_bias=cls_bias, box_bias=box_bias)
+                              m.rotated_bbox, logits=True, cls_bias=cls_bias, box_bias=box_bias, cls_thresholds=table)

@@ -158,6 +158,13 @@ def test_new_entry_points_validate_before_touching_the_device():
     assert lib.odtk_decode_levels(2, 1, lv, 9, 3, _C.BF16, _C.FLAG_LOGITS, 0.05, 100, None, 0, None, 0, None) == _C.ERR_UNSUPPORTED
     lv[0].channels_last = 0
     assert lib.odtk_decode_levels(2, 1, lv, 9, 80, _C.BF16, _C.FLAG_LOGITS, 0.05, 100, None, 0, None, 0, None) == _C.ERR_UNSUPPORTED
+    # the prefilter's threshold table: 16-byte aligned, 16-bit dtypes, A*C % 8 == 0
+    lv[0].channels_last, lv[0].cls_thresholds = 1, 4096 + 8
+    assert lib.odtk_decode_levels(2, 1, lv, 9, 80, _C.BF16, _C.FLAG_LOGITS, 0.05, 100, None, 0, None, 0, None) == _C.ERR_INVALID
+    assert lib.odtk_prefilter_thresholds(None, 720, _C.BF16, 0.05, 4096, None) == _C.ERR_INVALID
+    assert lib.odtk_prefilter_thresholds(4096, 720, _C.BF16, 0.05, 4096 + 8, None) == _C.ERR_INVALID
+    assert lib.odtk_prefilter_thresholds(4096, 723, _C.BF16, 0.05, 8192, None) == _C.ERR_INVALID
+    assert lib.odtk_prefilter_thresholds(4096, 720, _C.F32, 0.05, 8192, None) == _C.ERR_UNSUPPORTED
 
 
 def test_loss_tuning_hook_validates_without_a_gpu():

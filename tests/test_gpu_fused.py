@@ -201,6 +201,20 @@ def test_head_bias_folded_into_the_kernels(dtype, rotated):
     assert torch.equal(got[0], ref[0]) and torch.equal(got[2], ref[2])
     assert torch.equal(got[1], ref[1])                    # same fp32 deltas into the same box arithmetic
     assert (got[0] > 0).sum().item() > 300                # the case is not vacuous
+    # the prefilter's precomputed threshold table: the same outputs bit for bit; a table made for another threshold, dtype
+    # or bias length is recognised by its key word and not used (the prefilter then passes everything to the exact test)
+    table = _C.prefilter_thresholds(cls_bias, dtype, 0.05)
+    assert table.numel() == a * c + 8
+    other = torch.float16 if dtype == torch.bfloat16 else torch.bfloat16
+    stale = [_C.prefilter_thresholds(cls_bias, dtype, 0.3), _C.prefilter_thresholds(cls_bias, other, 0.05),
+             torch.zeros_like(table)]
+    for t in [table] + stale:
+        again = _C.decode_levels(cls, box_h, alist, strides, 0.05, 300, rotated, return_indices=True, logits=True,
+                                 cls_bias=cls_bias, box_bias=box_bias, cls_thresholds=t)
+        assert all(torch.equal(x, y) for x, y in zip(again, got))
+    with pytest.raises(RuntimeError):                     # wrong length
+        _C.decode_levels(cls, box_h, alist, strides, 0.05, 300, rotated, logits=True, cls_bias=cls_bias,
+                         cls_thresholds=table[:-8].contiguous())
     # the fold is refused where it cannot be exact-by-construction
     with pytest.raises(RuntimeError):
         _C.decode_levels([x.float() for x in cls], [x.float() for x in box_h], alist, strides, 0.05, 300, rotated,

@@ -40,6 +40,7 @@ def main():
     ap.add_argument('--logits', action='store_true', help='feed raw logits (sigmoid fused into the prefilter)')
     ap.add_argument('--channels-last', action='store_true')
     ap.add_argument('--bias', action='store_true', help='pass the last-conv biases to the kernels (cls_bias / box_bias)')
+    ap.add_argument('--table', action='store_true', help='with --bias: also the precomputed threshold table (cls_thresholds)')
     ap.add_argument('--torch-baselines', action='store_true', help='also time torch read-only / copy passes')
     args = ap.parse_args()
 
@@ -81,10 +82,11 @@ def main():
     if args.bias:
         cls_bias = torch.randn(args.anchors * args.classes, generator=g, device=dev) * 0.05
         box_bias = torch.randn(args.anchors * nb, generator=g, device=dev) * 0.05
+    table = _C.prefilter_thresholds(cls_bias, tdt, args.threshold) if args.bias and args.table else None
 
     def run():
         return box.detect(cls, dl, list(strides), anchors, args.threshold, 1000, 0.5, args.ndet, args.rotated,
-                          logits=args.logits, cls_bias=cls_bias, box_bias=box_bias)
+                          logits=args.logits, cls_bias=cls_bias, box_bias=box_bias, cls_thresholds=table)
 
     for _ in range(args.warmup):
         out = run()
