@@ -107,15 +107,17 @@ struct SupArgs {
 };
 
 constexpr int kSupThreads = 256;
+constexpr uint32_t kSupRows = 4;       // rows of a 64 x 64 tile per workgroup: at most ONE clip per thread (16 rows: up to four, one
+                                       // after the other, ~4 us each -- the densest slice set the launch's 18-21 us in round 3)
 
-// One workgroup per 16 x 64 slice of a 64 x 64 tile of (i < j) candidate pairs and image (four clips per thread at most: a
+// One workgroup per kSupRows x 64 slice of a 64 x 64 tile of (i < j) candidate pairs and image (one clip per thread at most: a
 // lone wave needs ~3..5 us per clip, so the work has to be wide, not deep).  A wave that clipped a whole row whenever ONE of its
 // 64 columns needed it paid ~46 000 wave-clips at m = 800 (44 us, VALU-bound) for pairs of which a quarter needed the clip;
 // so, as in the NMS kernel itself: enumerate the tile's pairs (class, distance reject), append the ones that need the
 // polygon clip to a queue in LDS, drain the queue one pair per thread, OR the verdicts into the tile's 64 row words.
 __global__ __launch_bounds__(kSupThreads) void rotated_sup_matrix_kernel(const SupArgs a) {
   __shared__ float2 s_clip[(kSupThreads / kWave) * kClipSlotsPerWave];
-  constexpr uint32_t kRows = 16, kSlices = 64 / kRows;         // rows of the tile this workgroup takes
+  constexpr uint32_t kRows = kSupRows, kSlices = 64 / kRows;   // rows of the tile this workgroup takes
   __shared__ float s_rows[kRows * 6], s_cols[64 * 6], s_rcls[kRows];
   __shared__ uint32_t s_words[kRows * 2];
   __shared__ uint16_t s_queue[kRows * 64];
@@ -323,6 +325,7 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsArgs a) {
   uint32_t *s_dead = s_misc + 112;
   uint64_t *s_sup = reinterpret_cast<uint64_t *>(smem + Fixed::sup);
   float2 *s_clip = reinterpret_cast<float2 *>(smem + lay.clip);     // rotated only
+  uint64_t *s_mat = reinterpret_cast<uint64_t *>(smem + lay.clip);  // stage 2: the suppression matrix (until the first polygon is clipped)
   uint64_t *s_win = reinterpret_cast<uint64_t *>(s_hist);           // sorted-run mode: the runs' probed slots
   uint32_t *s_queue = s_hist;                                       // rotated: pair queue (chunk phase; never while a round is selected)
   const int ways = lay.ways;
@@ -398,9 +401,36 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsArgs a) {
   };
 
   uint32_t left = 0;                 // candidates not yet handed to a round (block-uniform)
+  uint32_t my_valid = 0;
+  if (runs && tid < 8 && static_cast<uint32_t>(tid) < n_runs) my_valid = a.run_valid[static_cast<size_t>(img) * n_runs + tid];
+  if constexpr (kStage == 2) {
+    // Stage 1 selected and ordered the first round already: its keys, the boxes / classes of the candidates the matrix covers
+    // (stage 1 exported them in order: coalesced, and not behind the keys as a gather is) and the matrix itself are requested
+    // HERE, together with the runs' lengths: ONE global latency for everything the first round needs (round 3: lengths ->
+    // state -> keys -> gather, and two more per chunk for the matrix words).  Ranks the round does not have are never read
+    // (their dead bits are set); ranks >= m_max are staged when -- if -- a chunk gets there.
+    const uint64_t my_key = a.first_keys[static_cast<size_t>(img) * kNmsRound + tid];
+    float fb[NB], fc = 0.0f;
+#pragma unroll
+    for (int k = 0; k < NB; ++k) fb[k] = 0.0f;
+    if (static_cast<uint32_t>(tid) < a.m_max) {
+#pragma unroll
+      for (int k = 0; k < NB; ++k) fb[k] = a.first_box[(static_cast<size_t>(img) * a.m_max + tid) * NB + k];
+      fc = a.first_cls[static_cast<size_t>(img) * a.m_max + tid];
+    }
+    // the rows of the matrix this step can use, as they lie in memory (row stride m_max / 64 words): a flat, coalesced copy
+    const uint32_t n_vec = (a.step == 1 ? a.m_first : a.m_max) * (a.m_max / 64) / 2;
+    const vuint4 *sup = reinterpret_cast<const vuint4 *>(a.sup + static_cast<size_t>(img) * a.m_max * (a.m_max / 64));
+    vuint4 *dst = reinterpret_cast<vuint4 *>(s_mat);
+    for (uint32_t e = tid; e < n_vec; e += kNmsThreads) dst[e] = sup[e];
+    s_sel[tid] = my_key;
+#pragma unroll
+    for (int k = 0; k < NB; ++k) s_box[tid * NB + k] = fb[k];
+    s_cls[tid] = fc;
+  }
   if (runs) {
     if (tid < 8) {
-      const uint32_t v = static_cast<uint32_t>(tid) < n_runs ? a.run_valid[static_cast<size_t>(img) * n_runs + tid] : 0u;
+      const uint32_t v = my_valid;
       s_valid[tid] = v < a.run_len ? v : a.run_len;
       s_cursor[tid] = 0;
     }
@@ -563,12 +593,7 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsArgs a) {
         }
         while (kept < ndet) {                                  // block-uniform trip count
           const uint64_t b01 = mk[0] > mk[1] ? mk[0] : mk[1], b23 = mk[2] > mk[3] ? mk[2] : mk[3];
-          uint64_t best = b01 > b23 ? b01 : b23;
-#pragma unroll
-          for (int d = 32; d > 0; d >>= 1) {
-            const uint64_t o = shfl_xor_u64(best, d);
-            best = o > best ? o : best;
-          }
+          uint64_t best = wave_max_u64(b01 > b23 ? b01 : b23);   // (DPP row shifts / broadcasts: no LDS crossbar round trips)
           if (lane == 0) s_alive[wave] = best;
           __syncthreads();
           best = 0;
@@ -608,81 +633,127 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsArgs a) {
     // ---- round: the next (up to) 1024 best candidates, in order, into s_sel ----
     uint32_t n_round = left < kNmsRound ? left : kNmsRound;
     if (kStage == 2 && first_round) {
-      // stage 1 selected and ordered this round already: take its keys and the state of the selection after it
+      // stage 1 selected and ordered this round already (its keys, boxes and matrix are in LDS since the kernel's first
+      // instructions): its size and the state of the selection after it
       const uint32_t *state = a.first_state + static_cast<size_t>(img) * 16;
       n_round = __builtin_amdgcn_readfirstlane(state[0]);
-      if (static_cast<uint32_t>(tid) < n_round) s_sel[tid] = a.first_keys[static_cast<size_t>(img) * kNmsRound + tid];
       if (runs) { if (tid < 8) s_cursor[tid] = state[1 + tid]; }
       else upper = uniform_u64(static_cast<uint64_t>(state[1]) | (static_cast<uint64_t>(state[2]) << 32));
       __syncthreads();
-    } else if (runs && kStage != 0) {
-      // Rotated, staged: the first round should be as long as the suppression matrix (m_max, several hundred candidates), and
-      // the probe below returns as few as 1024 / n_runs when one level dominates.  Exact top-min(left, 1024) instead: every
-      // run's next min(avail, 1024) keys are laid out window after window in the key list's space, and a key's position in the
-      // round is its offset in its own run + the number of larger keys in every other window (binary searches, advanced
-      // together); keys with a position below the target are the round, already in order.
-      const uint32_t target = n_round;
-      uint32_t w_n[8], w_base[9];
-      w_base[0] = 0;
-#pragma unroll
-      for (uint32_t q = 0; q < 8; ++q) {
-        const uint32_t avail = q < n_runs ? s_valid[q] - s_cursor[q] : 0u;
-        w_n[q] = __builtin_amdgcn_readfirstlane(avail < kNmsRound ? avail : kNmsRound);
-        w_base[q + 1] = w_base[q] + w_n[q];
-      }
-      const uint32_t total = w_base[8];
-      uint32_t p2 = 1;
-      while (p2 < kNmsRound && p2 < total) p2 <<= 1;
-      auto slot_of = [&](uint32_t f, uint32_t *q_out, uint32_t *j_out) {
-        uint32_t q = 0, base = 0;
-#pragma unroll
-        for (uint32_t t = 1; t < 8; ++t) {
-          const bool past = f >= w_base[t];
-          q = past ? t : q;
-          base = past ? w_base[t] : base;
+    } else if (runs && kStage == 1) {
+      // Rotated, stage 1 (= the first round: every cursor is zero).  The round should be as long as the suppression matrix
+      // (m_max, several hundred candidates), and the probe of 1024 / n_runs slots per run (below) returns as few as
+      // 1024 / n_runs when one level dominates.  Exact top-`want` (want = min(left, m_max)) instead, in two steps on the
+      // runs' first min(valid, 1024) keys, loaded ONCE, window after window, into the key list's space:
+      //   cut    wave q <-> run q: 64 evenly spaced sample keys of the window, each ranked against all windows (one binary
+      //          search per run, advanced together); ranks are monotone along a run, so the first sample with rank >= want
+      //          bounds what the run can contribute: its prefix [0, u_q); the prefixes hold want + n_runs x 16 keys at most
+      //   rank   thread <-> key of a prefix: its exact rank (the same searches, over the prefixes only); rank < want -> it is
+      //          in the round, at position `rank`.
+      // Round 3 ranked ALL window keys (~5000) against all windows: 21 us; a first attempt this round repeated the 1024 / n_runs
+      // probe on the windows until the round was long enough: 42 us when one level dominates (8 probes).
+      uint32_t *s_wbase = s_misc + 96, *s_upto = s_misc + 104;   // (the probe keys of the generic form are not used here)
+      if (tid == 0) {
+        uint32_t acc = 0;
+        for (uint32_t q = 0; q < 8; ++q) {
+          s_wbase[q] = acc;
+          const uint32_t v = q < n_runs ? s_valid[q] : 0u;
+          acc += v < kNmsRound ? v : kNmsRound;
         }
-        *q_out = q;
-        *j_out = f - base;
-      };
+        s_misc[33] = acc;
+      }
+      __syncthreads();
+      const uint32_t total = __builtin_amdgcn_readfirstlane(s_misc[33]);
       for (uint32_t f = tid; f < total; f += kNmsThreads) {
-        uint32_t q, j;
-        slot_of(f, &q, &j);
-        const uint32_t p = q * a.run_len + s_cursor[q] + j;
+        uint32_t q = 0;
+#pragma unroll
+        for (uint32_t t = 1; t < 8; ++t) q += (t < n_runs && f >= s_wbase[t]) ? 1u : 0u;
+        const uint32_t p = q * a.run_len + (f - s_wbase[q]);
         s_keys[f] = make_key(in_s[p], p);
       }
       __syncthreads();
-      for (uint32_t f = tid; f < total; f += kNmsThreads) {
-        uint32_t q, j;
-        slot_of(f, &q, &j);
-        if (j >= target) continue;                             // its own run alone puts `target` keys above it
-        const uint64_t key = s_keys[f];
+      const uint32_t want = left < a.m_max ? left : a.m_max;   // (<= the windows' total: a window is the whole run or 1024 keys)
+      uint32_t w_n[8], w_b[8];                                 // the windows (block-uniform)
+#pragma unroll
+      for (uint32_t q = 0; q < 8; ++q) {
+        const uint32_t v = q < n_runs ? s_valid[q] : 0u;
+        w_n[q] = v < kNmsRound ? v : kNmsRound;
+        w_b[q] = w_n[q] ? s_wbase[q] : 0u;
+      }
+      // #{keys of the windows' first lim[.] entries above `key`}: the binary searches of all runs advance together
+      auto rank_of = [&](uint64_t key, const uint32_t *lim, uint32_t p2) {
         uint32_t lo[8];
 #pragma unroll
-        for (uint32_t t = 0; t < 8; ++t) lo[t] = 0;
+        for (uint32_t q = 0; q < 8; ++q) lo[q] = 0;
         for (uint32_t s2 = p2; s2 > 0; s2 >>= 1) {
 #pragma unroll
-          for (uint32_t t = 0; t < 8; ++t) {
-            if (t < n_runs) {                                  // (block-uniform; the key's own window is searched like the others:
-              const uint32_t at = lo[t] + s2;                  //  the count there is its own offset -- no per-thread exception,
-              const bool in_range = at <= w_n[t];              //  every load of a trip is unconditional and in flight together)
-              const uint64_t v = s_keys[w_base[t] + (in_range ? at - 1 : 0u)];
-              lo[t] = in_range && v > key ? at : lo[t];
+          for (uint32_t q = 0; q < 8; ++q) {
+            if (q < n_runs) {                                  // (block-uniform)
+              const uint32_t at = lo[q] + s2;
+              const bool in_range = at <= lim[q];
+              const uint64_t v = s_keys[w_b[q] + (in_range ? at - 1 : 0u)];
+              lo[q] = in_range && v > key ? at : lo[q];
             }
           }
         }
         uint32_t rank = 0;
 #pragma unroll
-        for (uint32_t t = 0; t < 8; ++t) rank += lo[t];
-        if (rank < target) s_sel[rank] = key;
+        for (uint32_t q = 0; q < 8; ++q) rank += lo[q];
+        return rank;
+      };
+      if (static_cast<uint32_t>(wave) < n_runs) {              // cut
+        uint32_t my_n = 0, my_b = 0;
+#pragma unroll
+        for (uint32_t q = 0; q < 8; ++q) { my_n = q == static_cast<uint32_t>(wave) ? w_n[q] : my_n; my_b = q == static_cast<uint32_t>(wave) ? w_b[q] : my_b; }
+        uint32_t upto = 0;
+        if (my_n) {                                            // (wave-uniform)
+          const uint32_t stride = (my_n + 63u) / 64u;
+          uint32_t pos = (static_cast<uint32_t>(lane) + 1u) * stride;
+          pos = (pos < my_n ? pos : my_n) - 1u;                // the window's last key closes the samples
+          const bool in = rank_of(s_keys[my_b + pos], w_n, kNmsRound) < want;
+          const uint32_t n_in = static_cast<uint32_t>(__popcll(__ballot(in)));   // monotone: the first n_in samples
+          // the first sample that is out sits at (n_in + 1) * stride - 1 (or is the window's last key): nothing from there on
+          const uint32_t first_out = (n_in + 1u) * stride - 1u;
+          upto = n_in == 64u ? my_n : (first_out < my_n ? first_out : my_n - 1u);
+        }
+        if (lane == 0) s_upto[wave] = upto;
+      }
+      __syncthreads();
+      uint32_t u_n[8], u_base[9];
+      u_base[0] = 0;
+      uint32_t longest = 0;
+#pragma unroll
+      for (uint32_t q = 0; q < 8; ++q) {
+        u_n[q] = q < n_runs ? __builtin_amdgcn_readfirstlane(s_upto[q]) : 0u;
+        u_base[q + 1] = u_base[q] + u_n[q];
+        longest = u_n[q] > longest ? u_n[q] : longest;
+      }
+      uint32_t p2 = 1;
+      while (p2 < longest) p2 <<= 1;
+      if (static_cast<uint32_t>(tid) < u_base[8]) {            // rank (u_base[8] <= want + 16 n_runs <= 1024)
+        uint32_t q = 0, base = 0;
+#pragma unroll
+        for (uint32_t t = 1; t < 8; ++t) {
+          const bool past = static_cast<uint32_t>(tid) >= u_base[t];
+          q = past ? t : q;
+          base = past ? u_base[t] : base;
+        }
+        uint32_t my_b = 0;
+#pragma unroll
+        for (uint32_t t = 0; t < 8; ++t) my_b = t == q ? w_b[t] : my_b;
+        const uint64_t key = s_keys[my_b + (static_cast<uint32_t>(tid) - base)];
+        const uint32_t rank = rank_of(key, u_n, p2);
+        if (rank < want) s_sel[rank] = key;
       }
       __syncthreads();
       if (static_cast<uint32_t>(tid) < n_runs) {               // how far every run was consumed: its keys >= the round's last key
-        uint32_t q = static_cast<uint32_t>(tid), n_w = 0, base = 0;
+        uint32_t n_w = 0, b_w = 0;
 #pragma unroll
-        for (uint32_t t = 0; t < 8; ++t) { n_w = t == q ? w_n[t] : n_w; base = t == q ? w_base[t] : base; }
-        s_cursor[q] += count_above<false>(s_keys + base, n_w, s_sel[target - 1], p2);
+        for (uint32_t t = 0; t < 8; ++t) { n_w = t == static_cast<uint32_t>(tid) ? u_n[t] : n_w; b_w = t == static_cast<uint32_t>(tid) ? w_b[t] : b_w; }
+        s_cursor[tid] += count_above<false>(s_keys + b_w, n_w, s_sel[want - 1], p2);
       }
       __syncthreads();
+      n_round = want;
     } else if (runs) {
       // slot t = (run l, offset j): the next `step` candidates of every run.  T = the largest of the runs' LAST examined
       // keys; the members of the round are the slots with key >= T: no run can hold an unexamined key >= T (its last
@@ -781,7 +852,7 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsArgs a) {
     phase(1);
 
     // thread t <-> rank `t` of this round: stage its box + class in LDS
-    if (static_cast<uint32_t>(tid) < n_round) {
+    if (static_cast<uint32_t>(tid) < n_round && !(kStage == 2 && first_round)) {
       const uint32_t p = key_index(s_sel[tid]);
 #pragma unroll
       for (int k = 0; k < NB; ++k) s_box[tid * NB + k] = in_b[static_cast<size_t>(p) * NB + k];
@@ -905,6 +976,18 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsArgs a) {
       cstamp(0);
       const uint32_t r = c0 + lane;                           // rank inside the round (< 1024)
       const uint32_t n_chunk = n_round - c0 < kNmsChunk ? n_round - c0 : kNmsChunk;
+      if constexpr (kStage == 2) {
+        if (first_round && c0 == a.m_max) {                    // beyond what stage 1 exported: gather the rest of the round
+          const uint32_t t = static_cast<uint32_t>(tid);
+          if (t >= c0 && t < n_round) {
+            const uint32_t p = key_index(s_sel[t]);
+#pragma unroll
+            for (int k = 0; k < NB; ++k) s_box[t * NB + k] = in_b[static_cast<size_t>(p) * NB + k];
+            s_cls[t] = in_c[p];
+          }
+          __syncthreads();
+        }
+      }
       if constexpr (NB == 4) {
         float jb[NB];
 #pragma unroll
@@ -926,7 +1009,7 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsArgs a) {
         // own rows are one word per candidate
         if (tid < kNmsChunk) {
           const uint32_t i = c0 + static_cast<uint32_t>(tid);
-          s_sup[tid] = i < m_cov ? a.sup[(static_cast<size_t>(img) * a.m_max + i) * (a.m_max / 64) + (c0 >> 6)] : 0ull;
+          s_sup[tid] = i < m_cov ? s_mat[i * (a.m_max / 64) + (c0 >> 6)] : 0ull;
         }
         __syncthreads();
       } else {
@@ -958,7 +1041,18 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsArgs a) {
         uint64_t kept_mask = 0;
         int k_cnt = kept_before;
         while (mask && k_cnt < ndet) {
-          const int l0 = __ffsll(static_cast<unsigned long long>(mask)) - 1;
+          // `hot`: alive candidates whose row hits something still alive.  The alive ones in front of the first of them are
+          // kept as they stand -- they suppress nothing -- in ONE trip (random-init rotated heads: 64 of 64 kept took 64
+          // trips of ~55 ns); a trip per hot candidate is what remains of the serial chain.
+          const uint64_t hot = __ballot((my_row & mask) != 0) & mask;
+          uint64_t run = hot ? mask & ((hot & (0ull - hot)) - 1ull) : mask;
+          const int room = ndet - k_cnt;
+          while (__popcll(run) > room) run &= ~(1ull << (63 - __clzll(static_cast<long long>(run))));   // (the list's last entries only)
+          kept_mask |= run;
+          k_cnt += __popcll(run);
+          mask &= ~run;
+          if (!hot || k_cnt >= ndet) break;
+          const int l0 = __ffsll(static_cast<unsigned long long>(hot)) - 1;
           const uint64_t row = (static_cast<uint64_t>(static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(row_hi), l0))) << 32) |
                                static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(row_lo), l0));
           kept_mask |= 1ull << l0;
@@ -990,11 +1084,11 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsArgs a) {
         if (c0 < m_cov) {
           // every box kept in this chunk ORs its row into the dead bits of the column blocks behind the chunk: thread
           // (candidate i, block w), one word each
-          const uint32_t nblk = a.m_max / 64, cov_blocks = (m_cov + 63) / 64;
+          const uint32_t cov_blocks = (m_cov + 63) / 64;
           const uint32_t i = static_cast<uint32_t>(tid) >> 4, w = static_cast<uint32_t>(tid) & 15u;
           const uint64_t kept_mask = static_cast<uint64_t>(s_misc[38]) | (static_cast<uint64_t>(s_misc[39]) << 32);
           if (((kept_mask >> i) & 1ull) && w > (c0 >> 6) && w < cov_blocks) {
-            const uint64_t word = a.sup[(static_cast<size_t>(img) * a.m_max + c0 + i) * nblk + w];
+            const uint64_t word = s_mat[(c0 + i) * (a.m_max / 64) + w];
             if (static_cast<uint32_t>(word)) atomicOr(&s_dead[2 * w], static_cast<uint32_t>(word));
             if (static_cast<uint32_t>(word >> 32)) atomicOr(&s_dead[2 * w + 1], static_cast<uint32_t>(word >> 32));
           }
@@ -1029,6 +1123,9 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsArgs a) {
       for (uint32_t f0 = 0; f0 < n_src; f0 += kNmsThreads) {   // block-uniform trip count
         const uint32_t f = f0 + tid;
         uint64_t key = 0;
+        float cb[NB];
+        float cc = 0.0f;
+        bool have_box = false;
         if (f < n_src) {
           if (runs) {
             uint32_t q = 0, base = 0, acc = 0;                   // flat index f -> (run q, offset f - base) over the runs' tails
@@ -1041,6 +1138,12 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsArgs a) {
               acc += n_t;
             }
             const uint32_t p = q * a.run_len + s_cursor[q] + (f - base);
+            if constexpr (NB == 4) {                           // box and class with the score: ONE global latency, not two
+#pragma unroll
+              for (int k = 0; k < NB; ++k) cb[k] = in_b[static_cast<size_t>(p) * NB + k];
+              cc = in_c[p];
+              have_box = true;
+            }
             key = make_key(in_s[p], p);
           } else {
             key = s_keys[f];
@@ -1048,9 +1151,7 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsArgs a) {
           }
         }
         bool alive = key != 0;
-        float cb[NB];
-        float cc = 0.0f;
-        if (alive) {
+        if (alive && !have_box) {
           const uint32_t p = key_index(key);
 #pragma unroll
           for (int k = 0; k < NB; ++k) cb[k] = in_b[static_cast<size_t>(p) * NB + k];

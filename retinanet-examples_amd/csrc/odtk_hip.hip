@@ -376,7 +376,7 @@ int nms_rotated_staged(odtk::NmsArgs na, int batch, size_t lds, hipStream_t stre
   auto matrix = [&](uint32_t m_launch, uint32_t m_done, const uint32_t *done) {
     sa.m_launch = m_launch; sa.m_done = m_done; sa.done = done;
     const unsigned nblk = m_launch / 64;
-    timed_launch(ODTK_KERNEL_NMS_MATRIX, odtk::rotated_sup_matrix_kernel, dim3(nblk * (nblk + 1) / 2 * 4, batch),
+    timed_launch(ODTK_KERNEL_NMS_MATRIX, odtk::rotated_sup_matrix_kernel, dim3(nblk * (nblk + 1) / 2 * (64 / odtk::kSupRows), batch),
                  dim3(odtk::kSupThreads), 0, stream, sa);
   };
   if (na.m_first >= na.m_max) {                              // the matrix is small: one step
@@ -409,11 +409,16 @@ uint32_t rotated_matrix_first(uint32_t m_max, int ndet) {
 
 // candidates of the first round the rotated suppression matrix covers: 8 x detections_per_im (the lazy pull of a typical
 // image examines 1.5 .. 7 x as many candidates as it keeps), whole 64-candidate chunks, at most one round
-uint32_t rotated_matrix_rows(size_t count, int ndet) {
+// ... and as many as the resolve kernel can hold in LDS: it keeps the matrix (m x m / 64 words) where the polygon clip's
+// columns will be once the first pair beyond the matrix is clipped (`ways` x 4 KiB: 704 candidates at 16 ways)
+uint32_t rotated_matrix_rows(size_t count, int ndet, int ways) {
   size_t m = static_cast<size_t>(ndet) * 8;
   if (m > count) m = count;
   if (m > static_cast<size_t>(odtk::kNmsRound)) m = odtk::kNmsRound;
-  return static_cast<uint32_t>((m + 63) / 64 * 64);
+  m = (m + 63) / 64 * 64;
+  const size_t room = static_cast<size_t>(ways) * odtk::kClipSlotsPerWave * sizeof(float2);
+  while (m > 64 && m * (m / 64) * sizeof(uint64_t) > room) m -= 64;
+  return static_cast<uint32_t>(m);
 }
 
 int nms_impl(int batch, const void *const *inputs, void *const *outputs, int n_outputs, size_t count,
@@ -431,7 +436,7 @@ int nms_impl(int batch, const void *const *inputs, void *const *outputs, int n_o
   const bool global_keys = count > ODTK_MAX_NMS_COUNT || local.total > odtk::NmsLds::kLdsBudget || (nb == 6 && local.ways < 8);
   const size_t keys_bytes = global_keys ? align_up(sizeof(uint64_t) * static_cast<size_t>(batch) * count) : kAlign;
   // rotated: [first-round boxes | classes | counts | suppression matrix] behind the keys
-  const uint32_t m_max = nb == 6 ? rotated_matrix_rows(count, ndet) : 0u;
+  const uint32_t m_max = nb == 6 ? rotated_matrix_rows(count, ndet, odtk::NmsLds(static_cast<uint32_t>(global_keys ? 1 : count), ndet, nb, global_keys).ways) : 0u;
   const size_t off_fb = keys_bytes;
   const size_t off_fc = off_fb + (nb == 6 ? align_up(sizeof(float) * 6 * batch * m_max) : 0);
   const size_t off_fn = off_fc + (nb == 6 ? align_up(sizeof(float) * batch * m_max) : 0);
