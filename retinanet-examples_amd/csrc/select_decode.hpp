@@ -412,36 +412,52 @@ __device__ __forceinline__ void sort_keys_desc(uint64_t *s_keys, uint32_t n_vali
 // place in the union of its run and the partner run is its place in its own run plus the number of partner keys above
 // it -- one binary search in LDS (keys are unique: no ties) -- instead of the 34 further compare-exchange stages of the
 // network, ten of them through LDS with a barrier each.  Measured: 7.7 us for the full network, see DESIGN.md.
-// s_buf must hold 2 * 1024 keys; returns where the sorted keys are (s_buf or s_buf + 1024).  Slots beyond n_valid are
-// padded with unique keys below every real one (a real key's score word is never 0).
+// s_buf must hold 2 * 1024 keys; returns where the sorted keys are (s_buf or s_buf + 1024): n_valid of them, what lies
+// behind is unspecified.  The work follows n_valid, not the capacity: slots beyond n_valid exist only inside the wave that
+// holds the last key (as values below every real key -- a real key's score word is never 0 -- for its network); waves
+// behind it skip the network, no padding is ever merged, and a search looks at the real keys of the partner run only --
+// the keys lie in [0, n_valid) before and after every level, so run r of length R holds clamp(n_valid - r R, 0, R) of
+// them, at its front.  (The sort is VALU-issue-bound -- 16 waves share 4 SIMDs -- so the 1300 survivors of a P3 segment
+// cost 1300 / 2048 of what the padded form did: 9.3 -> ~6.3 us.)
+__device__ __forceinline__ uint32_t keys_in_run(uint32_t n_valid, uint32_t run, uint32_t R) {
+  const uint32_t first = run * R;
+  return n_valid <= first ? 0u : (n_valid - first < R ? n_valid - first : R);
+}
+
 __device__ __forceinline__ const uint64_t *merge_sort_1024(uint64_t *s_buf, uint32_t n_valid) {
   const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1);
-  uint64_t v = tid < n_valid ? s_buf[tid] : static_cast<uint64_t>(kSelThreads - tid);
+  const bool real = tid < n_valid;
+  uint64_t v = real ? s_buf[tid] : static_cast<uint64_t>(kSelThreads - tid);
+  if ((tid & ~static_cast<uint32_t>(kWave - 1)) < n_valid) {   // (wave-uniform)
 #pragma unroll
-  for (uint32_t k = 2; k <= static_cast<uint32_t>(kWave); k <<= 1) {
+    for (uint32_t k = 2; k <= static_cast<uint32_t>(kWave); k <<= 1) {
 #pragma unroll
-    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-      const uint64_t p = shfl_xor_u64(v, static_cast<int>(j));
-      const bool take_max = ((lane & j) == 0) == ((lane & k) == 0);   // lower element of a descending pair
-      v = take_max ? (v > p ? v : p) : (v < p ? v : p);
+      for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+        const uint64_t p = shfl_xor_u64(v, static_cast<int>(j));
+        const bool take_max = ((lane & j) == 0) == ((lane & k) == 0);   // lower element of a descending pair
+        v = take_max ? (v > p ? v : p) : (v < p ? v : p);
+      }
     }
   }
   __syncthreads();                                         // every thread has read its key
   uint64_t *src = s_buf, *dst = s_buf + kSelThreads;
-  src[tid] = v;
+  if (real) src[tid] = v;                                  // (after its wave's network slot `tid` holds a real key iff tid < n_valid)
   __syncthreads();
   uint32_t g = tid;                                        // where this thread's key sits
 #pragma unroll
   for (uint32_t R = kWave; R < static_cast<uint32_t>(kSelThreads); R <<= 1) {
-    const uint32_t run = g / R, p = g - run * R;
-    const uint64_t *other = src + (run ^ 1u) * R;          // the partner run, descending
-    uint32_t above = 0;                                    // partner keys above mine
+    if (real) {
+      const uint32_t run = g / R, p = g - run * R;
+      const uint64_t *other = src + (run ^ 1u) * R;        // the partner run, descending
+      const uint32_t c = keys_in_run(n_valid, run ^ 1u, R);
+      uint32_t above = 0;                                  // partner keys above mine
 #pragma unroll
-    for (uint32_t step = R >> 1; step > 0; step >>= 1)
-      if (other[above + step - 1] > v) above += step;
-    above += other[above] > v ? 1u : 0u;
-    g = (run >> 1) * 2 * R + p + above;
-    dst[g] = v;
+      for (uint32_t step = R >> 1; step > 0; step >>= 1)
+        if (above + step <= c && other[above + step - 1] > v) above += step;
+      above += (above < c && other[above] > v) ? 1u : 0u;
+      g = (run >> 1) * 2 * R + p + above;
+      dst[g] = v;
+    }
     __syncthreads();
     uint64_t *t = src; src = dst; dst = t;
   }
@@ -453,44 +469,51 @@ __device__ __forceinline__ const uint64_t *merge_sort_1024(uint64_t *s_buf, uint
 __device__ __forceinline__ const uint64_t *merge_sort_2048(uint64_t *s_buf, uint32_t n_valid) {
   const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1);
   uint64_t v[2];
+  bool real[2];
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     const uint32_t i = tid + h * kSelThreads;
-    v[h] = i < n_valid ? s_buf[i] : static_cast<uint64_t>(2 * kSelThreads - i);
+    real[h] = i < n_valid;
+    v[h] = real[h] ? s_buf[i] : static_cast<uint64_t>(2 * kSelThreads - i);
   }
 #pragma unroll
-  for (uint32_t k = 2; k <= static_cast<uint32_t>(kWave); k <<= 1) {
+  for (int h = 0; h < 2; ++h) {
+    if ((tid & ~static_cast<uint32_t>(kWave - 1)) + h * kSelThreads < n_valid) {   // (wave-uniform)
 #pragma unroll
-    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-      const bool take_max = ((lane & j) == 0) == ((lane & k) == 0);
+      for (uint32_t k = 2; k <= static_cast<uint32_t>(kWave); k <<= 1) {
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const uint64_t p = shfl_xor_u64(v[h], static_cast<int>(j));
-        v[h] = take_max ? (v[h] > p ? v[h] : p) : (v[h] < p ? v[h] : p);
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+          const bool take_max = ((lane & j) == 0) == ((lane & k) == 0);
+          const uint64_t p = shfl_xor_u64(v[h], static_cast<int>(j));
+          v[h] = take_max ? (v[h] > p ? v[h] : p) : (v[h] < p ? v[h] : p);
+        }
       }
     }
   }
   __syncthreads();                                         // every thread has read its keys
   uint64_t *src = s_buf, *dst = s_buf + 2 * kSelThreads;
   uint32_t g[2] = {tid, tid + static_cast<uint32_t>(kSelThreads)};
-  src[g[0]] = v[0];
-  src[g[1]] = v[1];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+    if (real[h]) src[g[h]] = v[h];
   __syncthreads();
 #pragma unroll
   for (uint32_t R = kWave; R < 2u * kSelThreads; R <<= 1) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      const uint32_t run = g[h] / R, p = g[h] - run * R;
-      const uint64_t *other = src + (run ^ 1u) * R;
-      uint32_t above = 0;
+      if (real[h]) {
+        const uint32_t run = g[h] / R, p = g[h] - run * R;
+        const uint64_t *other = src + (run ^ 1u) * R;
+        const uint32_t c = keys_in_run(n_valid, run ^ 1u, R);
+        uint32_t above = 0;
 #pragma unroll
-      for (uint32_t step = R >> 1; step > 0; step >>= 1)
-        if (other[above + step - 1] > v[h]) above += step;
-      above += other[above] > v[h] ? 1u : 0u;
-      g[h] = (run >> 1) * 2 * R + p + above;
+        for (uint32_t step = R >> 1; step > 0; step >>= 1)
+          if (above + step <= c && other[above + step - 1] > v[h]) above += step;
+        above += (above < c && other[above] > v[h]) ? 1u : 0u;
+        g[h] = (run >> 1) * 2 * R + p + above;
+        dst[g[h]] = v[h];
+      }
     }
-    dst[g[0]] = v[0];
-    dst[g[1]] = v[1];
     __syncthreads();
     uint64_t *t = src; src = dst; dst = t;
   }
