@@ -195,4 +195,10 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("detect", &detect, py::arg("cls_heads"), py::arg("box_heads"), py::arg("anchors"), py::arg("strides"), py::arg("score_thresh"),
         py::arg("top_n"), py::arg("nms_thresh"), py::arg("detections_per_im"), py::arg("rotated") = false, py::arg("logits") = false);
   m.def("version", [] { return std::string(odtk_version()); });
+  // sizes of the ABI structs THIS module was compiled against: a module older than include/odtk_hip.h passes arrays of the
+  // wrong stride (tests/test_compiled_binding.py compares them with the ctypes mirror on every CPU run)
+  m.def("abi_sizes", [] {
+    return py::dict(py::arg("level") = sizeof(odtk_level_t), py::arg("snap_level") = sizeof(odtk_snap_level_t),
+                    py::arg("snap_rot_level") = sizeof(odtk_snap_rot_level_t));
+  });
 }

@@ -49,6 +49,16 @@ def _bits(t, ref, what):
     assert a.shape == b.shape and np.array_equal(a, b), what
 
 
+def test_module_is_compiled_against_the_current_header():
+    """A stale _C_ext (built before include/odtk_hip.h grew a field) hands the library arrays of the wrong stride: its struct
+    sizes must be the ctypes mirror's, which tests/test_abi_host.py ties to the header."""
+    import ctypes
+    sizes = _C_ext.abi_sizes()
+    assert sizes['level'] == ctypes.sizeof(_C.Level)
+    assert sizes['snap_level'] == ctypes.sizeof(_C.SnapLevel)
+    assert sizes['snap_rot_level'] == ctypes.sizeof(_C.SnapRotLevel)
+
+
 def test_module_surface_and_errors_on_cpu():
     assert _C_ext.version().startswith('odtk-hip')
     for name in ('decode', 'nms', 'iou', 'detect', 'Engine'):
