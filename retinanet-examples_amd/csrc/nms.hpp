@@ -632,6 +632,7 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsArgs a) {
     const int kept_at_round_start = kept;
     // ---- round: the next (up to) 1024 best candidates, in order, into s_sel ----
     uint32_t n_round = left < kNmsRound ? left : kNmsRound;
+    bool staged = false;               // the round's boxes / classes are in s_box / s_cls already (block-uniform)
     if (kStage == 2 && first_round) {
       // stage 1 selected and ordered this round already (its keys, boxes and matrix are in LDS since the kernel's first
       // instructions): its size and the state of the selection after it
@@ -742,9 +743,22 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsArgs a) {
 #pragma unroll
         for (uint32_t t = 0; t < 8; ++t) my_b = t == q ? w_b[t] : my_b;
         const uint64_t key = s_keys[my_b + (static_cast<uint32_t>(tid) - base)];
+        // its box and class are requested before the rank is known (cursors are zero: the key sits at its offset in run q),
+        // so the gather overlaps the searches instead of following them
+        const uint32_t pos = q * a.run_len + (static_cast<uint32_t>(tid) - base);
+        float pb[NB];
+#pragma unroll
+        for (int k = 0; k < NB; ++k) pb[k] = in_b[static_cast<size_t>(pos) * NB + k];
+        const float pc = in_c[pos];
         const uint32_t rank = rank_of(key, u_n, p2);
-        if (rank < want) s_sel[rank] = key;
+        if (rank < want) {
+          s_sel[rank] = key;
+#pragma unroll
+          for (int k = 0; k < NB; ++k) s_box[rank * NB + k] = pb[k];
+          s_cls[rank] = pc;
+        }
       }
+      staged = true;
       __syncthreads();
       if (static_cast<uint32_t>(tid) < n_runs) {               // how far every run was consumed: its keys >= the round's last key
         uint32_t n_w = 0, b_w = 0;
@@ -771,12 +785,20 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsArgs a) {
       if (tid < 8) s_probe[tid] = 0;
       __syncthreads();
       uint64_t key = 0;
-      if (l < n_runs) {
+      float pb[NB], pc = 0.0f;                               // (axis-aligned) the slot's box and class, requested WITH its score:
+#pragma unroll
+      for (int k = 0; k < NB; ++k) pb[k] = 0.0f;             // the position is known before the rank is -- one global latency per
+      if (l < n_runs) {                                      // round instead of two (score, then a gather behind the ordered keys)
         const uint32_t avail = s_valid[l] - s_cursor[l];
         const uint32_t n_l = avail < step ? avail : step;
         if (j < n_l) {
           const uint32_t p = l * a.run_len + s_cursor[l] + j;
           key = make_key(in_s[p], p);
+          if constexpr (NB == 4) {
+#pragma unroll
+            for (int k = 0; k < NB; ++k) pb[k] = in_b[static_cast<size_t>(p) * NB + k];
+            pc = in_c[p];
+          }
           if (j == n_l - 1) s_probe[l] = key;
         }
       }
@@ -811,7 +833,13 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsArgs a) {
 #pragma unroll
         for (uint32_t q = 0; q < 8; ++q) rank += lo[q];
         s_sel[rank] = key;
+        if constexpr (NB == 4) {
+#pragma unroll
+          for (int k = 0; k < NB; ++k) s_box[rank * NB + k] = pb[k];
+          s_cls[rank] = pc;
+        }
       }
+      staged = NB == 4;
       if (static_cast<uint32_t>(tid) < n_runs) {
         const uint32_t avail = s_valid[tid] - s_cursor[tid];
         s_members[tid] = count_above<false>(s_win + static_cast<uint32_t>(tid) * step, avail < step ? avail : step, T, p2);
@@ -852,7 +880,7 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsArgs a) {
     phase(1);
 
     // thread t <-> rank `t` of this round: stage its box + class in LDS
-    if (static_cast<uint32_t>(tid) < n_round && !(kStage == 2 && first_round)) {
+    if (static_cast<uint32_t>(tid) < n_round && !(kStage == 2 && first_round) && !staged) {
       const uint32_t p = key_index(s_sel[tid]);
 #pragma unroll
       for (int k = 0; k < NB; ++k) s_box[tid * NB + k] = in_b[static_cast<size_t>(p) * NB + k];
