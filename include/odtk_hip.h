@@ -395,6 +395,16 @@ int odtk_debug_set_trace(void *device_buffer);
  * best; results do not depend on the shape beyond the order of the partial sums.  Process-wide, not
  * thread-safe against concurrent loss launches; a workspace size queried before a change is stale after it. */
 int odtk_debug_loss_tuning(int which, int fp32_heads, int threads, int blocks_per_cu, int unroll, int box_blocks);
+/* Debug / A-B: arithmetic form of the classification walk of the loss kernels when gamma == 2 (csrc/loss.hpp).
+ * 0: every logit through the symmetric form (one select on the target, one on the sign);  1: 16-byte vectors that hold no
+ * positive element and no logit above 64 (all but ~1 in 1000) through the negatives-only form u = exp(x), q = u / (1 + u),
+ * ce = ln(1 + u) -- the same three hardware transcendentals, about a third fewer full-rate operations; every other vector
+ * and every other gamma as with 0.  Results agree to ~1e-8 (sums) / ~1e-6 of the largest gradient.  The default is
+ * ODTK_LOSS_FORM_DEFAULT; process-wide, read once per launch.  2, 3, 4: TIMING ABLATIONS of form 1 for the fp32 forward
+ * (no depth gather / no arithmetic / no index arithmetic and no depth gather; other launches as form 1) -- their sums are
+ * wrong on purpose, tools/loss_form_probe.py is their only user.  Returns ODTK_ERR_INVALID for any other value. */
+#define ODTK_LOSS_FORM_DEFAULT 1
+int odtk_debug_loss_form(int form);
 int odtk_profile_collect(double total_ms[ODTK_KERNEL_COUNT], int launches[ODTK_KERNEL_COUNT]);
 
 #ifdef __cplusplus

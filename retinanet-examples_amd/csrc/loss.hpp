@@ -96,6 +96,29 @@ __device__ __forceinline__ float focal_term(float x, bool positive, float w_neg,
   }
 }
 
+// Round 4 (late): the form for a vector of NEGATIVES.  All but about one 16-byte vector in a thousand hold no element that is
+// its anchor's class (foreground anchors are ~0.5 % of the cells and one class of C each) and no logit beyond kPlainMax; for
+// those neither the target select nor the split on the sign of s is needed.  With u = exp(x):
+//     q = sigmoid(x) = u / (1 + u),   1 - q = 1 / (1 + u)  (no cancellation),   ce = softplus(x) = ln(1 + u)
+//     loss = (1 - alpha) q^2 ce,      d loss / dx = (1 - alpha) q^2 (2 (1 - q) ce + q)          (focal_term with t = 0, gamma = 2)
+// -- the same three hardware transcendentals, 6 (forward) / 9 (backward) full-rate operations instead of ~15 / ~19; the
+// weight (1 - alpha) (x ln 2 forward, x the upstream gradient backward) is applied by the caller.  u stays finite for
+// x <= kPlainMax (exp(64) = 6e27) and underflows to 0 for x < -87, where q = 0 and the term is 0 as in focal_term.
+// Vectors with a positive element or a logit beyond kPlainMax (+inf included) take focal_term element by element as before.
+// A NaN logit is ignored by the maximum and yields NaN in either form; -inf gives u = 0: term and gradient 0, as focal_term.
+constexpr float kPlainMax = 64.0f;
+
+template <bool kBackward>
+__device__ __forceinline__ float focal_plain(float x) {
+  const float u = __builtin_amdgcn_exp2f(x * 1.4426950408889634f);
+  const float d = 1.0f + u;
+  const float r = __builtin_amdgcn_rcpf(d);                                      // 1 - sigmoid(x)
+  const float q = u * r;                                                         // sigmoid(x)
+  const float l2 = __builtin_amdgcn_logf(d);                                     // softplus(x) / ln 2
+  if constexpr (!kBackward) return q * q * l2;                                   // x (1 - alpha) ln 2
+  else return q * q * fmaf(r * l2, 1.3862943611198906f, q);                      // x (1 - alpha) g      (2 ln 2)
+}
+
 // loss.py:27-31
 template <bool kGrad>
 __device__ __forceinline__ float smooth_l1_element(float pred, float target, float beta, float *grad) {
@@ -169,8 +192,14 @@ __device__ __forceinline__ double block_sum(double v, double *s_red) {
 //   kCL (channels_last), vector inside one anchor's class run (C % kPer == 0: always): ONE depth value per vector
 //   NCHW, vector inside one (image, anchor, class) plane row (hw % kPer == 0: P3..P6): kPer consecutive depth values
 //   otherwise (tiny levels, class counts that are no multiple of the vector): element by element with carries
-template <typename T, bool kBackward, bool kGamma2, bool kCL, int kUnroll>
+//   kForm (gamma = 2 only; the launch-time switch is odtk_debug_loss_form): 0 = every element through focal_term, 1 = fast
+//   vectors of negatives take focal_plain (above).  2..4 are TIMING ABLATIONS of form 1 whose results are wrong on purpose
+//   (tools/loss_form_probe.py; fp32 forward only): 2 = no depth gather (every cell counts as background), 3 = no arithmetic
+//   (the logits are added up as they are), 4 = no index arithmetic and no depth gather.
+template <typename T, bool kBackward, bool kGamma2, bool kCL, int kUnroll, int kForm>
 __device__ __forceinline__ double focal_stream(const LossArgs &a, uint32_t block) {
+  static_assert(kForm == 0 || kGamma2, "focal_plain is the gamma = 2 form");
+  constexpr bool kPlain = kForm >= 1, kNoDepth = kForm == 2 || kForm == 4, kNoIndex = kForm == 4, kNoMath = kForm == 3;
   constexpr int kPer = T::kPerLoad;
   constexpr int kDep = kCL ? 1 : kPer;                     // depth words per fast vector
   const uint32_t A = a.num_anchors, C = a.num_classes, hw = a.hw;
@@ -200,14 +229,21 @@ __device__ __forceinline__ double focal_stream(const LossArgs &a, uint32_t block
       if (v < n_vec) {
         raw[u] = __builtin_nontemporal_load(src + v);
         const uint32_t r0 = v * kPer;
-        if constexpr (kCL) {
+        if constexpr (kNoIndex) {
+          fast[u] = true;
+          dep[u][0] = 0.0f;
+          if constexpr (!kCL) {
+#pragma unroll
+            for (int e = 0; e < kDep; ++e) dep[u][e] = 0.0f;
+          }
+        } else if constexpr (kCL) {
           uint32_t ch, pix, c;
           const uint32_t p = fastdivmod(r0, a.by_channels, &ch);
           const uint32_t img = fastdivmod(p, a.by_hw, &pix);
           const uint32_t an = fastdivmod(ch, a.by_classes, &c);
           c0[u] = c;
           fast[u] = c + kPer <= C;
-          if (fast[u]) dep[u][0] = a.depth[(img * A + an) * hw + pix];
+          if (fast[u]) dep[u][0] = kNoDepth ? ((img * A + an) * hw + pix == 0xffffffffu ? -1.0f : 0.0f) : a.depth[(img * A + an) * hw + pix];
         } else {
           uint32_t pix, c;
           const uint32_t q = fastdivmod(r0, a.by_hw, &pix);           // (img * A + an) * C + c
@@ -216,7 +252,7 @@ __device__ __forceinline__ double focal_stream(const LossArgs &a, uint32_t block
           fast[u] = pix + kPer <= hw;
           if (fast[u]) {
 #pragma unroll
-            for (int e = 0; e < kDep; ++e) dep[u][e] = a.depth[ia * hw + pix + e];
+            for (int e = 0; e < kDep; ++e) dep[u][e] = kNoDepth ? (ia * hw + pix + e == 0xffffffffu ? -1.0f : 0.0f) : a.depth[ia * hw + pix + e];
           }
         }
       } else {
@@ -234,16 +270,44 @@ __device__ __forceinline__ double focal_stream(const LossArgs &a, uint32_t block
         // depth is integral by contract (-1 / 0 / class + 1): "depth > 0 and class == depth - 1" is ONE compare
         const float tgt0 = static_cast<float>(c0[u] + 1);
         float vs = 0.0f;
+        bool plain = false;
+        if constexpr (kPlain) {
+          float mx = vec_elem<T>(raw[u], 0);
 #pragma unroll
-        for (int e = 0; e < kPer; ++e) {
-          const float d = dep[u][kCL ? 0 : e];
-          const bool positive = d == (kCL ? tgt0 + static_cast<float>(e) : tgt0);
-          const float t = focal_term<kBackward, kGamma2>(vec_elem<T>(raw[u], e), positive, w_neg, w_pos, gamma);
-          if constexpr (kBackward) out[e] = d >= 0.0f ? t : 0.0f;                // model.py:199 cls_mask
-          else if constexpr (kCL) vs += t;
-          else vs += d >= 0.0f ? t : 0.0f;
+          for (int e = 1; e < kPer; ++e) mx = fmaxf(mx, vec_elem<T>(raw[u], e));
+          if constexpr (kCL) {
+            const float rel = dep[u][0] - tgt0;                                  // which element is the anchor's class, if any
+            plain = !(rel >= 0.0f && rel < static_cast<float>(kPer));
+          } else {
+            plain = true;
+#pragma unroll
+            for (int e = 0; e < kPer; ++e) plain = plain && dep[u][e] != tgt0;
+          }
+          plain = plain && mx <= kPlainMax;
         }
-        if constexpr (!kBackward) sum += kCL ? (dep[u][0] >= 0.0f ? vs : 0.0f) : vs;
+        if (plain) {
+          // a vector of negatives (or ignored cells): one weight for the whole vector
+          const float wv = kBackward ? w_neg : w_neg * 0.6931471805599453f;
+#pragma unroll
+          for (int e = 0; e < kPer; ++e) {
+            const float t = kNoMath ? vec_elem<T>(raw[u], e) : focal_plain<kBackward>(vec_elem<T>(raw[u], e));
+            if constexpr (kBackward) out[e] = dep[u][kCL ? 0 : e] >= 0.0f ? wv * t : 0.0f;
+            else if constexpr (kCL) vs += t;
+            else vs += dep[u][e] >= 0.0f ? t : 0.0f;
+          }
+          if constexpr (!kBackward) sum += kCL ? (dep[u][0] >= 0.0f ? wv * vs : 0.0f) : wv * vs;
+        } else {
+#pragma unroll
+          for (int e = 0; e < kPer; ++e) {
+            const float d = dep[u][kCL ? 0 : e];
+            const bool positive = d == (kCL ? tgt0 + static_cast<float>(e) : tgt0);
+            const float t = focal_term<kBackward, kGamma2>(vec_elem<T>(raw[u], e), positive, w_neg, w_pos, gamma);
+            if constexpr (kBackward) out[e] = d >= 0.0f ? t : 0.0f;              // model.py:199 cls_mask
+            else if constexpr (kCL) vs += t;
+            else vs += d >= 0.0f ? t : 0.0f;
+          }
+          if constexpr (!kBackward) sum += kCL ? (dep[u][0] >= 0.0f ? vs : 0.0f) : vs;
+        }
       } else {
         // decompose the first element again; the others follow by increment with carry
         const uint32_t r0 = v * kPer;
@@ -298,17 +362,17 @@ __device__ __forceinline__ double focal_stream(const LossArgs &a, uint32_t block
 
 // One workgroup's share of one level: workgroup `block` of the `n_blocks` that level's slice of the launch consists of.
 // kBackward = false: accumulate the three sums.  kBackward = true: write the gradients.
-template <typename T, bool kBackward, int kUnroll>
+template <typename T, bool kBackward, int kUnroll, int kForm>
 __device__ __forceinline__ void retina_loss_block(const LossArgs &a, uint32_t block, uint32_t n_blocks, double *s_red) {
   const uint32_t A = a.num_anchors, hw = a.hw, NB = a.nb;
   double acc_cls = 0.0, acc_box = 0.0, acc_fg = 0.0;
 
   if (block < a.cls_blocks) {
     const bool g2 = a.gamma == 2.0f;                        // launch-uniform
-    if (a.channels_last) acc_cls = g2 ? focal_stream<T, kBackward, true, true, kUnroll>(a, block)
-                                      : focal_stream<T, kBackward, false, true, kUnroll>(a, block);
-    else acc_cls = g2 ? focal_stream<T, kBackward, true, false, kUnroll>(a, block)
-                      : focal_stream<T, kBackward, false, false, kUnroll>(a, block);
+    if (a.channels_last) acc_cls = g2 ? focal_stream<T, kBackward, true, true, kUnroll, kForm>(a, block)
+                                      : focal_stream<T, kBackward, false, true, kUnroll, 0>(a, block);
+    else acc_cls = g2 ? focal_stream<T, kBackward, true, false, kUnroll, kForm>(a, block)
+                      : focal_stream<T, kBackward, false, false, kUnroll, 0>(a, block);
   } else {
     // ---- the box deltas: one lane per (image, anchor, pixel), NB parameters each; only foreground anchors count ----
     const float g = kBackward ? (a.g_box ? *a.g_box : 0.0f) : 0.0f;
@@ -363,14 +427,14 @@ struct LossLevelsArgs {
   int n_levels;
 };
 
-template <typename T, bool kBackward, int kUnroll>
+template <typename T, bool kBackward, int kUnroll, int kForm>
 __global__ __launch_bounds__(kLossMaxThreads) void retina_loss_kernel(const LossLevelsArgs a) {
   __shared__ double s_red[kLossMaxThreads / kWave];
   int l = 0;
 #pragma unroll
   for (int i = 1; i < ODTK_MAX_LEVELS; ++i)
     if (i < a.n_levels && blockIdx.x >= a.block_begin[i]) l = i;
-  retina_loss_block<T, kBackward, kUnroll>(a.lv[l], blockIdx.x - a.block_begin[l], a.block_begin[l + 1] - a.block_begin[l], s_red);
+  retina_loss_block<T, kBackward, kUnroll, kForm>(a.lv[l], blockIdx.x - a.block_begin[l], a.block_begin[l + 1] - a.block_begin[l], s_red);
 }
 
 // Second launch of the workspace form of the forward: workgroup l adds up the per-workgroup sums of level l in a fixed

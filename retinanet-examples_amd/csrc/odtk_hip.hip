@@ -531,17 +531,25 @@ int bias_act_dispatch(void *y, const float *bias, const void *res, uint64_t n, u
 // workgroup size, resident workgroups per CU the logit walk is capped at, 16-byte vectors a lane loads per trip.
 struct LossTuning {
   int threads, per_cu, unroll, box_blocks;
+  int form;   // filled by loss_tuning_snapshot from g_loss_form (odtk_debug_loss_form): 1 = vectors of negatives take focal_plain
 };
 // [16-bit heads, fp32 heads][forward with atomics, backward, forward through a workspace] = threads, logit workgroups per
 // CU and level, vectors per trip, box workgroups per level; measured with tools/loss_probe.py (profiles/r03_loss_probe.txt)
 enum { kLossFwd = 0, kLossBwd = 1, kLossFwdWs = 2 };
 std::mutex g_loss_tuning_mu;
-LossTuning g_loss_tuning[2][3] = {{{512, 1, 2, 64}, {256, 4, 1, 256}, {256, 4, 1, 256}},
-                                  {{512, 1, 4, 64}, {1024, 16, 2, 1024}, {256, 4, 1, 256}}};
+LossTuning g_loss_tuning[2][3] = {{{512, 1, 2, 64, 0}, {256, 4, 1, 256, 0}, {256, 4, 1, 256, 0}},
+                                  {{512, 1, 4, 64, 0}, {1024, 16, 2, 1024, 0}, {256, 4, 1, 256, 0}}};
+
+// Arithmetic form of the classification walk with gamma = 2 (csrc/loss.hpp focal_plain): 0 = every element through the
+// symmetric focal_term (rounds 3-4), 1 = vectors that hold no positive element and no logit beyond kPlainMax through
+// focal_plain.  Same sums to ~1e-8, same gradients to ~1e-6 of the largest (both well inside the tested bars).
+int g_loss_form = ODTK_LOSS_FORM_DEFAULT;
 
 LossTuning loss_tuning_snapshot(int dtype, int which) {
   std::lock_guard<std::mutex> lock(g_loss_tuning_mu);
-  return g_loss_tuning[dtype == ODTK_F32][which];
+  LossTuning t = g_loss_tuning[dtype == ODTK_F32][which];
+  t.form = g_loss_form;
+  return t;
 }
 
 // fills the kernel arguments of one level; returns the number of workgroups it wants (0 on error, *rc set)
@@ -591,10 +599,24 @@ unsigned retina_loss_fill(odtk::LossArgs &la, int which, const void *cls, const 
 template <typename T, bool kBackward>
 void retina_loss_dispatch(const odtk::LossLevelsArgs &la, unsigned total, const LossTuning &t, hipStream_t stream) {
   const dim3 grid(total), block(t.threads);
+  if constexpr (std::is_same_v<T, odtk::F32> && !kBackward) {
+    // timing ablations of form 1 (wrong results on purpose; tools/loss_form_probe.py): fp32 forward, four vectors per trip
+    if (t.form == 2) { timed_launch(ODTK_KERNEL_LOSS, odtk::retina_loss_kernel<T, false, 4, 2>, grid, block, 0, stream, la); return; }
+    if (t.form == 3) { timed_launch(ODTK_KERNEL_LOSS, odtk::retina_loss_kernel<T, false, 4, 3>, grid, block, 0, stream, la); return; }
+    if (t.form == 4) { timed_launch(ODTK_KERNEL_LOSS, odtk::retina_loss_kernel<T, false, 4, 4>, grid, block, 0, stream, la); return; }
+  }
+  if (t.form) {
+    switch (t.unroll) {
+      case 1: timed_launch(ODTK_KERNEL_LOSS, odtk::retina_loss_kernel<T, kBackward, 1, 1>, grid, block, 0, stream, la); break;
+      case 2: timed_launch(ODTK_KERNEL_LOSS, odtk::retina_loss_kernel<T, kBackward, 2, 1>, grid, block, 0, stream, la); break;
+      default: timed_launch(ODTK_KERNEL_LOSS, odtk::retina_loss_kernel<T, kBackward, 4, 1>, grid, block, 0, stream, la); break;
+    }
+    return;
+  }
   switch (t.unroll) {
-    case 1: timed_launch(ODTK_KERNEL_LOSS, odtk::retina_loss_kernel<T, kBackward, 1>, grid, block, 0, stream, la); break;
-    case 2: timed_launch(ODTK_KERNEL_LOSS, odtk::retina_loss_kernel<T, kBackward, 2>, grid, block, 0, stream, la); break;
-    default: timed_launch(ODTK_KERNEL_LOSS, odtk::retina_loss_kernel<T, kBackward, 4>, grid, block, 0, stream, la); break;
+    case 1: timed_launch(ODTK_KERNEL_LOSS, odtk::retina_loss_kernel<T, kBackward, 1, 0>, grid, block, 0, stream, la); break;
+    case 2: timed_launch(ODTK_KERNEL_LOSS, odtk::retina_loss_kernel<T, kBackward, 2, 0>, grid, block, 0, stream, la); break;
+    default: timed_launch(ODTK_KERNEL_LOSS, odtk::retina_loss_kernel<T, kBackward, 4, 0>, grid, block, 0, stream, la); break;
   }
 }
 
@@ -697,7 +719,14 @@ int odtk_debug_loss_tuning(int which, int fp32_heads, int threads, int blocks_pe
       blocks_per_cu > 64 || (unroll != 1 && unroll != 2 && unroll != 4) || box_blocks < 1 || box_blocks > 16384)
     return ODTK_ERR_INVALID;
   std::lock_guard<std::mutex> lock(g_loss_tuning_mu);
-  g_loss_tuning[fp32_heads != 0][which] = LossTuning{threads, blocks_per_cu, unroll, box_blocks};
+  g_loss_tuning[fp32_heads != 0][which] = LossTuning{threads, blocks_per_cu, unroll, box_blocks, 0};
+  return ODTK_OK;
+}
+
+int odtk_debug_loss_form(int form) {
+  if (form < 0 || form > 4) return ODTK_ERR_INVALID;
+  std::lock_guard<std::mutex> lock(g_loss_tuning_mu);
+  g_loss_form = form;
   return ODTK_OK;
 }
 

@@ -100,6 +100,7 @@ _SIGNATURES = {
     'odtk_profile_enable': (ctypes.c_int, [ctypes.c_int]),
     'odtk_debug_set_trace': (ctypes.c_int, [_vp]),
     'odtk_debug_loss_tuning': (ctypes.c_int, [ctypes.c_int] * 6),
+    'odtk_debug_loss_form': (ctypes.c_int, [ctypes.c_int]),
     'odtk_bias_act_maxpool': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
                                              ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     'odtk_snap_to_anchors_rotated_levels': (ctypes.c_int, [ctypes.c_int, _vp, _vp, _vp, ctypes.c_int, ctypes.c_int,
@@ -153,6 +154,9 @@ def library():
             side = side.strip()
             _check(lib.odtk_debug_loss_tuning({'fwd': 0, 'bwd': 1, 'ws': 2}[side[:-2]], int(side.endswith('32')),
                                               *(int(v) for v in vals.split(','))), 'ODTK_LOSS_TUNING')
+        # ODTK_LOSS_FORM=0|1: arithmetic form of the gamma = 2 classification walk (include/odtk_hip.h: odtk_debug_loss_form)
+        if os.environ.get('ODTK_LOSS_FORM', '') != '':
+            _check(lib.odtk_debug_loss_form(int(os.environ['ODTK_LOSS_FORM'])), 'ODTK_LOSS_FORM')
     return _lib
 
 
@@ -773,6 +777,15 @@ def loss_tuning(which, fp32_heads, threads, blocks_per_cu, unroll, box_blocks):
     workspace) and head width (include/odtk_hip.h: odtk_debug_loss_tuning)."""
     _check(library().odtk_debug_loss_tuning(int(which), int(bool(fp32_heads)), int(threads), int(blocks_per_cu),
                                             int(unroll), int(box_blocks)), 'loss_tuning')
+
+
+LOSS_FORM_DEFAULT = 1      # = ODTK_LOSS_FORM_DEFAULT of include/odtk_hip.h (tests/test_abi_host.py compares the two)
+
+
+def loss_form(form):
+    """Debug / A-B: 0 = the symmetric element form everywhere, 1 (default) = vectors of negatives through the negatives-only
+    form; 2..4 = timing ablations with wrong sums (include/odtk_hip.h: odtk_debug_loss_form)."""
+    _check(library().odtk_debug_loss_form(int(form)), 'loss_form')
 
 
 def profile_enable(on=True, kernels=None):
