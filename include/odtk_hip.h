@@ -400,9 +400,10 @@ int odtk_debug_loss_tuning(int which, int fp32_heads, int threads, int blocks_pe
  * positive element and no logit above 64 (all but ~1 in 1000) through the negatives-only form u = exp(x), q = u / (1 + u),
  * ce = ln(1 + u) -- the same three hardware transcendentals, about a third fewer full-rate operations; every other vector
  * and every other gamma as with 0.  Results agree to ~1e-8 (sums) / ~1e-6 of the largest gradient.  The default is
- * ODTK_LOSS_FORM_DEFAULT; process-wide, read once per launch.  2, 3, 4: TIMING ABLATIONS of form 1 for the fp32 forward
- * (no depth gather / no arithmetic / no index arithmetic and no depth gather; other launches as form 1) -- their sums are
- * wrong on purpose, tools/loss_form_probe.py is their only user.  Returns ODTK_ERR_INVALID for any other value. */
+ * ODTK_LOSS_FORM_DEFAULT; process-wide, read once per launch.  2, 3, 4, 6, 7: TIMING ABLATIONS of form 1 for the fp32
+ * forward (no depth gather / no arithmetic / no index arithmetic and no depth gather / no box-delta walk / no logit walk;
+ * other launches as form 1) -- their sums are wrong on purpose, tools/loss_form_probe.py is their only user.  Returns
+ * ODTK_ERR_INVALID for any other value. */
 #define ODTK_LOSS_FORM_DEFAULT 1
 int odtk_debug_loss_form(int form);
 int odtk_profile_collect(double total_ms[ODTK_KERNEL_COUNT], int launches[ODTK_KERNEL_COUNT]);

@@ -195,7 +195,8 @@ __device__ __forceinline__ double block_sum(double v, double *s_red) {
 //   kForm (gamma = 2 only; the launch-time switch is odtk_debug_loss_form): 0 = every element through focal_term, 1 = fast
 //   vectors of negatives take focal_plain (above).  2..4 are TIMING ABLATIONS of form 1 whose results are wrong on purpose
 //   (tools/loss_form_probe.py; fp32 forward only): 2 = no depth gather (every cell counts as background), 3 = no arithmetic
-//   (the logits are added up as they are), 4 = no index arithmetic and no depth gather.
+//   (the logits are added up as they are), 4 = no index arithmetic and no depth gather, 6 = the box-delta workgroups return at
+//   once, 7 = the logit workgroups return at once.
 template <typename T, bool kBackward, bool kGamma2, bool kCL, int kUnroll, int kForm>
 __device__ __forceinline__ double focal_stream(const LossArgs &a, uint32_t block) {
   static_assert(kForm == 0 || kGamma2, "focal_plain is the gamma = 2 form");
@@ -368,6 +369,7 @@ __device__ __forceinline__ void retina_loss_block(const LossArgs &a, uint32_t bl
   double acc_cls = 0.0, acc_box = 0.0, acc_fg = 0.0;
 
   if (block < a.cls_blocks) {
+    if constexpr (kForm == 7) return;                        // timing ablation: no logit walk (wrong sums on purpose)
     const bool g2 = a.gamma == 2.0f;                        // launch-uniform
     if (a.channels_last) acc_cls = g2 ? focal_stream<T, kBackward, true, true, kUnroll, kForm>(a, block)
                                       : focal_stream<T, kBackward, false, true, kUnroll, 0>(a, block);
@@ -375,6 +377,7 @@ __device__ __forceinline__ void retina_loss_block(const LossArgs &a, uint32_t bl
                       : focal_stream<T, kBackward, false, false, kUnroll, 0>(a, block);
   } else {
     // ---- the box deltas: one lane per (image, anchor, pixel), NB parameters each; only foreground anchors count ----
+    if constexpr (kForm == 6) return;                        // timing ablation: no box-delta walk (wrong sums on purpose)
     const float g = kBackward ? (a.g_box ? *a.g_box : 0.0f) : 0.0f;
     float sum_box = 0.0f, n_fg = 0.0f;
     const uint32_t cells = a.batch * A * hw;                // < 2^32 (host)

@@ -604,6 +604,8 @@ void retina_loss_dispatch(const odtk::LossLevelsArgs &la, unsigned total, const 
     if (t.form == 2) { timed_launch(ODTK_KERNEL_LOSS, odtk::retina_loss_kernel<T, false, 4, 2>, grid, block, 0, stream, la); return; }
     if (t.form == 3) { timed_launch(ODTK_KERNEL_LOSS, odtk::retina_loss_kernel<T, false, 4, 3>, grid, block, 0, stream, la); return; }
     if (t.form == 4) { timed_launch(ODTK_KERNEL_LOSS, odtk::retina_loss_kernel<T, false, 4, 4>, grid, block, 0, stream, la); return; }
+    if (t.form == 6) { timed_launch(ODTK_KERNEL_LOSS, odtk::retina_loss_kernel<T, false, 4, 6>, grid, block, 0, stream, la); return; }
+    if (t.form == 7) { timed_launch(ODTK_KERNEL_LOSS, odtk::retina_loss_kernel<T, false, 4, 7>, grid, block, 0, stream, la); return; }
   }
   if (t.form) {
     switch (t.unroll) {
@@ -724,7 +726,7 @@ int odtk_debug_loss_tuning(int which, int fp32_heads, int threads, int blocks_pe
 }
 
 int odtk_debug_loss_form(int form) {
-  if (form < 0 || form > 4) return ODTK_ERR_INVALID;
+  if (form < 0 || form > 7 || form == 5) return ODTK_ERR_INVALID;
   std::lock_guard<std::mutex> lock(g_loss_tuning_mu);
   g_loss_form = form;
   return ODTK_OK;

@@ -139,7 +139,8 @@ def main():
     # ---- 3. where the fp32 forward's time goes: ablations of form 1 (wrong sums on purpose) and its launch shapes ----
     sets = [make_set(torch.float32, 10 + i, True) for i in range(3)]
     fwd = lambda s: _C.retina_loss_levels_forward(s[0], s[1], s[2], s[3], 0.25, 2.0, 0.11)
-    for form, what in ((1, 'form 1'), (2, 'no depth gather'), (3, 'no arithmetic'), (4, 'no index arithmetic, no depth gather'), (1, 'form 1 again')):
+    for form, what in ((1, 'form 1'), (2, 'no depth gather'), (3, 'no arithmetic'), (4, 'no index arithmetic, no depth gather'),
+                       (6, 'no box-delta walk'), (7, 'no logit walk'), (1, 'form 1 again'), (6, 'no box-delta walk again'), (7, 'no logit walk again')):
         _C.loss_form(form)
         say('ablation fp32 nhwc forward, %-38s %6.2f us' % (what + ':', timed(fwd, sets, 30)))
     _C.loss_form(1)
@@ -153,6 +154,10 @@ def main():
     rows.sort()
     for r in rows[:6] + rows[-2:]:
         say('shape fp32 nhwc forward form 1: %6.2f us  threads %4d  per_cu %d  unroll %d' % r)
+    for box_blocks in (16, 64, 256, 1024, 4096):
+        _C.loss_tuning(0, True, 512, 1, 4, box_blocks)
+        say('box workgroups per level %4d: fp32 nhwc forward form 1 %6.2f us' % (box_blocks, timed(fwd, sets, 20)))
+    _C.loss_tuning(0, True, 512, 1, 4, 64)
     ws = lambda s: _C.retina_loss_levels_forward(s[0], s[1], s[2], s[3], 0.25, 2.0, 0.11, reproducible=True)
     rows = []
     for threads in (256, 512):
