@@ -400,9 +400,7 @@ int odtk_debug_loss_tuning(int which, int fp32_heads, int threads, int blocks_pe
  * positive element and no logit above 64 (all but ~1 in 1000) through the negatives-only form u = exp(x), q = u / (1 + u),
  * ce = ln(1 + u) -- the same three hardware transcendentals, about a third fewer full-rate operations; every other vector
  * and every other gamma as with 0.  Results agree to ~1e-8 (sums) / ~1e-6 of the largest gradient.  The default is
- * ODTK_LOSS_FORM_DEFAULT; process-wide, read once per launch.  5: form 1 with the forward's trips software-pipelined (two
- * trips in registers, the next one's loads in flight while the current one is computed; workgroups of at most 512 threads;
- * bit-identical sums in the workspace form; the backward as form 1).  2, 3, 4, 6, 7: TIMING ABLATIONS of form 1 for the fp32
+ * ODTK_LOSS_FORM_DEFAULT; process-wide, read once per launch.  2, 3, 4, 6, 7: TIMING ABLATIONS of form 1 for the fp32
  * forward (no depth gather / no arithmetic / no index arithmetic and no depth gather / no box-delta walk / no logit walk;
  * other launches as form 1) -- their sums are wrong on purpose, tools/loss_form_probe.py is their only user.  Returns
  * ODTK_ERR_INVALID for any other value. */

@@ -196,12 +196,11 @@ __device__ __forceinline__ double block_sum(double v, double *s_red) {
 //   vectors of negatives take focal_plain (above).  2..4 are TIMING ABLATIONS of form 1 whose results are wrong on purpose
 //   (tools/loss_form_probe.py; fp32 forward only): 2 = no depth gather (every cell counts as background), 3 = no arithmetic
 //   (the logits are added up as they are), 4 = no index arithmetic and no depth gather, 6 = the box-delta workgroups return at
-//   once, 7 = the logit workgroups return at once.  5 = form 1 with the forward's trips software-pipelined (below).
+//   once, 7 = the logit workgroups return at once.
 template <typename T, bool kBackward, bool kGamma2, bool kCL, int kUnroll, int kForm>
 __device__ __forceinline__ double focal_stream(const LossArgs &a, uint32_t block) {
   static_assert(kForm == 0 || kGamma2, "focal_plain is the gamma = 2 form");
   constexpr bool kPlain = kForm >= 1, kNoDepth = kForm == 2 || kForm == 4, kNoIndex = kForm == 4, kNoMath = kForm == 3;
-  constexpr bool kPipe = kForm == 5 && !kBackward;         // (backward: its stores share the loads' counter; not pipelined)
   constexpr int kPer = T::kPerLoad;
   constexpr int kDep = kCL ? 1 : kPer;                     // depth words per fast vector
   const uint32_t A = a.num_anchors, C = a.num_classes, hw = a.hw;
@@ -216,108 +215,74 @@ __device__ __forceinline__ double focal_stream(const LossArgs &a, uint32_t block
   const uint32_t stride = a.cls_blocks * blockDim.x;
   double acc = 0.0;
 
-  // One trip of a lane = kUnroll vectors `stride` apart: what its loads bring (Trip), issuing them (load_trip / issue_trip) and
-  // the arithmetic on them (compute_trip).
-  struct Trip {
+  for (uint32_t v0 = block * blockDim.x + threadIdx.x; v0 < n_vec; v0 += stride * kUnroll) {
     vuint4 raw[kUnroll];
     float dep[kUnroll][kDep];
     uint32_t c0[kUnroll];                                  // class of the vector's first element
     bool fast[kUnroll];
-  };
-  auto load_trip = [&](uint32_t v0, Trip &tr) {
 #pragma unroll
     for (int u = 0; u < kUnroll; ++u) {
       const uint32_t v = v0 + u * stride;
-      tr.fast[u] = false;
-      tr.c0[u] = 0;
+      fast[u] = false;
+      c0[u] = 0;
 #pragma unroll
-      for (int e = 0; e < kDep; ++e) tr.dep[u][e] = -1.0f;
+      for (int e = 0; e < kDep; ++e) dep[u][e] = -1.0f;
       if (v < n_vec) {
-        tr.raw[u] = __builtin_nontemporal_load(src + v);
+        raw[u] = __builtin_nontemporal_load(src + v);
         const uint32_t r0 = v * kPer;
         if constexpr (kNoIndex) {
-          tr.fast[u] = true;
-          tr.dep[u][0] = 0.0f;
+          fast[u] = true;
+          dep[u][0] = 0.0f;
           if constexpr (!kCL) {
 #pragma unroll
-            for (int e = 0; e < kDep; ++e) tr.dep[u][e] = 0.0f;
+            for (int e = 0; e < kDep; ++e) dep[u][e] = 0.0f;
           }
         } else if constexpr (kCL) {
           uint32_t ch, pix, c;
           const uint32_t p = fastdivmod(r0, a.by_channels, &ch);
           const uint32_t img = fastdivmod(p, a.by_hw, &pix);
           const uint32_t an = fastdivmod(ch, a.by_classes, &c);
-          tr.c0[u] = c;
-          tr.fast[u] = c + kPer <= C;
-          if (tr.fast[u]) tr.dep[u][0] = kNoDepth ? ((img * A + an) * hw + pix == 0xffffffffu ? -1.0f : 0.0f) : a.depth[(img * A + an) * hw + pix];
+          c0[u] = c;
+          fast[u] = c + kPer <= C;
+          if (fast[u]) dep[u][0] = kNoDepth ? ((img * A + an) * hw + pix == 0xffffffffu ? -1.0f : 0.0f) : a.depth[(img * A + an) * hw + pix];
         } else {
           uint32_t pix, c;
           const uint32_t q = fastdivmod(r0, a.by_hw, &pix);           // (img * A + an) * C + c
           const uint32_t ia = fastdivmod(q, a.by_classes, &c);
-          tr.c0[u] = c;
-          tr.fast[u] = pix + kPer <= hw;
-          if (tr.fast[u]) {
+          c0[u] = c;
+          fast[u] = pix + kPer <= hw;
+          if (fast[u]) {
 #pragma unroll
-            for (int e = 0; e < kDep; ++e) tr.dep[u][e] = kNoDepth ? (ia * hw + pix + e == 0xffffffffu ? -1.0f : 0.0f) : a.depth[ia * hw + pix + e];
+            for (int e = 0; e < kDep; ++e) dep[u][e] = kNoDepth ? (ia * hw + pix + e == 0xffffffffu ? -1.0f : 0.0f) : a.depth[ia * hw + pix + e];
           }
         }
       } else {
-        tr.raw[u] = vuint4{0u, 0u, 0u, 0u};
+        raw[u] = vuint4{0u, 0u, 0u, 0u};
       }
     }
-  };
-  // kPipe: the same loads WITHOUT a branch around them (a vector beyond the end re-reads the last one; compute_trip skips it by its
-  // index): only straight-line loads let the compiler wait for the OLDER trip alone (s_waitcnt vmcnt(n > 0)) while this one flies
-  auto issue_trip = [&](uint32_t v0, Trip &tr) {
-    const uint32_t cells_m1 = a.batch * A * hw - 1u;
-#pragma unroll
-    for (int u = 0; u < kUnroll; ++u) {
-      const uint32_t v = min(v0 + u * stride, n_vec - 1u);
-      tr.raw[u] = __builtin_nontemporal_load(src + v);
-      const uint32_t r0 = v * kPer;
-      if constexpr (kCL) {
-        uint32_t ch, pix, c;
-        const uint32_t p = fastdivmod(r0, a.by_channels, &ch);
-        const uint32_t img = fastdivmod(p, a.by_hw, &pix);
-        const uint32_t an = fastdivmod(ch, a.by_classes, &c);
-        tr.c0[u] = c;
-        tr.fast[u] = c + kPer <= C;
-        tr.dep[u][0] = a.depth[(img * A + an) * hw + pix];
-      } else {
-        uint32_t pix, c;
-        const uint32_t q = fastdivmod(r0, a.by_hw, &pix);
-        const uint32_t ia = fastdivmod(q, a.by_classes, &c);
-        tr.c0[u] = c;
-        tr.fast[u] = pix + kPer <= hw;
-#pragma unroll
-        for (int e = 0; e < kDep; ++e) tr.dep[u][e] = a.depth[min(ia * hw + pix + e, cells_m1)];
-      }
-    }
-  };
-  auto compute_trip = [&](uint32_t v0, const Trip &tr) {
     float sum = 0.0f;                                      // fp32 partial of <= kUnroll * kPer <= 32 elements -> fp64
 #pragma unroll
     for (int u = 0; u < kUnroll; ++u) {
       const uint32_t v = v0 + u * stride;
       if (v >= n_vec) break;
       float out[kPer];
-      if (tr.fast[u]) {
+      if (fast[u]) {
         // evaluated for every element (no branch around the arithmetic: lanes diverge on `depth`), masked afterwards.
         // depth is integral by contract (-1 / 0 / class + 1): "depth > 0 and class == depth - 1" is ONE compare
-        const float tgt0 = static_cast<float>(tr.c0[u] + 1);
+        const float tgt0 = static_cast<float>(c0[u] + 1);
         float vs = 0.0f;
         bool plain = false;
         if constexpr (kPlain) {
-          float mx = vec_elem<T>(tr.raw[u], 0);
+          float mx = vec_elem<T>(raw[u], 0);
 #pragma unroll
-          for (int e = 1; e < kPer; ++e) mx = fmaxf(mx, vec_elem<T>(tr.raw[u], e));
+          for (int e = 1; e < kPer; ++e) mx = fmaxf(mx, vec_elem<T>(raw[u], e));
           if constexpr (kCL) {
-            const float rel = tr.dep[u][0] - tgt0;                                  // which element is the anchor's class, if any
+            const float rel = dep[u][0] - tgt0;                                  // which element is the anchor's class, if any
             plain = !(rel >= 0.0f && rel < static_cast<float>(kPer));
           } else {
             plain = true;
 #pragma unroll
-            for (int e = 0; e < kPer; ++e) plain = plain && tr.dep[u][e] != tgt0;
+            for (int e = 0; e < kPer; ++e) plain = plain && dep[u][e] != tgt0;
           }
           plain = plain && mx <= kPlainMax;
         }
@@ -326,23 +291,23 @@ __device__ __forceinline__ double focal_stream(const LossArgs &a, uint32_t block
           const float wv = kBackward ? w_neg : w_neg * 0.6931471805599453f;
 #pragma unroll
           for (int e = 0; e < kPer; ++e) {
-            const float t = kNoMath ? vec_elem<T>(tr.raw[u], e) : focal_plain<kBackward>(vec_elem<T>(tr.raw[u], e));
-            if constexpr (kBackward) out[e] = tr.dep[u][kCL ? 0 : e] >= 0.0f ? wv * t : 0.0f;
+            const float t = kNoMath ? vec_elem<T>(raw[u], e) : focal_plain<kBackward>(vec_elem<T>(raw[u], e));
+            if constexpr (kBackward) out[e] = dep[u][kCL ? 0 : e] >= 0.0f ? wv * t : 0.0f;
             else if constexpr (kCL) vs += t;
-            else vs += tr.dep[u][e] >= 0.0f ? t : 0.0f;
+            else vs += dep[u][e] >= 0.0f ? t : 0.0f;
           }
-          if constexpr (!kBackward) sum += kCL ? (tr.dep[u][0] >= 0.0f ? wv * vs : 0.0f) : wv * vs;
+          if constexpr (!kBackward) sum += kCL ? (dep[u][0] >= 0.0f ? wv * vs : 0.0f) : wv * vs;
         } else {
 #pragma unroll
           for (int e = 0; e < kPer; ++e) {
-            const float d = tr.dep[u][kCL ? 0 : e];
+            const float d = dep[u][kCL ? 0 : e];
             const bool positive = d == (kCL ? tgt0 + static_cast<float>(e) : tgt0);
-            const float t = focal_term<kBackward, kGamma2>(vec_elem<T>(tr.raw[u], e), positive, w_neg, w_pos, gamma);
+            const float t = focal_term<kBackward, kGamma2>(vec_elem<T>(raw[u], e), positive, w_neg, w_pos, gamma);
             if constexpr (kBackward) out[e] = d >= 0.0f ? t : 0.0f;              // model.py:199 cls_mask
             else if constexpr (kCL) vs += t;
             else vs += d >= 0.0f ? t : 0.0f;
           }
-          if constexpr (!kBackward) sum += kCL ? (tr.dep[u][0] >= 0.0f ? vs : 0.0f) : vs;
+          if constexpr (!kBackward) sum += kCL ? (dep[u][0] >= 0.0f ? vs : 0.0f) : vs;
         }
       } else {
         // decompose the first element again; the others follow by increment with carry
@@ -362,7 +327,7 @@ __device__ __forceinline__ double focal_stream(const LossArgs &a, uint32_t block
         for (int e = 0; e < kPer; ++e) {
           const float d = a.depth[(i2 * A + a2) * hw + p2];
           const bool positive = d == static_cast<float>(c2 + 1);
-          const float t = focal_term<kBackward, kGamma2>(vec_elem<T>(tr.raw[u], e), positive, w_neg, w_pos, gamma);
+          const float t = focal_term<kBackward, kGamma2>(vec_elem<T>(raw[u], e), positive, w_neg, w_pos, gamma);
           if constexpr (kBackward) out[e] = d >= 0.0f ? t : 0.0f;
           else sum += d >= 0.0f ? t : 0.0f;
           if constexpr (kCL) { if (++c2 == C) { c2 = 0; if (++a2 == A) { a2 = 0; if (++p2 == hw) { p2 = 0; ++i2; } } } }
@@ -372,29 +337,6 @@ __device__ __forceinline__ double focal_stream(const LossArgs &a, uint32_t block
       if constexpr (kBackward) __builtin_nontemporal_store(pack_vec<T>(out), static_cast<vuint4 *>(a.dcls) + v);
     }
     if constexpr (!kBackward) acc += sum;
-  };
-  const uint32_t first = block * blockDim.x + threadIdx.x, step = stride * kUnroll;   // step <= 2^26, n_vec < 2^30: no overflow
-  if constexpr (!kPipe) {
-    for (uint32_t v0 = first; v0 < n_vec; v0 += step) {
-      Trip tr;
-      load_trip(v0, tr);
-      compute_trip(v0, tr);
-    }
-  } else if (n_vec != 0) {
-    // two trips in registers, no copies: while one is computed the other one's loads are in flight -- the forward's few,
-    // large workgroups otherwise pay a full memory latency with NOTHING in flight once per trip (P3: 11 trips; section 4)
-    Trip ta, tb;
-    uint32_t v0 = first;
-    issue_trip(v0, ta);
-    while (v0 < n_vec) {
-      issue_trip(v0 + step, tb);
-      compute_trip(v0, ta);
-      v0 += step;
-      if (v0 >= n_vec) break;
-      issue_trip(v0 + step, ta);
-      compute_trip(v0, tb);
-      v0 += step;
-    }
   }
 
   // scalar tail (n % kPer elements), first block only
@@ -488,11 +430,8 @@ struct LossLevelsArgs {
   int n_levels;
 };
 
-// (form 5 holds two trips in registers: workgroups of at most 512 threads, i.e. up to 256 VGPRs -- the host clamps)
-constexpr int kLossPipeThreads = 512;
-
 template <typename T, bool kBackward, int kUnroll, int kForm>
-__global__ __launch_bounds__(kForm == 5 && !kBackward ? kLossPipeThreads : kLossMaxThreads) void retina_loss_kernel(const LossLevelsArgs a) {
+__global__ __launch_bounds__(kLossMaxThreads) void retina_loss_kernel(const LossLevelsArgs a) {
   __shared__ double s_red[kLossMaxThreads / kWave];
   int l = 0;
 #pragma unroll

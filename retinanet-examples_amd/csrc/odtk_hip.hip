@@ -549,7 +549,6 @@ LossTuning loss_tuning_snapshot(int dtype, int which) {
   std::lock_guard<std::mutex> lock(g_loss_tuning_mu);
   LossTuning t = g_loss_tuning[dtype == ODTK_F32][which];
   t.form = g_loss_form;
-  if (t.form == 5 && which != kLossBwd && t.threads > odtk::kLossPipeThreads) t.threads = odtk::kLossPipeThreads;
   return t;
 }
 
@@ -607,16 +606,6 @@ void retina_loss_dispatch(const odtk::LossLevelsArgs &la, unsigned total, const 
     if (t.form == 4) { timed_launch(ODTK_KERNEL_LOSS, odtk::retina_loss_kernel<T, false, 4, 4>, grid, block, 0, stream, la); return; }
     if (t.form == 6) { timed_launch(ODTK_KERNEL_LOSS, odtk::retina_loss_kernel<T, false, 4, 6>, grid, block, 0, stream, la); return; }
     if (t.form == 7) { timed_launch(ODTK_KERNEL_LOSS, odtk::retina_loss_kernel<T, false, 4, 7>, grid, block, 0, stream, la); return; }
-  }
-  if constexpr (!kBackward) {
-    if (t.form == 5) {                                      // form 1 with the trips software-pipelined (forward only)
-      switch (t.unroll) {
-        case 1: timed_launch(ODTK_KERNEL_LOSS, odtk::retina_loss_kernel<T, false, 1, 5>, grid, block, 0, stream, la); break;
-        case 2: timed_launch(ODTK_KERNEL_LOSS, odtk::retina_loss_kernel<T, false, 2, 5>, grid, block, 0, stream, la); break;
-        default: timed_launch(ODTK_KERNEL_LOSS, odtk::retina_loss_kernel<T, false, 4, 5>, grid, block, 0, stream, la); break;
-      }
-      return;
-    }
   }
   if (t.form) {
     switch (t.unroll) {
@@ -737,7 +726,7 @@ int odtk_debug_loss_tuning(int which, int fp32_heads, int threads, int blocks_pe
 }
 
 int odtk_debug_loss_form(int form) {
-  if (form < 0 || form > 7) return ODTK_ERR_INVALID;
+  if (form < 0 || form > 7 || form == 5) return ODTK_ERR_INVALID;
   std::lock_guard<std::mutex> lock(g_loss_tuning_mu);
   g_loss_form = form;
   return ODTK_OK;

@@ -181,17 +181,17 @@ def test_loss_tuning_hook_validates_without_a_gpu():
 
 
 def test_loss_form_hook_validates_without_a_gpu():
-    """odtk_debug_loss_form (arithmetic form of the gamma = 2 classification walk): 0 / 1 / 5 and the timing ablations 2..4, 6, 7; the
+    """odtk_debug_loss_form (arithmetic form of the gamma = 2 classification walk): 0 / 1 and the timing ablations 2..4, 6, 7; the
     binding's default is the header's ODTK_LOSS_FORM_DEFAULT."""
     lib = _C.library()
     header = open(os.path.join(ROOT, 'include', 'odtk_hip.h')).read()
     assert int(re.search(r'#define ODTK_LOSS_FORM_DEFAULT\s+(\d+)', header).group(1)) == _C.LOSS_FORM_DEFAULT
-    for bad in (-1, 8, 9):
+    for bad in (-1, 5, 8):
         assert lib.odtk_debug_loss_form(bad) == _C.ERR_INVALID
-    for good in (0, 1, 4, 5, 7, _C.LOSS_FORM_DEFAULT):
+    for good in (0, 1, 4, _C.LOSS_FORM_DEFAULT):
         assert lib.odtk_debug_loss_form(good) == 0
     with pytest.raises(RuntimeError, match='invalid argument'):
-        _C.loss_form(8)
+        _C.loss_form(5)
 
 
 def test_loss_forward_workspace_query_without_a_gpu():

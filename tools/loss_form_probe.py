@@ -177,40 +177,6 @@ def main():
     rows.sort()
     for r in rows[:4] + rows[-1:]:
         say('shape fp32 nhwc forward (workspace, 2 launches) form 1: %6.2f us  threads %4d  per_cu %2d  unroll %d' % r)
-    # ---- 4. form 5: form 1 with the forward's trips software-pipelined (same operations in the same order: bit-equal sums) ----
-    del sets
-    for dtype, name, cl in ((torch.float32, 'fp32', True), (torch.bfloat16, 'bf16', True), (torch.float32, 'fp32', False)):
-        fp32 = dtype == torch.float32
-        sets = [make_set(dtype, 10 + i, cl) for i in range(3)]
-        ws = lambda s: _C.retina_loss_levels_forward(s[0], s[1], s[2], s[3], 0.25, 2.0, 0.11, reproducible=True)
-        fwd = lambda s: _C.retina_loss_levels_forward(s[0], s[1], s[2], s[3], 0.25, 2.0, 0.11)
-        _C.loss_form(1)
-        want = ws(sets[1]).clone()
-        _C.loss_form(5)
-        got = ws(sets[1]).clone()
-        good = torch.equal(want, got)
-        ok &= good
-        say('form 5 %s %s: workspace-form sums bit-equal to form 1: %s' % (name, 'nhwc' if cl else 'nchw', 'ok' if good else 'BAD %s %s' % (want.tolist(), got.tolist())))
-        row = []
-        for form in (1, 5, 1, 5):
-            _C.loss_form(form)
-            row.append(timed(fwd, sets, 30))
-        alg = sum(B * A * C * h * w for h, w in SIZES) * (4 if fp32 else 2)
-        say('time %s %s forward  form 1: %6.2f / %6.2f us   form 5: %6.2f / %6.2f us   -> %.3f -> %.3f of 8 TB/s'
-            % (name, 'nhwc' if cl else 'nchw', row[0], row[2], row[1], row[3], alg / min(row[0], row[2]) / 1e3 / 8000, alg / min(row[1], row[3]) / 1e3 / 8000))
-        if cl:
-            _C.loss_form(5)
-            rows = []
-            for threads in (256, 512):
-                for per_cu in (1, 2, 4):
-                    for unroll in (1, 2, 4):
-                        _C.loss_tuning(0, fp32, threads, per_cu, unroll, 64)
-                        rows.append((timed(fwd, sets, 20), threads, per_cu, unroll))
-            _C.loss_tuning(0, fp32, 512, 1, 4 if fp32 else 2, 64)
-            rows.sort()
-            for r in rows[:5] + rows[-1:]:
-                say('shape %s nhwc forward form 5: %6.2f us  threads %4d  per_cu %d  unroll %d' % ((name,) + r))
-        del sets
     _C.profile_enable(False)
     _C.loss_form(_C.LOSS_FORM_DEFAULT)
     say('ALL AGREE' if ok else 'DISAGREEMENT')
