@@ -62,7 +62,27 @@ def timed(fn, sets, iters):
     return ms * 1e3 / iters
 
 
+def pmc_mode():
+    """A short, fixed sequence for a rocprofv3 --pmc pass (tools/loss_pmc.sh): per dtype 3 warm-up + 10 measured launches of
+    the forward (atomics form), the forward through the workspace and the backward, inputs rotated through three sets."""
+    gc = torch.full((len(SIZES),), 0.37, device='cuda')
+    gb = torch.full((len(SIZES),), -1.9, device='cuda')
+    for dtype in (torch.float32, torch.bfloat16):
+        sets = [make_set(dtype, 10 + i, True) for i in range(3)]
+        for i in range(13):
+            s = sets[i % 3]
+            _C.retina_loss_levels_forward(s[0], s[1], s[2], s[3], 0.25, 2.0, 0.11)
+        for i in range(13):
+            s = sets[i % 3]
+            _C.retina_loss_levels_backward(s[0], s[1], s[2], s[3], 0.25, 2.0, 0.11, gc, gb)
+        torch.cuda.synchronize()
+        del sets
+    return 0
+
+
 def main():
+    if '--pmc' in sys.argv:
+        return pmc_mode()
     gc = torch.full((len(SIZES),), 0.37, device='cuda')
     gb = torch.full((len(SIZES),), -1.9, device='cuda')
     ok = True
