@@ -88,6 +88,51 @@ def test_ddp_two_ranks_gloo():
     assert res[0][3] == res[1][3]             # the reduced losses are the same on both ranks
 
 
+def _quiet_worker(rank, world, port, q):
+    """bench.py run_train's `exposed_allreduce_ms`: steps through the DDP wrapper, then the SAME step on the bare module (same
+    parameters and optimizer, no gradient all-reduce).  DDP's gradient hooks stay registered on the parameters; outside a DDP
+    forward they must do nothing -- and the bare step must be exactly the step DDP's no_sync() would take."""
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    dev = torch.device('cpu')
+    data, target = T.SyntheticBatches(2, 128, 128, classes=4, max_boxes=4, seed=3, rank=rank, world=world).batch()
+    out = []
+    for mode in ('bare', 'no_sync'):
+        model, net, opt, sched = T.prepare(_build(), dev, lr=0.001, world=world, rank=rank, warmup=10)
+        for _ in range(2):
+            T.train_step(net, opt, sched, None, data, target)
+        if mode == 'bare':
+            for _ in range(2):
+                c, b = T.train_step(model, opt, sched, None, data, target)
+        else:
+            with net.no_sync():
+                for _ in range(2):
+                    c, b = T.train_step(net, opt, sched, None, data, target)
+        out.append((float(c), float(b), torch.cat([p.detach().flatten() for p in model.parameters()])))
+    # (run-to-run noise of the CPU convolution backward is ~1e-20 on a few hundred parameters: compare to 1e-12, not bit for bit)
+    q.put((rank, out[0][:2], out[1][:2], float((out[0][2] - out[1][2]).abs().max())))
+    dist.destroy_process_group()
+
+
+def test_bare_module_steps_after_ddp_steps_equal_no_sync_steps():
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_quiet_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=600) for _ in range(world))
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    for rank, bare, no_sync, worst in res:
+        assert all(abs(x - y) <= 1e-6 * abs(y) for x, y in zip(bare, no_sync)) and all(v == v and v > 0 for v in bare)
+        assert worst <= 1e-12                 # the same parameters after the quiet steps either way
+    assert res[0][1] != res[1][1]             # no all-reduce in the quiet steps: the replicas have drifted apart
+
+
 def test_lr_schedule_and_synthetic_batches():
     f = T.lr_schedule(100, [200, 300], 0.1)
     assert abs(f(0) - 0.1) < 1e-12 and abs(f(50) - 0.55) < 1e-12 and f(100) == 1.0
