@@ -41,6 +41,10 @@ for p in (ROOT, os.path.join(ROOT, 'retinanet-examples_amd')):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+# multi-process GPU work on this image needs dmabuf IPC (the host driver has no legacy IPC: RCCL otherwise fails with
+# `hipIpcGetMemHandle: invalid argument`); the launcher's environment normally carries it already
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+
 import torch                      # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
