@@ -6,7 +6,10 @@ and `slots` = full + 4 x quarter (the issue slots of a wave64 on a 16-lane SIMD 
 occupies 4 of them).  `per` divides by the number of v_exp_f32 in the body (one per logit in the gamma = 2 loss kernels).
 No GPU needed: this is how a change to an arithmetic-bound kernel is sized before it is measured.
 
-    python tools/isa_loops.py file.s [substring of the kernel name] [--blocks]
+    python tools/isa_loops.py file.s [substring of the kernel name] [--blocks] [--quarter-cost=4]
+
+--quarter-cost: issue slots charged per quarter-rate instruction (default 4, the architectural rate; MI355X_MICROARCH.md measures
+the ISSUE cost of a transcendental beside other work at ~5/3 of a plain VALU operation -- pass 1.67 to count that way).
 
 --blocks: instead of the loops, every straight-line block (label / branch to label / branch) that holds a v_exp_f32 -- the
 arithmetic of one code path without the other paths of the same loop mixed in.
@@ -95,6 +98,7 @@ def main():
     args = [a for a in sys.argv[2:] if not a.startswith('--')]
     want = args[0] if args else ''
     by_block = '--blocks' in sys.argv
+    quarter_cost = next((float(a.split('=', 1)[1]) for a in sys.argv[2:] if a.startswith('--quarter-cost=')), 4.0)
     for name, body in kernels(text):
         if want not in name:
             continue
@@ -106,9 +110,9 @@ def main():
             for s in seq:
                 n[classify(s.split()[0])] += 1
             exps = sum(1 for s in seq if s.startswith('v_exp_f32'))
-            slots = n['valu'] + n['packed'] + 4 * n['quarter']
+            slots = n['valu'] + n['packed'] + quarter_cost * n['quarter']
             per = ' = %.1f slots per v_exp' % (slots / exps) if exps else ''
-            print('  %-4s %-10s %5d instr: valu %4d  packed %3d  quarter %3d  vmem %3d  lds %2d  salu %3d  -> %d VALU slots%s'
+            print('  %-4s %-10s %5d instr: valu %4d  packed %3d  quarter %3d  vmem %3d  lds %2d  salu %3d  -> %.0f VALU slots%s'
                   % ('block' if by_block else 'loop', label, len(seq), n['valu'], n['packed'], n['quarter'], n['vmem'], n['lds'], n['salu'], slots, per))
 
 
