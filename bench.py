@@ -32,6 +32,7 @@ Extra objects on the line:
 import argparse
 import copy
 import json
+import math
 import os
 import sys
 import time
@@ -126,6 +127,8 @@ def run_train(args, rank, local_rank, world, dev):
     model.initialize(None)
     per_gpu = args.batch
     amp_dtype = {'bf16': torch.bfloat16, 'fp16': torch.float16, 'fp32': None}[args.dtype]
+    on_gpu = dev.type == 'cuda'
+    sync = torch.cuda.synchronize if on_gpu else (lambda: None)
     model, net, optimizer, scheduler = T.prepare(model, dev, lr=0.01, world=world, rank=rank, warmup=1000)
     model.fused_loss = not args.no_fused_loss
     scaler = torch.amp.GradScaler('cuda', enabled=amp_dtype == torch.float16) if amp_dtype == torch.float16 else None
@@ -147,20 +150,21 @@ def run_train(args, rank, local_rank, world, dev):
 
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize()
-    elapsed, _ = parallel.timed_steps(step, args.steps, torch.cuda.synchronize, dev)
+    sync()
+    elapsed, _ = parallel.timed_steps(step, args.steps, sync, dev)
     both = T.reduce_losses(losses[-1][0], losses[-1][1], world)
     # the hand-written training-side kernels, timed on a few extra steps outside the timed region.  EVERY rank runs the
     # steps (each one all-reduces gradients under DDP); only rank 0 records
-    from odtk import _C
     hip_kernels = None
-    if rank == 0:
+    if on_gpu:
+        from odtk import _C
+    if rank == 0 and on_gpu:
         _C.profile_enable(True, ('retina_loss_kernel', 'snap_to_anchors_kernel'))
         _C.profile_collect()
-    for _ in range(5):
+    for _ in range(5 if on_gpu else 0):
         step()
-    torch.cuda.synchronize()
-    if rank == 0:
+    sync()
+    if rank == 0 and on_gpu:
         _C.profile_enable(False)
         prof = _C.profile_collect()
         hip_kernels = {k: {'us_per_step': round(v[0] / 5 * 1e3, 1), 'launches_per_step': v[1] // 5} for k, v in prof.items() if v[1]}
@@ -181,10 +185,11 @@ def run_train(args, rank, local_rank, world, dev):
             d, t = batches[it[0] % len(batches)]
             it[0] += 1
             return T.train_step(model, optimizer, scheduler, scaler, d, t, amp_dtype)[0]
-        for _ in range(2):
+        for _ in range(2 if on_gpu else 1):
             quiet_step()
-        quiet, _ = parallel.timed_steps(quiet_step, max(args.steps // 2, 5), torch.cuda.synchronize, dev)
-        exposed = round((elapsed / args.steps - quiet / max(args.steps // 2, 5)) * 1e3, 3)
+        n_quiet = max(args.steps // 2, 5) if on_gpu else max(args.steps // 2, 1)
+        quiet, _ = parallel.timed_steps(quiet_step, n_quiet, sync, dev)
+        exposed = round((elapsed / args.steps - quiet / n_quiet) * 1e3, 3)
     line = None
     if rank == 0:
         images = per_gpu * world * args.steps
@@ -198,17 +203,31 @@ def run_train(args, rank, local_rank, world, dev):
             'data': 'synthetic randn images + synthetic targets (1..20 boxes per image, SURVEY 8d config 3), random-init weights',
             'config': {'workload': '%s %s training, %d images per GPU at %dx%d, target assignment + losses: %s'
                                    % (args.backbone, args.dtype, per_gpu, args.height, args.width,
-                                      'fused HIP' if model.fused_loss else 'torch'),
-                       'global_batch': per_gpu * world, 'parallelism': 'ddp x%d (RCCL all-reduce, 25 MB buckets, overlapped)' % world,
-                       'gradient_bytes_per_step': grad_bytes},
+                                      'fused HIP' if (model.fused_loss and on_gpu) else 'torch'),
+                       'global_batch': per_gpu * world,
+                       'parallelism': 'ddp x%d (%s all-reduce, 25 MB buckets, overlapped)' % (world, 'RCCL' if args.backend == 'nccl' else args.backend),
+                       'gradient_bytes_per_step': grad_bytes, 'device': dev.type, 'backend': args.backend if world > 1 else None},
             'exposed_allreduce_ms': exposed, 'hip_kernels': hip_kernels,
-            'loss': {'focal': round(float(both[0]), 5), 'box': round(float(both[1]), 5),
-                     'first_step': [round(float(v), 5) for v in losses[0]],
-                     'note': None if (float(both[0]) == float(both[0]) and float(both[1]) == float(both[1])) else
-                     "non-finite after %d SGD steps from the reference's random init on random targets (model.py:121-122 puts the class prior "
-                     'on the box head: box loss starts at ~28); throughput is what this leg measures' % len(losses)},
+            # a throughput measured on non-finite tensors is not a measurement of the configuration: `finite` says which it is
+            'loss': {'focal': round(float(both[0]), 5), 'box': round(float(both[1]), 5), 'first_step': [round(float(v), 5) for v in losses[0]],
+                     'finite': bool(math.isfinite(float(both[0])) and math.isfinite(float(both[1]))), 'sgd_steps': len(losses)},
         }
+        if not line['loss']['finite']:
+            line['error'] = 'loss went non-finite within %d SGD steps: the throughput below is not a valid measurement' % len(losses)
     return line
+
+
+def kernel_src_hash():
+    """sha256 (16 hex) over the HIP sources of the C-ABI library: ties a figure quoted from profiles/ to the kernels it was
+    measured on (tools/pmc_traffic.py records the same hash)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, 'retinanet-examples_amd', 'csrc', '*.hpp')) +
+                    glob.glob(os.path.join(ROOT, 'retinanet-examples_amd', 'csrc', '*.hip'))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, 'rb').read())
+    return h.hexdigest()[:16]
 
 
 def default_workload(args):
@@ -221,7 +240,7 @@ def short_name(backbone):
     return backbone.replace('ResNet', 'RN').replace('ResNeXt', 'RNX')
 
 
-def main():
+def build_parser():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=50)
@@ -256,34 +275,215 @@ def main():
     ap.add_argument('--no-fused-loss', action='store_true', help='train mode: torch losses instead of the HIP focal/smooth-L1 kernel')
     ap.add_argument('--no-other-configs', action='store_true',
                     help="default 1-GPU run: skip the legs for BASELINE.json's other configurations (`other_configs` on the line)")
-    ap.add_argument('--other-steps', type=int, default=20, help='timed steps of each other_configs leg')
-    args = ap.parse_args()
+    ap.add_argument('--other-steps', type=int, default=10, help='timed steps of each other_configs leg')
+    ap.add_argument('--leg-budget-s', type=float, default=100.0,
+                    help='wall-clock budget of the other_configs legs together: a leg only starts while budget is left (its typical '
+                         'cost included); the rest are reported as skipped.  0 = no limit (tools/profile_round.sh)')
+    ap.add_argument('--device', default='cuda', choices=['cuda', 'cpu'],
+                    help='cpu: the plumbing run of the CPU tests (gloo, the reference CPU branch of odtk/box.py; no HIP kernel runs, '
+                         'no roofline) -- never a measurement')
+    ap.add_argument('--backend', default=None, choices=['nccl', 'gloo'], help='default: nccl (= RCCL) on cuda, gloo on cpu')
+    ap.add_argument('--tiny', action='store_true', help='ResNet18FPN on one 128x128 image per rank: the size the CPU tests run')
+    ap.add_argument('--detail-out', default=os.path.join(ROOT, 'gpurun_out', 'bench_detail_latest.json'),
+                    help='where the full record (every leg, every sub-object) is written; the stdout line is the compact headline')
+    return ap
+
+
+def sanitize(obj):
+    """Strict-JSON form: non-finite floats -> None, tensors / numpy scalars -> python numbers, tuples -> lists."""
+    if isinstance(obj, dict):
+        return {str(k): sanitize(v) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return [sanitize(v) for v in obj]
+    if isinstance(obj, bool) or obj is None or isinstance(obj, (int, str)):
+        return obj
+    if isinstance(obj, float):
+        return obj if math.isfinite(obj) else None
+    if hasattr(obj, 'item'):                                 # torch / numpy scalar
+        try:
+            return sanitize(obj.item())
+        except Exception:                                    # noqa: BLE001
+            return str(obj)
+    return str(obj)
+
+
+def strict_json(obj):
+    return json.dumps(sanitize(obj), allow_nan=False, separators=(', ', ': '))
+
+
+def pick(d, *keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d} if d else None
+
+
+HEADLINE_LIMIT = 4096
+
+
+def headline(full):
+    """The compact object that goes on stdout (< HEADLINE_LIMIT bytes, strict JSON): the contract's keys + `roofline` +
+    `cpu_baseline`, the latency-bound ratios, the conv roofline, and ONE number per other configuration.  Everything else
+    (per-leg records, epilogue figures, figures quoted from committed profiles) lives in the detail file."""
+    h = {k: full.get(k) for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better',
+                                  'scaling', 'vs_baseline', 'dtype', 'data')}
+    cfg = full.get('config') or {}
+    h['config'] = pick(cfg, 'workload', 'global_batch', 'parallelism', 'entry', 'postproc', 'device', 'backend')
+    if full.get('roofline'):
+        h['roofline'] = pick(full['roofline'], 'kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic',
+                             'alg_bytes_per_launch', 'avg_us', 'launches')
+    else:
+        h['roofline'] = None
+    lb = full.get('latency_bound') or {}
+    if lb:
+        h['latency_bound'] = {k: pick(v, 'us_per_step', 'launches_per_step', 'lower_bound_us', 'ratio') for k, v in lb.items()}
+    if full.get('conv_roofline'):
+        h['conv_roofline'] = pick(full['conv_roofline'], 'bound', 'achieved', 'peak', 'unit', 'frac')
+    if full.get('kernels'):
+        h['kernels_avg_us'] = {k: v.get('avg_us') for k, v in full['kernels'].items()}
+        h['postproc_us_per_step'] = full.get('postproc_us_per_step')
+    if full.get('eager'):
+        h['eager'] = pick(full['eager'], 'value', 'ms_per_step')
+    cb = full.get('cpu_baseline')
+    if cb:
+        h['cpu_baseline'] = pick(cb, 'value', 'unit', 'cores', 'kind', 'sample')
+        if cb.get('postproc'):
+            h['cpu_baseline']['postproc'] = pick(cb['postproc'], 'value', 'unit', 'ms_per_image', 'cores', 'kind',
+                                                 'gpu_us_per_image', 'gpu_vs_cpu')
+    else:
+        h['cpu_baseline'] = None
+    for k in ('parity', 'exposed_allreduce_ms', 'loss', 'quoted'):
+        if full.get(k) is not None:
+            h[k] = full[k]
+    if full.get('hip_kernels'):
+        h['hip_kernels'] = {k: pick(v, 'us_per_step', 'frac_of_hbm_peak') for k, v in full['hip_kernels'].items()}
+    legs = full.get('other_configs')
+    if legs:
+        h['other_configs'] = {}
+        for leg in legs:
+            e = pick(leg, 'value', 'unit', 'ms_per_step', 'dtype', 'error', 'skipped')
+            if leg.get('roofline'):
+                e['roofline_frac'] = leg['roofline'].get('frac')
+            if isinstance(leg.get('latency_bound'), dict):
+                e['latency_ratio'] = {k: v.get('ratio') for k, v in leg['latency_bound'].items()}
+            if isinstance(leg.get('loss'), dict):
+                e['loss'] = pick(leg['loss'], 'focal', 'box', 'finite')
+            h['other_configs'][leg.get('key', leg.get('leg', '?'))] = e
+    h['detail'] = full.get('detail')
+    return h
+
+
+def headline_line(full):
+    """-> the ONE stdout line.  Never raises, never exceeds HEADLINE_LIMIT: optional objects are dropped in order (least
+    important first) until it fits."""
+    h = headline(full)
+    line = strict_json(h)
+    for drop in ('quoted', 'eager', 'kernels_avg_us', 'hip_kernels', 'loss', 'parity', 'other_configs', 'conv_roofline',
+                 'latency_bound', 'data'):
+        if len(line) < HEADLINE_LIMIT:
+            break
+        h.pop(drop, None)
+        h['dropped_to_fit'] = h.get('dropped_to_fit', []) + [drop]
+        line = strict_json(h)
+    if len(line) >= HEADLINE_LIMIT and isinstance(h.get('cpu_baseline'), dict):
+        h['cpu_baseline']['sample'] = str(h['cpu_baseline'].get('sample'))[:120]
+        line = strict_json(h)
+    return line
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script (one per GPU, the reference's own habit --
+    odtk/main.py:155-171,246-250 spawns one worker per GPU and initialises NCCL from MASTER_ADDR/PORT), wait for them, and
+    hand back the first non-zero exit code.  Rank 0 inherits stdout, so its one JSON line is this command's line."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for rank in range(args.gpus):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(args.gpus), MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'),
+                   ODTK_BENCH_SELF_LAUNCHED='1')
+        if args.device == 'cpu':
+            env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 2) // args.gpus)))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=None if rank == 0 else subprocess.DEVNULL))
+    codes = []
+    try:
+        for p in procs:
+            codes.append(p.wait())
+    except BaseException:                                    # Ctrl-C / a driver timeout: take the ranks we started down with us
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        raise
+    return next((c for c in codes if c), 0)
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    ap = build_parser()
+    args = ap.parse_args(argv)
     default_run = all(getattr(args, k) == ap.get_default(k) for k in
-                      ('mode', 'backbone', 'batch', 'height', 'width', 'dtype', 'rotated_bbox', 'no_fuse', 'postproc', 'fraction'))
+                      ('mode', 'backbone', 'batch', 'height', 'width', 'dtype', 'rotated_bbox', 'no_fuse', 'postproc', 'fraction',
+                       'device', 'tiny'))
+    if args.tiny:
+        args.backbone, args.height, args.width = 'ResNet18FPN', 128, 128
+        args.batch = args.batch or 1
+        args.cpu_seconds, args.no_eager_leg, args.no_other_configs = 0.0, True, True
     if args.batch is None:
         args.batch = 8 if args.mode == 'infer' else 2
     if args.dtype is None:
-        args.dtype = 'bf16' if args.mode == 'infer' else 'fp32'
+        args.dtype = 'fp32' if (args.mode == 'train' or args.device == 'cpu') else 'bf16'
+    if args.backend is None:
+        args.backend = 'nccl' if args.device == 'cuda' else 'gloo'    # "nccl" IS RCCL on ROCm
+
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(self_launch(args, argv))
+
+    # stdout carries ONE line.  Libraries write there too (gloo's "[Gloo] Rank 0 is connected ..." banner, NCCL_DEBUG=INFO):
+    # point fd 1 at stderr for the life of the process and keep a private handle on the real stdout for the headline
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), 'w')
+    os.dup2(2, 1)
 
     from odtk import parallel
-    rank, local_rank, world = parallel.init_from_env('nccl')     # "nccl" IS RCCL on ROCm
-    assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
-    assert torch.cuda.is_available(), 'bench.py needs a GPU (the HIP post-processing is what it measures)'
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
-    miopen_find = not args.no_miopen_find
-    torch.backends.cudnn.benchmark = miopen_find
+    rank, local_rank, world = parallel.init_from_env(args.backend)
+    if world != args.gpus:
+        raise SystemExit('bench.py --gpus %d was started with WORLD_SIZE=%d: launch one rank per GPU (or drop the launcher: '
+                         'bench.py spawns its own ranks)' % (args.gpus, world))
+    if args.device == 'cuda':
+        assert torch.cuda.is_available(), 'bench.py needs a GPU (the HIP post-processing is what it measures)'
+        torch.cuda.set_device(local_rank)
+        dev = torch.device('cuda', local_rank)
+    else:
+        dev = torch.device('cpu')
+    torch.backends.cudnn.benchmark = not args.no_miopen_find
+    t_start = time.perf_counter()
     if args.mode == 'train':
         line = run_train(args, rank, local_rank, world, dev)
     else:
         line = run_infer(args, rank, world, dev)
+    if rank == 0:
+        # the headline is safe from here on: printed FIRST to stderr (a leg that kills the process cannot take it down),
+        # then the legs, then the one stdout line
+        log('[bench] headline %.1f s: %s' % (time.perf_counter() - t_start, headline_line(line)))
         # BASELINE.json's other configurations behind the headline (1 GPU, default invocation only): RN101FPN bs 16 (config 4),
         # --rotated-bbox bs 8 (config 5), the per-GPU share of config 3 (fp32 training, 2 images) and the batch-1 latency the
         # reference publishes for its TensorRT engines (README.md:26-34; timing loop extras/cppapi/infer.cpp:69-77)
-        if world == 1 and rank == 0 and default_run and not args.no_other_configs:
-            line['other_configs'] = other_configs(args, rank, local_rank, world, dev)
-    if rank == 0:
-        print(json.dumps(line), flush=True)
+        if world == 1 and default_run and args.mode == 'infer' and not args.no_other_configs:
+            try:
+                line['other_configs'] = other_configs(args, rank, local_rank, world, dev)
+            except Exception as e:                           # noqa: BLE001 -- never the headline's problem
+                line['other_configs'] = [{'key': 'legs', 'error': '%s: %s' % (type(e).__name__, e)}]
+        line['wall_s'] = round(time.perf_counter() - t_start, 1)
+        try:
+            os.makedirs(os.path.dirname(args.detail_out), exist_ok=True)
+            with open(args.detail_out, 'w') as f:
+                f.write(json.dumps(sanitize(line), allow_nan=False, indent=1))
+            line['detail'] = os.path.relpath(args.detail_out, ROOT)
+        except OSError as e:
+            line['detail'] = 'not written: %s' % e
+        real_stdout.write(headline_line(line) + '\n')
+        real_stdout.flush()
     if world > 1:
         dist.destroy_process_group()
 
@@ -296,31 +496,48 @@ def leg_args(args, **over):
     return leg
 
 
+# (key, name, typical wall seconds on a fresh box [MIOpen find + model build dominate], builder of the leg).  Order = priority:
+# the legs run while --leg-budget-s lasts.
+def leg_table(args, rank, local_rank, world, dev):
+    return [
+        ('cfg4_rn101_bs16', 'config 4: ResNet101FPN bf16 inference bs 16', 40,
+         lambda: run_infer(leg_args(args, backbone='ResNet101FPN', batch=16), rank, world, dev)),
+        ('cfg5_rotated_bs8', 'config 5: ResNet50FPN --rotated-bbox bf16 inference bs 8', 42,
+         lambda: run_infer(leg_args(args, rotated_bbox=True), rank, world, dev)),
+        ('bs1_latency_ms', 'batch-1 latency: ResNet50FPN bf16', 12, lambda: run_latency(leg_args(args, batch=1), dev)),
+        # the precision `odtk infer` runs by default (fp16 autocast, as the reference's mixed precision)
+        ('cfg2_fp16', 'config 2 in fp16: ResNet50FPN fp16 inference bs 8', 22,
+         lambda: run_infer(leg_args(args, dtype='fp16'), rank, world, dev)),
+        ('cfg3_train_fp32_2img', 'config 3 (per-GPU share): ResNet50FPN fp32 training, 2 images per GPU', 125,
+         lambda: run_train(leg_args(args, mode='train', batch=2, dtype='fp32'), rank, local_rank, world, dev)),
+        ('cfg3_train_rotated', 'config 3 with --rotated-bbox (per-GPU share): fused rotated target assignment', 47,
+         lambda: run_train(leg_args(args, mode='train', batch=2, dtype='fp32', rotated_bbox=True), rank, local_rank, world, dev)),
+        ('cfg5_rotated_unit', 'config 5 with a unit (sin, cos) head bias', 5,
+         lambda: run_infer(leg_args(args, rotated_bbox=True, unit_rotation=True), rank, world, dev)),
+    ]
+
+
 def other_configs(args, rank, local_rank, world, dev):
     legs = []
-
-    def run(name, fn):
+    t_legs = time.perf_counter()
+    for key, name, typical_s, fn in leg_table(args, rank, local_rank, world, dev):
+        left = args.leg_budget_s - (time.perf_counter() - t_legs)
+        if args.leg_budget_s > 0 and left < typical_s:
+            legs.append({'key': key, 'leg': name, 'skipped': 'leg budget (%.0f s left of --leg-budget-s %.0f, typical cost %d s)'
+                                                            % (max(left, 0), args.leg_budget_s, typical_s)})
+            log('[bench] leg %s: skipped (budget)' % key)
+            continue
         t0 = time.perf_counter()
         try:
             line = fn()
-        except Exception as e:                                # a failing leg is reported, never hidden, and never takes the headline down
+        except Exception as e:                                # noqa: BLE001 -- a failing leg is reported, never hidden, and never takes the headline down
             line = {'error': '%s: %s' % (type(e).__name__, e)}
-        line['leg'] = name
+        line['key'], line['leg'] = key, name
         line['leg_wall_s'] = round(time.perf_counter() - t0, 1)
         legs.append(line)
-        torch.cuda.empty_cache()
-        log('[bench] leg %s: %s' % (name, {k: line.get(k) for k in ('value', 'unit', 'ms_per_step', 'error', 'leg_wall_s')}))
-
-    run('config 4: ResNet101FPN bf16 inference bs 16', lambda: run_infer(leg_args(args, backbone='ResNet101FPN', batch=16), rank, world, dev))
-    run('config 5: ResNet50FPN --rotated-bbox bf16 inference bs 8', lambda: run_infer(leg_args(args, rotated_bbox=True), rank, world, dev))
-    run('config 5 with a unit (sin, cos) head bias', lambda: run_infer(leg_args(args, rotated_bbox=True, unit_rotation=True), rank, world, dev))
-    # the precision `odtk infer` runs by default (fp16 autocast, as the reference's mixed precision)
-    run('config 2 in fp16: ResNet50FPN fp16 inference bs 8', lambda: run_infer(leg_args(args, dtype='fp16'), rank, world, dev))
-    run('config 3 (per-GPU share): ResNet50FPN fp32 training, 2 images per GPU',
-        lambda: run_train(leg_args(args, mode='train', batch=2, dtype='fp32'), rank, local_rank, world, dev))
-    run('config 3 with --rotated-bbox (per-GPU share): fused rotated target assignment',
-        lambda: run_train(leg_args(args, mode='train', batch=2, dtype='fp32', rotated_bbox=True), rank, local_rank, world, dev))
-    run('batch-1 latency: ResNet50FPN bf16', lambda: run_latency(leg_args(args, batch=1), dev))
+        if dev.type == 'cuda':
+            torch.cuda.empty_cache()
+        log('[bench] leg ' + strict_json(pick(line, 'key', 'value', 'unit', 'ms_per_step', 'error', 'leg_wall_s')))
     return legs
 
 
@@ -371,6 +588,37 @@ def run_latency(args, dev):
                                    % (args.backbone, args.dtype, args.height, args.width)}}
 
 
+def run_infer_cpu_plumbing(args, rank, world, dev, model, amp_dtype):
+    """--device cpu: the same launch / sharding / timing bracket / line as the GPU run, with Model.forward on the reference's
+    CPU branch of odtk/box.py (BASELINE configs[0]'s plumbing).  No HIP kernel runs, so there is no roofline: the CPU tests
+    use this to run `bench.py --gpus 2` end to end (gloo)."""
+    from odtk import parallel
+    x = torch.randn(args.batch, 3, args.height, args.width, generator=torch.Generator().manual_seed(rank)).contiguous(
+        memory_format=torch.channels_last)
+
+    def step():
+        with torch.no_grad():
+            return model(x)
+
+    out = None
+    for _ in range(max(args.warmup, 1)):
+        out = step()
+    elapsed, out = parallel.timed_steps(step, args.steps, None, dev)
+    if rank != 0:
+        return None
+    return {'metric': 'images/sec end-to-end (incl. decode+NMS), %s %dpx bs=%d' % (short_name(args.backbone), args.height, args.batch),
+            'value': round(args.batch * world * args.steps / elapsed, 2), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': args.dtype,
+            'data': 'synthetic randn images, random-init weights; CPU plumbing run -- NOT a measurement of the HIP path',
+            'config': {'workload': '%s fp32 inference on the host cores, bs=%d per rank at %dx%d, pure-torch decode x5 + nms'
+                                   % (args.backbone, args.batch, args.height, args.width),
+                       'global_batch': args.batch * world, 'parallelism': 'replicas x%d (no data-path collective)' % world,
+                       'entry': 'Model.forward (eval)', 'postproc': 'odtk/box.py CPU branch', 'device': 'cpu',
+                       'backend': args.backend if world > 1 else None},
+            'roofline': None, 'cpu_baseline': None, 'detections_shape': list(out[0].shape)}
+
+
 def run_infer(args, rank, world, dev):
     from odtk import _C, parallel
     from odtk.model import Model
@@ -386,9 +634,12 @@ def run_infer(args, rank, world, dev):
             bias.zero_()
             bias[:, 5] = 1.0
     model = model.to(dev).to(memory_format=torch.channels_last).eval()
+    on_gpu = dev.type == 'cuda'
     model.fused_postprocess = args.postproc == 'fused'
-    fuse_graph = not args.no_fuse and args.postproc == 'fused'
+    fuse_graph = not args.no_fuse and args.postproc == 'fused' and on_gpu
     model.fused_graph = fuse_graph
+    if not on_gpu:
+        return run_infer_cpu_plumbing(args, rank, world, dev, model, amp_dtype)
 
     g = torch.Generator(device='cpu').manual_seed(rank)
     x = torch.randn(args.batch, 3, args.height, args.width, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
@@ -458,8 +709,10 @@ def run_infer(args, rank, world, dev):
         _C.traffic_count = False
         extra = _C.profile_collect()
         profiled = {}
-        stats = os.path.join(ROOT, 'profiles', 'r04_bench_steady_kernel_stats.csv')
-        if default_workload(args) and os.path.isfile(stats):
+        stats_name = next((n for n in ('r05_bench_steady_kernel_stats.csv', 'r04_bench_steady_kernel_stats.csv')
+                           if os.path.isfile(os.path.join(ROOT, 'profiles', n))), None)
+        stats = os.path.join(ROOT, 'profiles', stats_name or 'none')
+        if default_workload(args) and stats_name:
             import csv
             rows = list(csv.reader(open(stats)))[1:]
             steps_profiled = next((int(r[1]) for r in rows if 'prefilter_scan_kernel' in r[0]), 0)
@@ -481,7 +734,7 @@ def run_infer(args, rank, world, dev):
                 gbs = nbytes / (us * 1e-6) / 1e9
                 entry.update({'launches_per_step': round(calls, 1), 'us_per_step': round(us, 1), 'achieved': round(gbs, 1),
                               'frac': round(gbs / HBM_PEAK_GBS, 4),
-                              'time_source': 'profiles/r04_bench_steady_kernel_stats.csv (rocprofv3 --kernel-trace --stats of this command)'})
+                              'time_source': 'QUOTED, not measured in this run: profiles/%s (rocprofv3 --kernel-trace --stats of this command)' % stats_name})
             epilogue_roofline[k] = entry
         # hipBLASLt launches its own kernels: the library can only put marker packets around the call, and a marker pair
         # includes the dispatch latency on both sides -- NOT comparable with the dispatch-timestamp figures in `kernels`
@@ -524,13 +777,22 @@ def run_infer(args, rank, world, dev):
     roofline = None
     # HBM traffic per launch comes from PMC passes (cannot be collected live next to the timing):
     # profiles/r03_pmc_traffic.json (tools/profile_round.sh), quoted only when the workload matches the profiled one
-    traffic, traffic_src = None, None
-    for name in ('r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
+    # It goes on the line only when the file was taken on THESE kernel sources (hash recorded by tools/pmc_traffic.py);
+    # an older file is named under `quoted` with its mismatch and `roofline.traffic` stays null.
+    traffic, traffic_src, quoted = None, None, None
+    src_hash = kernel_src_hash()
+    for name in ('r05_pmc_traffic.json', 'r04_pmc_traffic.json', 'r03_pmc_traffic.json'):
         try:
             pmc = json.load(open(os.path.join(ROOT, 'profiles', name)))
             key = 'bf16_logits_channels_last' if (model.fused_postprocess and bytes_per_score == 2) else 'fp32_scores_nchw'
             if pmc[key]['scores_per_launch'] == scores_per_batch and (bytes_per_score == 2) == (key[0] == 'b'):
-                traffic, traffic_src = pmc[key]['traffic_bytes'], 'profiles/%s (rocprofv3 --pmc, same workload)' % name
+                same = pmc.get('kernel_src_sha16') == src_hash
+                quoted = {'prefilter_traffic_bytes': pmc[key]['traffic_bytes'],
+                          'ratio_to_algorithmic': round(pmc[key]['traffic_bytes'] / float(bytes_per_score * scores_per_batch), 4),
+                          'source': 'profiles/%s (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, same workload)' % name,
+                          'same_kernel_sources': same}
+                if same:
+                    traffic, traffic_src = pmc[key]['traffic_bytes'], 'quoted: ' + quoted['source']
                 break
         except Exception:
             continue
@@ -540,7 +802,8 @@ def run_infer(args, rank, world, dev):
         roofline = {'kernel': 'prefilter_scan_kernel', 'bound': 'hbm', 'achieved': round(achieved, 1),
                     'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
                     'traffic': traffic, 'traffic_source': traffic_src, 'alg_bytes_per_launch': alg_bytes,
-                    'bytes_per_score': bytes_per_score, 'avg_ms': round(avg_ms, 5), 'launches': n}
+                    'bytes_per_score': bytes_per_score, 'avg_ms': round(avg_ms, 5), 'avg_us': round(avg_ms * 1e3, 2), 'launches': n,
+                    'timing': 'hipEvent pairs on the launch stream inside the timed region (include/odtk_hip.h odtk_profile_*)'}
     kernels = {k: {'avg_us': round(v[0] / v[1] * 1e3, 2), 'launches': v[1]} for k, v in prof.items() if v[1]}
     # the latency-bound launches against their serial-chain lower bounds (one workgroup per image / per segment:
     # the launch time IS the per-image time)
@@ -570,7 +833,7 @@ def run_infer(args, rank, world, dev):
 
     # ---- CPU baseline (rank 0, N=1): the hot path = decode x5 + nms of the reference's CPU algorithm on the
     # captured head tensors; and the whole pipeline (same model on the host cores + that post-processing) ----
-    cpu_baseline = None
+    cpu_baseline, parity = None, None
     if rank == 0 and world == 1 and args.cpu_seconds > 0 and not args.rotated_bbox:
         from oracle import box_oracle      # the checker, timed as the reference's CPU path ("port")
         strides = [x.shape[-1] // c.shape[-1] for c in cls_heads]
@@ -595,12 +858,31 @@ def run_infer(args, rank, world, dev):
             trials[nt] = best_nt
         cores = min(trials, key=trials.get)
         torch.set_num_threads(cores)
-        per_image = []
+        per_image, oracle_out = [], []
         for i in range(args.batch):                          # every captured image once ...
             t0 = time.perf_counter()
-            box_oracle.postprocess([c[i:i + 1] for c in cap_cls], [b[i:i + 1] for b in cap_box], strides, anchors,
-                                   model.threshold, model.top_n, model.nms, model.detections)
+            oracle_out.append(box_oracle.postprocess([c[i:i + 1] for c in cap_cls], [b[i:i + 1] for b in cap_box], strides, anchors,
+                                                     model.threshold, model.top_n, model.nms, model.detections))
             per_image.append(time.perf_counter() - t0)
+        # the checker doing its other job: the HIP op on the SAME captured head tensors (bf16 channels_last logits in place,
+        # sigmoid inside the kernel -- the form the step runs) against what the CPU path just produced, all images
+        try:
+            from odtk import box as hip_box
+            from oracle import box_check
+            got = hip_box.detect(cls_heads, box_heads, strides, {s: a.to(dev) for s, a in anchors.items()}, model.threshold,
+                                 model.top_n, model.nms, model.detections, logits=model.fused_postprocess) \
+                if model.fused_postprocess else hip_box.detect([c.to(dev) for c in cap_cls], [b.to(dev) for b in cap_box], strides,
+                                                               {s: a.to(dev) for s, a in anchors.items()}, model.threshold,
+                                                               model.top_n, model.nms, model.detections)
+            got = [t.float().cpu() for t in got]
+            ref = [torch.cat([o[k] for o in oracle_out]) for k in range(3)]
+            diff = (got[1] - ref[1]).abs()
+            parity = {'images': args.batch, 'scores_bit_exact': bool(torch.equal(got[0], ref[0])),
+                      'classes_bit_exact': bool(torch.equal(got[2], ref[2])), 'max_box_abs_diff': float(diff.max()),
+                      'box_coords_beyond_1e-4': int((diff > box_check.NORTH_STAR_ATOL).sum()), 'box_coords': int(diff.numel()),
+                      'checker': 'oracle/box_oracle.py (restatement of reference odtk/box.py, pinned) on the captured heads'}
+        except Exception as e:                               # noqa: BLE001 -- the check reports, it never takes the line down
+            parity = {'error': '%s: %s' % (type(e).__name__, e)}
         best = min(per_image)
         for _ in range(4):                                   # ... and image 0 four more times: best of 5
             t0 = time.perf_counter()
@@ -669,6 +951,8 @@ def run_infer(args, rank, world, dev):
                        'graph': 'BN folded into conv weights + HIP bias/skip/ReLU epilogue + 1x1 convs as fused GEMMs' if fuse_graph
                                 else 'eager nn.Module under autocast'},
             'roofline': roofline, 'latency_bound': latency_bound, 'conv_roofline': conv_roofline, 'kernels': kernels,
+            'postproc_us_per_step': round(sum(kernels[k]['avg_us'] * kernels[k]['launches'] for k in post if k in kernels) / max(n, 1), 2),
+            'quoted': quoted, 'parity': parity, 'kernel_src_sha16': src_hash,
             'epilogue_roofline': epilogue_roofline, 'marker_timed': marker_timed,
             'candidates_per_image_per_level': candidates,
             'spec_candidates_per_image_per_level': SPEC_CANDIDATES if (args.height, args.width) == (800, 1280) and not args.rotated_bbox else None,

@@ -54,6 +54,11 @@ def main():
         open(a.csv, 'w').write('\n'.join(lines) + '\n')
     if a.json and a.key and 'FETCH_SIZE' in got and 'WRITE_SIZE' in got:
         doc = json.load(open(a.json))
+        import os
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import bench
+        doc['kernel_src_sha16'] = bench.kernel_src_hash()      # bench.py quotes this file only for these kernel sources
         traffic = int(round((2.0 * got['FETCH_SIZE'] + got['WRITE_SIZE']) * 1024))
         doc[a.key] = {'scores_per_launch': a.scores, 'fetch_kb': round(got['FETCH_SIZE'], 1), 'write_kb': round(got['WRITE_SIZE'], 1),
                       'traffic_bytes': traffic, 'algorithmic_bytes': a.scores * a.bytes_per_score}
