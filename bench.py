@@ -125,6 +125,14 @@ def run_train(args, rank, local_rank, world, dev):
     torch.manual_seed(0)
     model = Model(backbones=args.backbone, classes=80, rotated_bbox=args.rotated_bbox)
     model.initialize(None)
+    if args.rotated_bbox and args.unit_rotation:
+        # the reference's init puts the -4.6 class prior on all six box outputs (model.py:121-122): the box loss starts at ~28 and
+        # SGD diverges within a few dozen steps in the reference's own arithmetic (tools/rotated_train_probe.py,
+        # profiles/r05_rotated_train_trajectory.txt); (0, 0, 0, 0, sin 0, cos 1) is what a trained rotated model emits
+        with torch.no_grad():
+            bias = model.box_head[-1].bias.view(model.num_anchors, 6)
+            bias.zero_()
+            bias[:, 5] = 1.0
     per_gpu = args.batch
     amp_dtype = {'bf16': torch.bfloat16, 'fp16': torch.float16, 'fp32': None}[args.dtype]
     on_gpu = dev.type == 'cuda'

@@ -133,6 +133,7 @@ def test_full_size_saturated_and_empty():
 # ------------------------------------------------------------------------------------------------
 # (1) the oracle at full size
 # ------------------------------------------------------------------------------------------------
+MAX_PROVEN_PER_CONFIGURATION = 4   # a decode coordinate beyond 1e-4 reappears once more in the detections when NMS keeps that box
 EXP_ROUNDING_CASES = {}        # test id -> coordinates beyond 1e-4 that were proven to be the reference's exp rounding
 
 
@@ -145,6 +146,10 @@ def _boxes_close(got, ref, proof, what, tally):
     exact, truth = proof
     n = box_check.check_boxes(got, ref, exact, truth, what)
     EXP_ROUNDING_CASES[tally] = EXP_ROUNDING_CASES.get(tally, 0) + n
+    # the proof is an escape for the reference's own exp rounding, seen 0-1 times per configuration (decode + detections of
+    # 8-16 images, ~10^5 coordinates): bounded, so that a regression cannot hide behind it
+    assert EXP_ROUNDING_CASES[tally] <= MAX_PROVEN_PER_CONFIGURATION, \
+        '%s: %d coordinates beyond 1e-4 needed the exp-rounding proof (bound %d)' % (tally, EXP_ROUNDING_CASES[tally], MAX_PROVEN_PER_CONFIGURATION)
     return n
 
 
@@ -197,9 +202,10 @@ def test_full_size_vs_oracle(kind, dtype, logits, channels_last, batch):
 
 def test_full_size_rotated_vs_oracle():
     """Config 5 at full size: A = 27, 6 box parameters, 46.07 M scores per image, bs 8.  The C restatement
-    (pinned to the reference's decode_rotate.cu lambda / nms_iou.cu device code) checks images 0 and 7 of
-    the batch -- a subset because one image costs the single-threaded C oracle seconds; the HIP launch is
-    the full bs-8 one."""
+    (pinned to the reference's decode_rotate.cu lambda / nms_iou.cu device code) checks EVERY image of the batch: one image
+    costs the single-threaded C oracle seconds, so the eight run on eight host threads (ctypes releases the GIL around the
+    C calls); the HIP launch is the full bs-8 one."""
+    from concurrent.futures import ThreadPoolExecutor
     top_n, thr, nms_thr, ndet, batch = 1000, 0.05, 0.5, 100, 8
     cls, dl = full_heads('sparse', torch.bfloat16, True, True, batch=batch, seed=131, num_anchors=27, nb=6)
     angles = [-np.pi / 6, 0, np.pi / 6]
@@ -209,15 +215,22 @@ def test_full_size_rotated_vs_oracle():
     det = box.detect(cls, dl, STRIDES, anchors, thr, top_n, nms_thr, ndet, rotated=True, logits=True)
     dec = [t.cpu().numpy() for t in dec]
     det = [t.cpu().numpy() for t in det]
-    for b in (0, batch - 1):
-        per = [c_oracle.decode(c[b:b + 1].sigmoid().float().contiguous().cpu().numpy(),
-                               d[b:b + 1].float().contiguous().cpu().numpy(), st, thr, top_n, anchors[st][0].numpy(),
-                               rotated=True) for c, d, st in zip(cls, dl, STRIDES)]
+    # what the reference's op receives, per image: fp32 NCHW post-sigmoid scores, fp32 deltas (made on the GPU, moved once)
+    inputs = [[(c[b:b + 1].sigmoid().float().contiguous().cpu().numpy(), d[b:b + 1].float().contiguous().cpu().numpy())
+               for c, d in zip(cls, dl)] for b in range(batch)]
+    c_oracle.library()
+
+    def oracle_image(b):
+        per = [c_oracle.decode(c, d, st, thr, top_n, anchors[st][0].numpy(), rotated=True) for (c, d), st in zip(inputs[b], STRIDES)]
         ref = [np.concatenate(t, 1) for t in zip(*per)]
+        return ref, c_oracle.nms(ref[0], ref[1], ref[2], nms_thr, ndet, rotated=True)
+
+    with ThreadPoolExecutor(max_workers=batch) as pool:
+        refs = list(pool.map(oracle_image, range(batch)))
+    for b, (ref, ref_nms) in enumerate(refs):
         assert np.array_equal(dec[3][b].astype(np.int64), ref[3][0]), 'image %d: flat indices' % b
         for k, name in ((0, 'scores'), (1, 'boxes'), (2, 'classes')):     # the C oracle rounds exp() like the kernel: bits
             assert np.array_equal(dec[k][b].view(np.uint32), ref[k][0].view(np.uint32)), 'image %d: %s' % (b, name)
-        ref_nms = c_oracle.nms(ref[0], ref[1], ref[2], nms_thr, ndet, rotated=True)
         for k, name in ((0, 'scores'), (1, 'boxes'), (2, 'classes')):
             assert np.array_equal(det[k][b].view(np.uint32), ref_nms[k][0].view(np.uint32)), 'image %d: nms %s' % (b, name)
         assert int((ref_nms[0] > 0).sum()) > 20

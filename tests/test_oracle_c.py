@@ -107,8 +107,12 @@ def test_box_acceptance_helper_proves_exp_rounding():
     anchors = {s: box.generate_anchors(s, RATIOS, SCALES) for s in strides}
     s, b, c, exact, truth, cand = box_check.reference_with_proof(cls, dl, strides, anchors, 0.05, 1000, 0.5, 100)
     assert int((s > 0).sum()) == 100
-    n_cand = box_check.check_boxes(cand['exact'], cand['boxes'], cand['exact'], cand['truth'], 'candidates')
-    n_kept = box_check.check_boxes(exact, b, exact, truth, 'kept')
+    # (2560-px coordinates make the case common on purpose: the per-call bound of the escape is lifted to exercise the proof)
+    n_cand = box_check.check_boxes(cand['exact'], cand['boxes'], cand['exact'], cand['truth'], 'candidates', max_proven=10 ** 9)
+    n_kept = box_check.check_boxes(exact, b, exact, truth, 'kept', max_proven=10 ** 9)
+    if n_cand > box_check.MAX_PROVEN_PER_CALL:                    # the default bound refuses a blanket use of the proof
+        with pytest.raises(AssertionError, match='more than the 2'):
+            box_check.check_boxes(cand['exact'], cand['boxes'], cand['exact'], cand['truth'], 'candidates')
     print('coordinates beyond 1e-4 explained as exp rounding: %d of %d candidates, %d of %d kept' % (
         n_cand, cand['boxes'].numel(), n_kept, b.numel()))
     assert n_cand > 0                                             # the case exists at this image size ...
@@ -120,7 +124,7 @@ def test_box_acceptance_helper_proves_exp_rounding():
     i = int((cand['scores'][0] > 0).nonzero()[0])
     wrong[0, i, 2] += 2.5e-4
     with pytest.raises(AssertionError):
-        box_check.check_boxes(wrong, cand['boxes'], None, None, 'no proof')
+        box_check.check_boxes(wrong, cand['boxes'], None, None, 'no proof', max_proven=10 ** 9)
     # ... and not with them either: it is not the restatement's value
     with pytest.raises(AssertionError):
-        box_check.check_boxes(wrong, cand['boxes'], cand['exact'], cand['truth'], 'wrong')
+        box_check.check_boxes(wrong, cand['boxes'], cand['exact'], cand['truth'], 'wrong', max_proven=10 ** 9)

@@ -1,6 +1,17 @@
 #!/usr/bin/env python
-"""Rotated training: the fused path (one target launch + fused loss) against the reference-style path (per-image
-snap_to_anchors_rotated + torch losses) on the same model and batches; loss trajectory of a few SGD steps."""
+"""Rotated training, settled: does the loss go non-finite because of the reference's initialisation
+(model.py:121-122 puts the -4.6 class prior on all six box outputs: box loss starts at ~28) or because of a kernel?
+
+Two replicas of the same seeded model take the same SGD steps on the same batches: one through the fused path (one HIP
+target launch + the fused focal / smooth-L1 kernel), one through the reference-style path (per-image
+snap_to_anchors_rotated + torch losses).  Printed per step: both losses of both replicas.  Then the same again with the box
+head's bias at (0, 0, 0, 0, sin = 0, cos = 1) -- what `bench.py --unit-rotation` uses -- instead of the prior.
+
+    python tools/rotated_train_probe.py [--steps 60] [--lr 0.001] [--backbone ResNet18FPN]
+"""
+import argparse
+import copy
+import math
 import os
 import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -9,26 +20,61 @@ import torch
 from odtk import train as T
 from odtk.model import Model
 
-torch.manual_seed(0)
-m = Model('ResNet18FPN', classes=20, rotated_bbox=True)
-m.initialize(None)
-m = m.cuda().to(memory_format=torch.channels_last).train()
-src = T.SyntheticBatches(2, 384, 512, classes=20, max_boxes=12, seed=3, device='cuda', rotated=True)
-data, target = src.batch()
-data = data.contiguous(memory_format=torch.channels_last)
-for fused in (True, False):
-    m.fused_loss = fused
-    m.zero_grad(set_to_none=True)
-    c, b = m([data, target])
-    (c + b).backward()
-    gn = sum(float(p.grad.float().pow(2).sum()) for p in m.parameters() if p.grad is not None) ** 0.5
-    print('fused' if fused else 'torch', 'cls %.6f box %.6f grad-norm %.6f' % (float(c), float(b), gn), flush=True)
-m.fused_loss = True
-opt = torch.optim.SGD(m.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
-for step in range(12):
-    d, t = src.batch()
-    opt.zero_grad(set_to_none=True)
-    c, b = m([d.contiguous(memory_format=torch.channels_last), t])
-    (c + b).backward()
-    opt.step()
-    print('step %d cls %.5f box %.5f' % (step, float(c), float(b)), flush=True)
+
+def unit_rotation_bias(model):
+    with torch.no_grad():
+        bias = model.box_head[-1].bias.view(model.num_anchors, 6)
+        bias.zero_()
+        bias[:, 5] = 1.0
+
+
+def trajectory(backbone, steps, lr, unit, height=384, width=512, classes=20, seed=0, momentum=0.9):
+    torch.manual_seed(seed)
+    base = Model(backbone, classes=classes, rotated_bbox=True)
+    base.initialize(None)
+    if unit:
+        unit_rotation_bias(base)
+    src = T.SyntheticBatches(2, height, width, classes=classes, max_boxes=12, seed=3, device='cuda', rotated=True)
+    batches = [src.batch() for _ in range(4)]
+    rows = {}
+    for fused in (True, False):
+        m = copy.deepcopy(base).cuda().to(memory_format=torch.channels_last).train()
+        m.fused_loss = fused
+        opt = torch.optim.SGD(m.parameters(), lr=lr, momentum=momentum, weight_decay=1e-4)
+        out = []
+        for step in range(steps):
+            d, t = batches[step % len(batches)]
+            opt.zero_grad(set_to_none=True)
+            c, b = m([d.contiguous(memory_format=torch.channels_last), t])
+            (c + b).backward()
+            opt.step()
+            out.append((float(c.detach()), float(b.detach())))
+            if not math.isfinite(out[-1][0] + out[-1][1]):
+                break
+        rows['fused' if fused else 'torch'] = out
+    return rows
+
+
+def first_nonfinite(rows):
+    return next((i for i, (c, b) in enumerate(rows) if not math.isfinite(c + b)), None)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--steps', type=int, default=60)
+    ap.add_argument('--lr', type=float, default=0.001)      # what bench.py's leg runs at (0.01 x the 0.1 warm-up factor)
+    ap.add_argument('--backbone', default='ResNet18FPN')
+    a = ap.parse_args()
+    for unit in (False, True):
+        rows = trajectory(a.backbone, a.steps, a.lr, unit)
+        print('== %s, lr %g, box-head bias: %s ==' % (a.backbone, a.lr, 'unit rotation (0,0,0,0,0,1)' if unit else "reference prior -4.6 (model.py:121-122)"))
+        print('step   fused: focal      box   |   torch: focal      box')
+        for i in range(max(len(rows['fused']), len(rows['torch']))):
+            f = rows['fused'][i] if i < len(rows['fused']) else (float('nan'),) * 2
+            t = rows['torch'][i] if i < len(rows['torch']) else (float('nan'),) * 2
+            print('%4d   %12.5f %9.4f   |   %12.5f %9.4f' % (i, f[0], f[1], t[0], t[1]))
+        print('first non-finite step: fused %s, torch %s' % (first_nonfinite(rows['fused']), first_nonfinite(rows['torch'])), flush=True)
+
+
+if __name__ == '__main__':
+    main()
