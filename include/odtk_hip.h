@@ -64,6 +64,11 @@ extern "C" {
                                       /* csrc/cuda/nms_iou.cu:192; that is the default here too)        */
 
 const char *odtk_version(void);
+/* ABI guard.  sizeof() of a struct type of this header AS THE LIBRARY WAS COMPILED: which = 0 odtk_level_t,
+ * 1 odtk_snap_level_t, 2 odtk_snap_rot_level_t, 3 odtk_loss_level_t; -1 for any other value.  A binding compiled (or
+ * mirrored) against another revision of this header would pass level arrays of the wrong stride: both bindings compare
+ * their own sizeof with this at load time and refuse to load on a mismatch (odtk/_C.py, csrc/odtk_binding.cpp). */
+int odtk_abi_struct_size(int which);
 /* hipGetErrorString of the last HIP failure seen by this thread ("" if none). */
 const char *odtk_last_hip_error(void);
 
@@ -385,8 +390,9 @@ int odtk_retina_loss_levels_backward(int n_levels, const odtk_loss_level_t *leve
  * measurably NOT free for the ~110 epilogue launches (about 10 % of an 8.7 ms step), so time those
  * only in a separate pass. */
 int odtk_profile_enable(int on);
-/* Debug: device buffer (>= 64 KiB, zero-filled) that select_decode / nms workgroups stamp with wall_clock64()
- * (100 MHz) at their phase boundaries; NULL (default) disables.  Not for production use. */
+/* Debug: device buffer (>= 128 KiB, zero-filled) that select_decode / nms workgroups stamp with wall_clock64()
+ * (100 MHz) at their phase boundaries -- coarse stamps in the first 64 KiB, select_decode's per-segment fine-phase stamps
+ * (16 words per segment, up to 512 segments) in the second; NULL (default) disables.  Not for production use. */
 int odtk_debug_set_trace(void *device_buffer);
 /* Debug / tuning: launch shape of the loss kernels for one form (which = 0: forward with atomics, 1: backward, 2: forward
  * through a workspace) and head width (fp32_heads = 0: bf16 / fp16, 1: fp32): workgroup size (multiple of 64, <= 1024),
@@ -402,8 +408,9 @@ int odtk_debug_loss_tuning(int which, int fp32_heads, int threads, int blocks_pe
  * and every other gamma as with 0.  Results agree to ~1e-8 (sums) / ~1e-6 of the largest gradient.  The default is
  * ODTK_LOSS_FORM_DEFAULT; process-wide, read once per launch.  2, 3, 4, 6, 7: TIMING ABLATIONS of form 1 for the fp32
  * forward (no depth gather / no arithmetic / no index arithmetic and no depth gather / no box-delta walk / no logit walk;
- * other launches as form 1) -- their sums are wrong on purpose, tools/loss_form_probe.py is their only user.  Returns
- * ODTK_ERR_INVALID for any other value. */
+ * other launches as form 1) -- their sums are wrong on purpose, tools/loss_form_probe.py is their only user, and they
+ * exist only in a library built with -DODTK_LOSS_ABLATIONS (`make ablations` -> build_ablate/): the shipped library
+ * accepts 0 and 1.  Returns ODTK_ERR_INVALID for any other value. */
 #define ODTK_LOSS_FORM_DEFAULT 1
 int odtk_debug_loss_form(int form);
 int odtk_profile_collect(double total_ms[ODTK_KERNEL_COUNT], int launches[ODTK_KERNEL_COUNT]);

@@ -180,6 +180,13 @@ struct Engine {};   // csrc/engine.h: the TensorRT engine class -- not available
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   namespace py = pybind11;
   m.doc() = "odtk._C on MI355X: decode / nms / iou of NVIDIA/retinanet-examples over libodtk_hip.so";
+  // ABI guard: this module was compiled against ONE revision of include/odtk_hip.h; the library it found at load time must
+  // have been compiled against the same struct layouts (a stale module would pass level arrays of the wrong stride)
+  if (odtk_abi_struct_size(0) != static_cast<int>(sizeof(odtk_level_t)) ||
+      odtk_abi_struct_size(1) != static_cast<int>(sizeof(odtk_snap_level_t)) ||
+      odtk_abi_struct_size(2) != static_cast<int>(sizeof(odtk_snap_rot_level_t)))
+    throw py::import_error("odtk._C_ext was compiled against another revision of include/odtk_hip.h than libodtk_hip.so "
+                           "(struct sizes differ): rebuild it -- make -C retinanet-examples_amd/csrc");
   py::class_<Engine>(m, "Engine")
       .def(py::init([](py::args, py::kwargs) -> Engine * {
         throw std::runtime_error("odtk._C.Engine: the TensorRT engine path is not available on MI355X");

@@ -599,6 +599,7 @@ unsigned retina_loss_fill(odtk::LossArgs &la, int which, const void *cls, const 
 template <typename T, bool kBackward>
 void retina_loss_dispatch(const odtk::LossLevelsArgs &la, unsigned total, const LossTuning &t, hipStream_t stream) {
   const dim3 grid(total), block(t.threads);
+#ifdef ODTK_LOSS_ABLATIONS   // build flag of tools/loss_form_probe.py only (make ablations): never in the shipped library
   if constexpr (std::is_same_v<T, odtk::F32> && !kBackward) {
     // timing ablations of form 1 (wrong results on purpose; tools/loss_form_probe.py): fp32 forward, four vectors per trip
     if (t.form == 2) { timed_launch(ODTK_KERNEL_LOSS, odtk::retina_loss_kernel<T, false, 4, 2>, grid, block, 0, stream, la); return; }
@@ -607,6 +608,7 @@ void retina_loss_dispatch(const odtk::LossLevelsArgs &la, unsigned total, const 
     if (t.form == 6) { timed_launch(ODTK_KERNEL_LOSS, odtk::retina_loss_kernel<T, false, 4, 6>, grid, block, 0, stream, la); return; }
     if (t.form == 7) { timed_launch(ODTK_KERNEL_LOSS, odtk::retina_loss_kernel<T, false, 4, 7>, grid, block, 0, stream, la); return; }
   }
+#endif
   if (t.form) {
     switch (t.unroll) {
       case 1: timed_launch(ODTK_KERNEL_LOSS, odtk::retina_loss_kernel<T, kBackward, 1, 1>, grid, block, 0, stream, la); break;
@@ -709,6 +711,16 @@ int decode_single(bool rotated, int batch, const void *const *inputs, void *cons
 extern "C" {
 
 const char *odtk_version(void) { return "odtk-hip 0.1 (gfx950)"; }
+
+int odtk_abi_struct_size(int which) {
+  switch (which) {
+    case 0: return static_cast<int>(sizeof(odtk_level_t));
+    case 1: return static_cast<int>(sizeof(odtk_snap_level_t));
+    case 2: return static_cast<int>(sizeof(odtk_snap_rot_level_t));
+    case 3: return static_cast<int>(sizeof(odtk_loss_level_t));
+    default: return -1;
+  }
+}
 const char *odtk_last_hip_error(void) { return g_last_error; }
 
 int odtk_debug_set_trace(void *device_buffer) {
@@ -726,7 +738,11 @@ int odtk_debug_loss_tuning(int which, int fp32_heads, int threads, int blocks_pe
 }
 
 int odtk_debug_loss_form(int form) {
+#ifdef ODTK_LOSS_ABLATIONS
   if (form < 0 || form > 7 || form == 5) return ODTK_ERR_INVALID;
+#else
+  if (form != 0 && form != 1) return ODTK_ERR_INVALID;   // the ablation forms (wrong sums on purpose) are not compiled in
+#endif
   std::lock_guard<std::mutex> lock(g_loss_tuning_mu);
   g_loss_form = form;
   return ODTK_OK;

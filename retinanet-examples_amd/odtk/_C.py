@@ -66,6 +66,7 @@ class Level(ctypes.Structure):
 
 _SIGNATURES = {
     'odtk_version': (ctypes.c_char_p, []),
+    'odtk_abi_struct_size': (ctypes.c_int, [ctypes.c_int]),
     'odtk_last_hip_error': (ctypes.c_char_p, []),
     'odtk_decode': (ctypes.c_int, [ctypes.c_int, _vpp, _vpp, _sz, _sz, _sz, _sz, _sz, _fp, _sz, ctypes.c_float,
                                    ctypes.c_int, _vp, _sz, _vp]),
@@ -146,6 +147,12 @@ def library():
             fn = getattr(lib, name)      # AttributeError if the ABI lost a symbol
             fn.restype = res
             fn.argtypes = args
+        # ABI guard: the ctypes mirrors below must have the layout the library was compiled with (include/odtk_hip.h)
+        for which, mirror in enumerate((Level, SnapLevel, SnapRotLevel, LossLevel)):
+            if lib.odtk_abi_struct_size(which) != ctypes.sizeof(mirror):
+                raise ImportError('odtk._C: %s was built from another revision of include/odtk_hip.h (sizeof struct %d: library %d, '
+                                  'binding %d) -- rebuild it (make -C retinanet-examples_amd/csrc)'
+                                  % (_LIB_PATH, which, lib.odtk_abi_struct_size(which), ctypes.sizeof(mirror)))
         _lib = lib
         # Debug knob (tools/loss_probe.py): ODTK_LOSS_TUNING="fwd32:threads,blocks_per_cu,unroll,box_blocks;bwd16:...;ws32:..."
         # (fwd = forward with atomics, bwd, ws = forward through a workspace) overrides the built-in launch shapes
@@ -154,8 +161,12 @@ def library():
             side = side.strip()
             _check(lib.odtk_debug_loss_tuning({'fwd': 0, 'bwd': 1, 'ws': 2}[side[:-2]], int(side.endswith('32')),
                                               *(int(v) for v in vals.split(','))), 'ODTK_LOSS_TUNING')
-        # ODTK_LOSS_FORM=0|1: arithmetic form of the gamma = 2 classification walk (include/odtk_hip.h: odtk_debug_loss_form)
+        # ODTK_LOSS_FORM=0|1: arithmetic form of the gamma = 2 classification walk (include/odtk_hip.h: odtk_debug_loss_form).
+        # Said out loud: a process-wide numerical switch must not be silent.  (The ablation forms 2..7 -- wrong sums on purpose --
+        # exist only in a -DODTK_LOSS_ABLATIONS build; the shipped library refuses them here.)
         if os.environ.get('ODTK_LOSS_FORM', '') != '':
+            import warnings
+            warnings.warn('odtk._C: ODTK_LOSS_FORM=%s overrides the loss kernels\' arithmetic form for this process' % os.environ['ODTK_LOSS_FORM'])
             _check(lib.odtk_debug_loss_form(int(os.environ['ODTK_LOSS_FORM'])), 'ODTK_LOSS_FORM')
     return _lib
 

@@ -148,7 +148,7 @@ class FusedRetinaNet(nn.Module):
         self.level_streams = True                                       # small pyramid levels on side HIP streams
         self._streams = None
         self.tower_plan = 0
-        self._graphs = {}                                               # input geometry -> (hipGraph, static input, outputs)
+        self._graphs = {}                                               # input geometry + bias state -> (hipGraph, static input, outputs, tables kept alive)
         self._thresholds = {}                                           # score threshold -> the prefilter's table for cls_head[-1].bias
         self.max_graphs = 8
 
@@ -247,8 +247,9 @@ class FusedRetinaNet(nn.Module):
         capture and therefore owned by the graph; nothing cached outside it is referenced (odtk/_C.py:_workspace).  The
         returned tensors are copies (the graph's own output buffers are overwritten by the next replay)."""
         m = self.model[0]                                                # (post-processing parameters are baked into the launches)
+        bias = self.cls_head[-1].bias                                    # its state is baked in too: the prefilter's threshold table
         key = (tuple(x.shape), x.dtype, x.device, x.is_contiguous(memory_format=torch.channels_last),
-               m.threshold, m.top_n, m.nms, m.detections, self.level_streams, self.tower_plan)
+               m.threshold, m.top_n, m.nms, m.detections, self.level_streams, self.tower_plan, bias.data_ptr(), bias._version)
         entry = self._graphs.get(key)
         if entry is None:
             static_x = torch.empty_like(x)
@@ -266,8 +267,11 @@ class FusedRetinaNet(nn.Module):
                 out = self.forward(static_x)
             while len(self._graphs) >= self.max_graphs:                 # a graph pins its activations: keep a handful of geometries
                 self._graphs.pop(next(iter(self._graphs)))              # (oldest first: dicts keep insertion order)
-            entry = self._graphs[key] = (graph, static_x, out)
-        graph, static_x, out = entry
+            # the capture baked the address of the threshold table its warm-up passes made into the prefilter's launch: the
+            # graph entry co-owns that table, so a later `_thresholds.clear()` (new threshold, bias updated in place) cannot
+            # free memory a cached graph still reads
+            entry = self._graphs[key] = (graph, static_x, out, tuple(self._thresholds.values()))
+        graph, static_x, out = entry[:3]
         static_x.copy_(x)
         graph.replay()
         return tuple(o.clone() for o in out)

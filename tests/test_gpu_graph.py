@@ -106,6 +106,24 @@ def test_model_forward_as_one_graph():
         # new input values through the same graph
         x3 = torch.randn_like(x)
         assert all(torch.equal(a, b) for a, b in zip(call(x3, False), call(x3, True)))
+        # the prefilter's threshold table is baked into a capture: a graph co-owns the table it captured, so another score
+        # threshold (which drops the engine's own reference to the old table) leaves the first graph replayable ...
+        model.threshold = 0.3
+        at_03 = [t.clone() for t in call(x, False)]
+        assert all(torch.equal(a, b) for a, b in zip(at_03, call(x, True)))
+        filler = [torch.full((724,), float('nan'), device='cuda') for _ in range(64)]   # would land in a freed 2.9 KB table
+        model.threshold = 0.05
+        assert all(torch.equal(a, b) for a, b in zip(eager, call(x, True)))
+        del filler
+        # ... and the ENGINE's bias updated in place is part of the graph key: no replay with stale thresholds
+        n_graphs = len(engine._graphs)
+        with torch.no_grad():
+            engine.cls_head[-1].bias.add_(0.5)
+        fresh = [t.clone() for t in engine.forward(x)]
+        assert not torch.equal(fresh[0], eager[0])
+        assert all(torch.equal(a, b) for a, b in zip(fresh, engine.replay(x))) and len(engine._graphs) == n_graphs + 1
+        with torch.no_grad():
+            engine.cls_head[-1].bias.sub_(0.5)
         # weights change: engine re-folded, its graphs dropped, a new capture happens (capture after destroy)
         with torch.no_grad():
             model.cls_head[-1].bias.add_(0.25)

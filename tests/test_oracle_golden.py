@@ -113,3 +113,41 @@ def test_truediv_shim_does_not_leak():
     with ref_loader.legacy_int_division():
         pass
     assert (torch.tensor([7]) / 2).item() == 3.5
+
+
+@needs_ref
+def test_port_costs_what_the_reference_costs_on_one_full_image():
+    """bench.py's `cpu_baseline.kind` is "port": the GPU box has no /root/reference, so the restatement is what gets timed
+    there.  Here, where the reference exists, both process ONE 800x1280 RN50FPN image (sparse-realistic scores, SURVEY 8d:
+    ~31 k candidates) -- same outputs bit for bit, and the port's time within 10 % of the reference's own module (or
+    faster-never: a port that beat the reference by more would flatter nothing, but would not be "its" time either)."""
+    import time
+    cls, box, strides = synthetic.pyramid(1, 9, 80, 800, 1280, 'sparse', 7)
+    anchors = {s: box_oracle.generate_anchors(s, RATIOS, SCALES) for s in strides}
+
+    def run_ref():
+        dec = [ref_loader.ref_decode(c, b, s, 0.05, 1000, anchors[s]) for c, b, s in zip(cls, box, strides)]
+        return ref_loader.ref_nms(*[torch.cat(t, 1) for t in zip(*dec)], 0.5, 100)
+
+    def run_port():
+        return box_oracle.postprocess(cls, box, strides, anchors, 0.05, 1000, 0.5, 100)
+
+    def best_of(fn, n=5):
+        out, best = None, float('inf')
+        for _ in range(n):
+            t0 = time.perf_counter()
+            out = fn()
+            best = min(best, time.perf_counter() - t0)
+        return out, best
+
+    run_ref(), run_port()                                        # warm both
+    for attempt in range(3):                                     # a busy host can spoil one round of timings, not three
+        (ref, t_ref), (port, t_port) = best_of(run_ref), best_of(run_port)
+        for r, o in zip(ref, port):
+            assert _bit_equal(r, o)
+        assert int((port[0] > 0).sum()) == 100
+        print('one 800x1280 image, decode x5 + nms: reference odtk/box.py %.1f ms, port %.1f ms (ratio %.3f)' % (
+            t_ref * 1e3, t_port * 1e3, t_port / t_ref))
+        if 0.9 <= t_port / t_ref <= 1.1:
+            return
+    raise AssertionError('port %.1f ms vs reference %.1f ms: not within 10 %%' % (t_port * 1e3, t_ref * 1e3))

@@ -157,6 +157,11 @@ def main():
                    alg / min(row[0], row[2]) / 1e3 / 8000, alg / min(row[1], row[3]) / 1e3 / 8000))
         del sets
     # ---- 3. where the fp32 forward's time goes: ablations of form 1 (wrong sums on purpose) and its launch shapes ----
+    # (the ablation forms exist only in a -DODTK_LOSS_ABLATIONS library:  make -C retinanet-examples_amd/csrc ablations, then
+    #  ODTK_HIP_LIBRARY=build_ablate/libodtk_hip.so python tools/loss_form_probe.py ...)
+    if _C.library().odtk_debug_loss_form(2) != 0:
+        say('ablations skipped: this library was built without -DODTK_LOSS_ABLATIONS')
+        return
     sets = [make_set(torch.float32, 10 + i, True) for i in range(3)]
     fwd = lambda s: _C.retina_loss_levels_forward(s[0], s[1], s[2], s[3], 0.25, 2.0, 0.11)
     for form, what in ((1, 'form 1'), (2, 'no depth gather'), (3, 'no arithmetic'), (4, 'no index arithmetic, no depth gather'),
