@@ -28,30 +28,41 @@ def unit_rotation_bias(model):
         bias[:, 5] = 1.0
 
 
-def trajectory(backbone, steps, lr, unit, height=384, width=512, classes=20, seed=0, momentum=0.9):
+def trajectory(backbone, steps, lr, unit, height=384, width=512, classes=20, seed=0, momentum=0.9, bench_like=False):
     torch.manual_seed(seed)
     base = Model(backbone, classes=classes, rotated_bbox=True)
     base.initialize(None)
     if unit:
         unit_rotation_bias(base)
-    src = T.SyntheticBatches(2, height, width, classes=classes, max_boxes=12, seed=3, device='cuda', rotated=True)
+    src = T.SyntheticBatches(2, height, width, classes=classes, max_boxes=20 if bench_like else 12, seed=0 if bench_like else 3,
+                             device='cuda', rotated=True)
     batches = [src.batch() for _ in range(4)]
     rows = {}
     for fused in (True, False):
-        m = copy.deepcopy(base).cuda().to(memory_format=torch.channels_last).train()
+        if bench_like:
+            # exactly bench.py's leg: frozen BN, lr 0.01 behind the reference's 1000-step warm-up (x 0.1 at step 0), fp32
+            m, net, opt, sched = T.prepare(copy.deepcopy(base), torch.device('cuda'), lr=0.01, world=1, rank=0, warmup=1000)
+        else:
+            m = copy.deepcopy(base).cuda().to(memory_format=torch.channels_last).train()
+            opt = torch.optim.SGD(m.parameters(), lr=lr, momentum=momentum, weight_decay=1e-4)
+            sched = None
         m.fused_loss = fused
-        opt = torch.optim.SGD(m.parameters(), lr=lr, momentum=momentum, weight_decay=1e-4)
         out = []
         for step in range(steps):
             d, t = batches[step % len(batches)]
-            opt.zero_grad(set_to_none=True)
-            c, b = m([d.contiguous(memory_format=torch.channels_last), t])
-            (c + b).backward()
-            opt.step()
+            if bench_like:
+                c, b = T.train_step(m, opt, sched, None, d.contiguous(memory_format=torch.channels_last), t, None)
+            else:
+                opt.zero_grad(set_to_none=True)
+                c, b = m([d.contiguous(memory_format=torch.channels_last), t])
+                (c + b).backward()
+                opt.step()
             out.append((float(c.detach()), float(b.detach())))
             if not math.isfinite(out[-1][0] + out[-1][1]):
                 break
         rows['fused' if fused else 'torch'] = out
+        del m, opt
+        torch.cuda.empty_cache()
     return rows
 
 
@@ -64,10 +75,16 @@ def main():
     ap.add_argument('--steps', type=int, default=60)
     ap.add_argument('--lr', type=float, default=0.001)      # what bench.py's leg runs at (0.01 x the 0.1 warm-up factor)
     ap.add_argument('--backbone', default='ResNet18FPN')
+    ap.add_argument('--height', type=int, default=384)
+    ap.add_argument('--width', type=int, default=512)
+    ap.add_argument('--classes', type=int, default=20)
+    ap.add_argument('--bench-like', action='store_true', help="bench.py's rotated training leg: ResNet50FPN, 800x1280, 80 classes")
     a = ap.parse_args()
+    if a.bench_like:
+        a.backbone, a.height, a.width, a.classes = 'ResNet50FPN', 800, 1280, 80
     for unit in (False, True):
-        rows = trajectory(a.backbone, a.steps, a.lr, unit)
-        print('== %s, lr %g, box-head bias: %s ==' % (a.backbone, a.lr, 'unit rotation (0,0,0,0,0,1)' if unit else "reference prior -4.6 (model.py:121-122)"))
+        rows = trajectory(a.backbone, a.steps, a.lr, unit, a.height, a.width, a.classes, bench_like=a.bench_like)
+        print('== %s %dx%d, %d classes, lr %g, box-head bias: %s ==' % (a.backbone, a.height, a.width, a.classes, a.lr, 'unit rotation (0,0,0,0,0,1)' if unit else "reference prior -4.6 (model.py:121-122)"))
         print('step   fused: focal      box   |   torch: focal      box')
         for i in range(max(len(rows['fused']), len(rows['torch']))):
             f = rows['fused'][i] if i < len(rows['fused']) else (float('nan'),) * 2
