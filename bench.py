@@ -127,8 +127,8 @@ def run_train(args, rank, local_rank, world, dev):
     model.initialize(None)
     if args.rotated_bbox and args.unit_rotation:
         # the reference's init puts the -4.6 class prior on all six box outputs (model.py:121-122): the box loss starts at ~28 and
-        # SGD diverges within a few dozen steps in the reference's own arithmetic (tools/rotated_train_probe.py,
-        # profiles/r05_rotated_train_trajectory.txt); (0, 0, 0, 0, sin 0, cos 1) is what a trained rotated model emits
+        # SGD diverges within a few dozen steps in the reference's own arithmetic (tools/rotated_train_probe.py --bench-like,
+        # profiles/r05_rotated_train_trajectory.txt: non-finite at step 6 fused / 7 torch); (0, 0, 0, 0, sin 0, cos 1) is what a trained rotated model emits
         with torch.no_grad():
             bias = model.box_head[-1].bias.view(model.num_anchors, 6)
             bias.zero_()
@@ -273,6 +273,9 @@ def build_parser():
     ap.add_argument('--no-fuse', action='store_true',
                     help='time the eager nn.Module graph under autocast (Model.fused_graph = False) instead of the '
                          'BN-folded engine Model.forward uses by default')
+    ap.add_argument('--no-conv-library', action='store_true',
+                    help='A/B: every k x k convolution as MIOpen convolution + odtk_bias_act (round 4\'s graph) instead of the '
+                         'per-layer plan that may route it to the convolution library\'s fused epilogue (csrc/conv_ck.cpp)')
     ap.add_argument('--no-eager-leg', action='store_true', help='skip the extra (untimed-region) eager-graph measurement')
     ap.add_argument('--no-level-streams', action='store_true',
                     help='run the head towers of all pyramid levels on one stream (default: small levels on side streams)')
@@ -349,6 +352,8 @@ def headline(full):
         h['postproc_us_per_step'] = full.get('postproc_us_per_step')
     if full.get('eager'):
         h['eager'] = pick(full['eager'], 'value', 'ms_per_step')
+    if full.get('conv_epilogue'):
+        h['conv_epilogue'] = pick(full['conv_epilogue'], 'layers_routed_to_library', 'layers_measured', 'us_saved_per_step')
     cb = full.get('cpu_baseline')
     if cb:
         h['cpu_baseline'] = pick(cb, 'value', 'unit', 'cores', 'kind', 'sample')
@@ -465,6 +470,9 @@ def main(argv=None):
     else:
         dev = torch.device('cpu')
     torch.backends.cudnn.benchmark = not args.no_miopen_find
+    if args.no_conv_library:
+        from odtk import fused
+        fused._Conv.use_conv_library = False
     t_start = time.perf_counter()
     if args.mode == 'train':
         line = run_train(args, rank, local_rank, world, dev)
@@ -518,8 +526,11 @@ def leg_table(args, rank, local_rank, world, dev):
          lambda: run_infer(leg_args(args, dtype='fp16'), rank, world, dev)),
         ('cfg3_train_fp32_2img', 'config 3 (per-GPU share): ResNet50FPN fp32 training, 2 images per GPU', 125,
          lambda: run_train(leg_args(args, mode='train', batch=2, dtype='fp32'), rank, local_rank, world, dev)),
-        ('cfg3_train_rotated', 'config 3 with --rotated-bbox (per-GPU share): fused rotated target assignment', 47,
-         lambda: run_train(leg_args(args, mode='train', batch=2, dtype='fp32', rotated_bbox=True), rank, local_rank, world, dev)),
+        # (unit (sin, cos) head bias: with the reference's own initialisation -- the -4.6 class prior on all six box outputs,
+        # model.py:121-122 -- SGD diverges within 6-7 steps in the reference's arithmetic exactly as in the fused kernels:
+        # profiles/r05_rotated_train_trajectory.txt, tools/rotated_train_probe.py --bench-like)
+        ('cfg3_train_rotated', 'config 3 with --rotated-bbox, unit (sin, cos) head bias (per-GPU share): fused rotated target assignment', 47,
+         lambda: run_train(leg_args(args, mode='train', batch=2, dtype='fp32', rotated_bbox=True, unit_rotation=True), rank, local_rank, world, dev)),
         ('cfg5_rotated_unit', 'config 5 with a unit (sin, cos) head bias', 5,
          lambda: run_infer(leg_args(args, rotated_bbox=True, unit_rotation=True), rank, world, dev)),
     ]
@@ -697,6 +708,7 @@ def run_infer(args, rank, world, dev):
     prof = _C.profile_collect()
     eager = None
     epilogue_roofline, marker_timed = None, None
+    conv_epilogue = conv_epilogue_record(engine()) if (fuse_graph and rank == 0) else None
     if rank == 0:
         # The engine's own epilogue kernels.  Their algorithmic bytes (every element read once and written once, + the skip
         # input) are counted live over three untimed steps.  Their TIME cannot be taken live: an event pair handed to a launch
@@ -961,7 +973,7 @@ def run_infer(args, rank, world, dev):
             'roofline': roofline, 'latency_bound': latency_bound, 'conv_roofline': conv_roofline, 'kernels': kernels,
             'postproc_us_per_step': round(sum(kernels[k]['avg_us'] * kernels[k]['launches'] for k in post if k in kernels) / max(n, 1), 2),
             'quoted': quoted, 'parity': parity, 'kernel_src_sha16': src_hash,
-            'epilogue_roofline': epilogue_roofline, 'marker_timed': marker_timed,
+            'epilogue_roofline': epilogue_roofline, 'marker_timed': marker_timed, 'conv_epilogue': conv_epilogue,
             'candidates_per_image_per_level': candidates,
             'spec_candidates_per_image_per_level': SPEC_CANDIDATES if (args.height, args.width) == (800, 1280) and not args.rotated_bbox else None,
             'eager': eager,
@@ -969,6 +981,29 @@ def run_infer(args, rank, world, dev):
         }
     model.__dict__['_engine_cache'].clear()
     return line
+
+
+def conv_epilogue_record(engine):
+    """What the engine's plan pass decided for its k x k convolutions (odtk/fused.py: `_Conv.route`): per layer and input
+    shape the time of the ONE-launch form (composable_kernel convolution with bias + ReLU in its epilogue, csrc/conv_ck.cpp)
+    and of the TWO-launch form (MIOpen convolution + odtk_bias_act), both measured back to back on this GPU during the
+    plan pass, and which one the step runs."""
+    routes = engine.conv_routes()
+    if not routes:
+        return None
+    layers, one, two, saved, n_lib = {}, 0.0, 0.0, 0.0, 0
+    for name, per_shape in sorted(routes.items()):
+        for shape, (use, t_one, t_two) in per_shape.items():
+            layers['%s %s' % (name, ('conv only ' if shape[0] == 'only' else '') + 'x'.join(str(v) for v in shape if v != 'only'))] = {
+                'library': bool(use), 'us_one_launch': None if t_one == float('inf') else round(t_one, 1), 'us_two_launches': round(t_two, 1)}
+            n_lib += bool(use)
+            two += t_two
+            one += min(t_one, t_two)
+            saved += max(t_two - t_one, 0.0)
+    return {'layers_routed_to_library': n_lib, 'layers_measured': len(layers), 'us_per_step_two_launch_form': round(two, 1),
+            'us_per_step_as_routed': round(one, 1), 'us_saved_per_step': round(saved, 1),
+            'note': 'per-layer A/B of the plan pass (median of 5, back to back, caller stream only): shared tower layers run once '
+                    'per pyramid level and are listed per input shape', 'layers': layers}
 
 
 if __name__ == '__main__':

@@ -783,6 +783,68 @@ def gemm_bias_act(x, weight, bias, residual=None, relu=True):
     return y
 
 
+# ---- libodtk_conv.so: k x k convolution with the bias + ReLU in its own epilogue (csrc/conv_ck.cpp) -----------------------------
+_CONV_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libodtk_conv.so')
+_conv_lib = []
+
+
+def conv_library():
+    """The loaded libodtk_conv.so, or None when it has not been built (the engine then keeps convolution + odtk_bias_act)."""
+    if not _conv_lib:
+        lib = None
+        if os.path.isfile(_CONV_LIB_PATH) and not os.environ.get('ODTK_NO_CONV_LIBRARY'):
+            lib = ctypes.CDLL(_CONV_LIB_PATH)
+            lib.odtk_conv_bias_act.restype = ctypes.c_int
+            lib.odtk_conv_bias_act.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] * 13 + [ctypes.c_void_p]
+            lib.odtk_conv_last_plan.restype = ctypes.c_char_p
+            lib.odtk_conv_last_plan.argtypes = []
+            lib.odtk_conv_instance_count.restype = ctypes.c_int
+            lib.odtk_conv_instance_count.argtypes = [ctypes.c_int]
+        _conv_lib.append(lib)
+    return _conv_lib[0]
+
+
+def conv_available():
+    return conv_library() is not None
+
+
+def conv_bias_act(x, weight, bias, stride=(1, 1), padding=(1, 1), relu=True):
+    """act(conv2d(x, weight) + bias) of a channels_last bf16 / fp16 activation in ONE launch: a composable_kernel implicit-GEMM
+    convolution with the bias and the ReLU in its epilogue (include/odtk_conv.h: odtk_conv_bias_act).  x [B, Cin, H, W]
+    channels_last, weight [Cout, Cin, kh, kw] channels_last (= K, Y, X, C in memory), bias [Cout] of x.dtype.  The first call
+    for a problem times the library's instances on the current stream (one synchronisation each); later calls only enqueue.
+    Raises RuntimeError (ODTK_ERR_UNSUPPORTED) when no instance takes the problem."""
+    lib = conv_library()
+    if lib is None:
+        raise ImportError('odtk._C: %s is missing -- build it (python __graft_entry__.py, or make -C retinanet-examples_amd/csrc conv)'
+                          % _CONV_LIB_PATH)
+    if not x.is_cuda or x.dim() != 4 or x.dtype not in (torch.bfloat16, torch.float16):
+        raise RuntimeError('conv_bias_act: x must be a 4-d CUDA tensor of bfloat16/float16')
+    b, c, h, w = x.shape
+    k, c2, kh, kw = weight.shape
+    if c2 != c or weight.dtype != x.dtype or not weight.is_contiguous(memory_format=torch.channels_last):
+        raise RuntimeError('conv_bias_act: weight must be [Cout, Cin, kh, kw] of x.dtype, channels_last')
+    if not x.is_contiguous(memory_format=torch.channels_last):
+        raise RuntimeError('conv_bias_act: x must be channels_last')
+    if bias.dtype != x.dtype or bias.numel() != k or not bias.is_cuda or not bias.is_contiguous():
+        raise RuntimeError('conv_bias_act: bias must be a CUDA vector of length Cout in the dtype of x')
+    sh, sw = (stride, stride) if isinstance(stride, int) else stride
+    ph, pw = (padding, padding) if isinstance(padding, int) else padding
+    ho, wo = (h + 2 * ph - kh) // sh + 1, (w + 2 * pw - kw) // sw + 1
+    y = torch.empty((b, k, ho, wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    with torch.cuda.device(x.device):
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        _check(lib.odtk_conv_bias_act(y.data_ptr(), x.data_ptr(), weight.data_ptr(), bias.data_ptr(), b, c, h, w, k, kh, kw,
+                                      sh, sw, ph, pw, _DTYPES[x.dtype], 1 if relu else 0, stream), 'conv_bias_act')
+    return y
+
+
+def conv_last_plan():
+    """'#index time name' of the instance the last conv_bias_act call of this thread ran (measurement records)."""
+    lib = conv_library()
+    return lib.odtk_conv_last_plan().decode() if lib is not None else ''
+
+
 def loss_tuning(which, fp32_heads, threads, blocks_per_cu, unroll, box_blocks):
     """Debug / tuning: launch shape of the loss kernels of one form (0 forward with atomics, 1 backward, 2 forward through a
     workspace) and head width (include/odtk_hip.h: odtk_debug_loss_tuning)."""

@@ -47,34 +47,100 @@ def fold_conv_bn(conv, bn=None):
 
 
 class _Conv(nn.Module):
-    """Convolution without bias (MIOpen) + fused epilogue bias (+ residual) (+ ReLU) (HIP)."""
+    """Convolution + bias (+ residual) (+ ReLU).  Three native routes, by kernel shape:
+      * 1x1: ONE hipBLASLt GEMM with the whole epilogue (`odtk_gemm_bias_act`);
+      * k x k without a skip input, 16-bit: ONE composable_kernel implicit-GEMM convolution with bias + ReLU in its own
+        epilogue (`odtk_conv_bias_act`, csrc/conv_ck.cpp) -- where the engine's plan pass measured it faster than
+      * the MIOpen convolution followed by the HIP epilogue pass `odtk_bias_act` (in place)."""
+
+    planning = False          # class-wide: the engine's plan pass is running -> undecided k x k shapes are measured (A/B)
+    use_conv_library = True   # set False to A/B the whole engine against round 4's graph
 
     def __init__(self, conv, bn=None, relu=False, dtype=torch.bfloat16):
         super().__init__()
         w, b = fold_conv_bn(conv, bn)
         self.register_buffer('weight', w.to(dtype).contiguous(memory_format=torch.channels_last))
         self.register_buffer('bias', b.contiguous())
+        # the convolution library's epilogue reads its bias in the activation dtype (the instance lists are built that way)
+        self.register_buffer('bias_lp', b.to(dtype).contiguous())
         self.stride, self.padding, self.relu, self.groups = conv.stride, conv.padding, relu, conv.groups
         # pointwise: a GEMM over [N*H*W, Cin] with the whole epilogue fused (set False to A/B against MIOpen)
         # (a strided 1x1 convolution -- the downsample branch -- is the same GEMM on the subsampled pixels)
         self.pointwise = (tuple(conv.kernel_size) == (1, 1) and tuple(conv.padding) == (0, 0) and conv.groups == 1
                           and tuple(conv.dilation) == (1, 1))
+        # (which channel counts the instances take is the library's business: it says "unsupported" and the A/B records inf)
+        self.library_ok = (not self.pointwise and conv.groups == 1 and tuple(conv.dilation) == (1, 1)
+                           and dtype in (torch.bfloat16, torch.float16) and w.shape[1] % 8 == 0)
+        self.zero_bias = None
+        self.route = {}                                                 # input shape -> (use the library, us library, us miopen + epilogue)
 
     def conv_only(self, x):
-        """The convolution without its epilogue (the caller owns the bias)."""
+        """The convolution without its epilogue (the caller owns the bias: the heads' last convolutions, whose bias the
+        post-processing kernels add).  Routed like `forward`: the library's instance list is a second find space for the same
+        contraction (a zero bias, no clamp), taken where the plan pass measured it faster than MIOpen's pick."""
+        if (self.library_ok and _Conv.use_conv_library and x.is_cuda and x.is_contiguous(memory_format=torch.channels_last)
+                and _C.conv_available()):
+            key = ('only',) + tuple(x.shape)
+            route = self.route.get(key)
+            if route is None and _Conv.planning and not torch.cuda.is_current_stream_capturing():
+                if self.zero_bias is None:
+                    self.zero_bias = torch.zeros_like(self.bias_lp)
+                route = self.route[key] = self._measure(x, self._miopen_only, self._library_only)
+            if route is not None and route[0]:
+                return self._library_only(x)
+        return self._miopen_only(x)
+
+    def _miopen_only(self, x):
         y = F.conv2d(x, self.weight, None, self.stride, self.padding, groups=self.groups)
         return y if y.is_contiguous(memory_format=torch.channels_last) else y.contiguous(memory_format=torch.channels_last)
+
+    def _library_only(self, x):
+        return _C.conv_bias_act(x, self.weight, self.zero_bias, self.stride, self.padding, False)
+
+    def _two_pass(self, x, residual=None):
+        y = F.conv2d(x, self.weight, None, self.stride, self.padding, groups=self.groups)
+        if not y.is_contiguous(memory_format=torch.channels_last):
+            y = y.contiguous(memory_format=torch.channels_last)
+        return _C.bias_act_(y, self.bias, residual, self.relu)
+
+    def _one_pass(self, x):
+        return _C.conv_bias_act(x, self.weight, self.bias_lp, self.stride, self.padding, self.relu)
+
+    def _measure(self, x, two=None, one=None):
+        """A/B of the two k x k routes on this input (plan pass only): median of 5 after a warm-up, events on the current stream."""
+        two, one = two or self._two_pass, one or self._one_pass
+
+        def timed(fn):
+            fn(x)
+            times = []
+            for _ in range(5):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                fn(x)
+                e1.record()
+                e1.synchronize()
+                times.append(e0.elapsed_time(e1) * 1e3)
+            return sorted(times)[2]
+        t_two = timed(two)
+        try:
+            t_one = timed(one)
+        except RuntimeError:                                            # no instance of the library takes the problem
+            t_one = float('inf')
+        return (t_one < t_two, t_one, t_two)
 
     def forward(self, x, residual=None):
         if self.pointwise and _C.gemm_available():
             if tuple(self.stride) != (1, 1):
                 x = x[:, :, ::self.stride[0], ::self.stride[1]].contiguous(memory_format=torch.channels_last)
             return _C.gemm_bias_act(x, self.weight, self.bias, residual, self.relu)
-        y = F.conv2d(x, self.weight, None, self.stride, self.padding, groups=self.groups)
-        if not y.is_contiguous(memory_format=torch.channels_last):
-            y = y.contiguous(memory_format=torch.channels_last)
-        return _C.bias_act_(y, self.bias, residual, self.relu)
-
+        if (residual is None and self.library_ok and _Conv.use_conv_library and x.is_cuda
+                and x.is_contiguous(memory_format=torch.channels_last) and _C.conv_available()):
+            route = self.route.get(tuple(x.shape))
+            if route is None and _Conv.planning and not torch.cuda.is_current_stream_capturing():
+                route = self.route[tuple(x.shape)] = self._measure(x)
+            if route is not None and route[0]:
+                return self._one_pass(x)
+        return self._two_pass(x, residual)
 
     def conv_then_pool(self, x):
         """conv -> bias -> ReLU -> maxpool 3x3/s2 with the epilogue folded into the pooling pass."""
@@ -148,6 +214,7 @@ class FusedRetinaNet(nn.Module):
         self.level_streams = True                                       # small pyramid levels on side HIP streams
         self._streams = None
         self.tower_plan = 0
+        self._planned = set()                                           # input geometries whose k x k convolutions were routed (plan pass)
         self._graphs = {}                                               # input geometry + bias state -> (hipGraph, static input, outputs, tables kept alive)
         self._thresholds = {}                                           # score threshold -> the prefilter's table for cls_head[-1].bias
         self.max_graphs = 8
@@ -276,9 +343,32 @@ class FusedRetinaNet(nn.Module):
         graph.replay()
         return tuple(o.clone() for o in out)
 
+    def plan(self, x):
+        """Routes every k x k convolution for this input geometry: one pass over the graph on the caller's stream (no side
+        streams: nothing runs beside a convolution while it is timed) in which each such convolution is run both ways -- the
+        convolution library's fused epilogue vs MIOpen + `odtk_bias_act` -- and keeps the faster (`_Conv.route`)."""
+        key = (tuple(x.shape), x.device)
+        if key in self._planned or not x.is_cuda or not _C.conv_available() or not _Conv.use_conv_library:
+            return
+        if torch.cuda.is_current_stream_capturing():
+            return                                                      # (replay() warms up eagerly first: planned by then)
+        streams, _Conv.planning, self.level_streams = self.level_streams, True, False
+        try:
+            with torch.autocast(x.device.type, enabled=False):
+                t = x.to(self.dtype).contiguous(memory_format=torch.channels_last)
+                self._towers(self.features(t), False)
+        finally:
+            _Conv.planning, self.level_streams = False, streams
+        self._planned.add(key)
+
+    def conv_routes(self):
+        """{layer name: {input shape: (library?, us library, us two-pass)}} of the plan passes so far (measurement records)."""
+        return {name: dict(mod.route) for name, mod in self.named_modules() if isinstance(mod, _Conv) and mod.route}
+
     @torch.no_grad()
     def forward(self, x):
         m = self.model[0]
+        self.plan(x)
         fold = self.dtype in (torch.bfloat16, torch.float16) and self.cls_head[-1].bias.numel() % 8 == 0
         if fold:
             cls_heads, box_heads, cls_bias, box_bias = self.heads_without_last_bias(x)
