@@ -696,9 +696,8 @@ def run_infer(args, rank, world, dev):
 
     # time only the three post-processing launches inside the timed region (6 event records per step);
     # the ~110 epilogue launches per step are timed in a separate, untimed pass below
-    post = ('prefilter_scan_kernel', 'select_decode_kernel', 'nms_kernel', 'detect_kernel',
-            'nms_first_round_kernel', 'rotated_sup_matrix_kernel')   # (detect_kernel: selection + NMS in one launch, round 5;
-                                                                     #  the last two: rotated boxes only)
+    post = ('prefilter_scan_kernel', 'select_decode_kernel', 'nms_kernel',
+            'nms_first_round_kernel', 'rotated_sup_matrix_kernel')   # (the last two: rotated boxes only, five launches)
     post = tuple(k for k in post if k in _C.KERNEL_NAMES)
     _C.profile_enable(True, post)
     _C.profile_collect()
@@ -840,19 +839,6 @@ def run_infer(args, rank, world, dev):
                                        'model': '%d kept boxes x %d clk (LDS read + dependent IoU chain + ballot/readlane) at %.1f GHz'
                                                 % (model.detections, NMS_CLK_PER_KEPT, CLOCK_GHZ),
                                        'ratio': round(nms_us / lb, 1)}
-    if 'detect_kernel' in kernels:
-        # round 5: selection + decode + (per image, in the workgroup that finishes it) the NMS are ONE launch: the chain is the
-        # selection's plus the NMS's (rotated: + the matrix / resolve launches behind it)
-        lb = 4.0 + model.detections * NMS_CLK_PER_KEPT / (CLOCK_GHZ * 1e3)
-        parts = [k for k in ('detect_kernel', 'rotated_sup_matrix_kernel', 'nms_kernel') if k in kernels]
-        us = round(sum(kernels[k]['avg_us'] * kernels[k]['launches'] for k in parts) / max(n, 1), 2)
-        latency_bound.pop('nms_kernel', None)
-        latency_bound['select_and_nms'] = {'us_per_step': us, 'kernels': parts,
-                                           'launches_per_step': round(sum(kernels[k]['launches'] for k in parts) / max(n, 1), 2),
-                                           'lower_bound_us': round(lb, 2),
-                                           'model': 'selection (one pass over the keys out of L2 ~1 us + one sort of 1024 keys ~3 us) '
-                                                    '+ %d kept boxes x %d clk at %.1f GHz' % (model.detections, NMS_CLK_PER_KEPT, CLOCK_GHZ),
-                                           'ratio': round(us / lb, 1)}
     sel = [k for k in ('select_decode_kernel',) if k in kernels]
     if sel:
         total = sum(kernels[k]['avg_us'] * kernels[k]['launches'] for k in sel) / kernels['select_decode_kernel']['launches']

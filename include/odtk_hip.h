@@ -384,8 +384,7 @@ int odtk_retina_loss_levels_backward(int n_levels, const odtk_loss_level_t *leve
 #define ODTK_KERNEL_NMS_MATRIX 11 /* rotated_sup_matrix_kernel (rotated: pairwise suppression) */
 #define ODTK_KERNEL_POOL      12  /* bias_act_maxpool_kernel (the stem's bias + ReLU + max-pool pass)  */
 #define ODTK_KERNEL_UPSAMPLE  13  /* upsample_nearest2x_kernel                                         */
-#define ODTK_KERNEL_DETECT    14  /* detect_kernel: select_decode + (in the workgroup that finishes an image) its nms; odtk_detect */
-#define ODTK_KERNEL_COUNT     15
+#define ODTK_KERNEL_COUNT     14
 /* on: 0 = off, otherwise a bit mask of kernel ids (1 << ODTK_KERNEL_*), -1 = all.  An event pair
  * is a queue marker before and after the kernel: cheap for the 3 post-processing launches of a step,
  * measurably NOT free for the ~110 epilogue launches (about 10 % of an 8.7 ms step), so time those

@@ -291,35 +291,19 @@ __device__ __forceinline__ uint32_t count_above(const uint64_t *A, uint32_t n, u
   return lo;
 }
 
-// A read-only fp32 array in global memory.  kCoherent: its contents were written by OTHER workgroups of the SAME launch (the
-// fused form, detect.hpp: select_decode's lists, stored write-through) -- agent-scope loads (`sc1`), which do not trust a line
-// this XCD's L2 may hold from before those stores (publication by ticket, no fence: csrc/select_decode.hpp "Publish").
-template <bool kCoherent>
-struct GlobalF32 {
-  const float *p;
-  __device__ __forceinline__ float operator[](size_t i) const {
-    if constexpr (kCoherent)
-      return __uint_as_float(__hip_atomic_load(reinterpret_cast<const uint32_t *>(p) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    else
-      return p[i];
-  }
-};
-
-// The NMS of image `img` by the calling 1024-thread workgroup (`smem`: its dynamic LDS, NmsLds bytes); n_images: the batch (trace
-// slots only).  nms_kernel (below) is this body with one workgroup per image; detect_kernel (csrc/detect.hpp) calls it from the
-// workgroup that finished an image's last candidate list.
 // kGlobalKeys: more candidates than the LDS holds (count > ODTK_MAX_NMS_COUNT): the key list of an image lives in the
 // caller's workspace instead; rounds then walk it out of L2 -- slower, same result.
 // kStage (rotated only): 0 = the whole NMS in this launch; 1 = export the first round and stop; 2 = resolve the first round
 // from the suppression matrix, then go on as stage 0 would.
-template <int NB, bool kGlobalKeys, int kStage, bool kCoherent>
-__device__ __forceinline__ void nms_body(const NmsArgs &a, const int img, const int n_images, unsigned char *smem) {
+template <int NB, bool kGlobalKeys = false, int kStage = 0>
+__global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsArgs a) {
   static_assert(kStage == 0 || NB == 6, "the staged form exists for rotated boxes only");
   if constexpr (kStage == 2) {
-    if (a.step == 2 && a.done[img]) return;                  // (block-uniform) step 1 finished this image: leave at once
+    if (a.step == 2 && a.done[blockIdx.x]) return;           // (block-uniform) step 1 finished this image: leave at once
   }
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const NmsLds lay(a.count, a.ndet, NB, kGlobalKeys);
-  uint64_t *s_keys = kGlobalKeys ? a.key_scratch + static_cast<size_t>(img) * a.count
+  uint64_t *s_keys = kGlobalKeys ? a.key_scratch + static_cast<size_t>(blockIdx.x) * a.count
                                  : reinterpret_cast<uint64_t *>(smem + lay.keys);
   using Fixed = NmsFixedLds<NB>;
   uint64_t *s_sel = reinterpret_cast<uint64_t *>(smem + Fixed::sel);
@@ -349,22 +333,23 @@ __device__ __forceinline__ void nms_body(const NmsArgs &a, const int img, const 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  if (a.trace && tid == 0) a.trace[(n_images + img) * 8 + 0] = wall_clock64();
+  const int img = blockIdx.x;
+  if (a.trace && tid == 0) a.trace[(gridDim.x + blockIdx.x) * 8 + 0] = wall_clock64();
   const long long shader_clock0 = a.trace ? clock64() : 0;   // debug: shader cycles vs the 100 MHz wall clock = effective clock
   const uint32_t count = a.count;
   const int ndet = a.ndet;
   const float thr = a.thresh;
   const bool own_angle = (a.flags & ODTK_FLAG_ROTATED_NMS_FIXED_ANGLE) != 0;
-  const GlobalF32<kCoherent> in_s{uniform_ptr(a.scores + static_cast<size_t>(img) * count)};
-  const GlobalF32<kCoherent> in_b{uniform_ptr(a.boxes + static_cast<size_t>(img) * count * NB)};
-  const GlobalF32<kCoherent> in_c{uniform_ptr(a.classes + static_cast<size_t>(img) * count)};
-  auto stamp = [&](int k) { if (a.trace && tid == 0) a.trace[(n_images + img) * 8 + k] = wall_clock64(); };
+  const float *in_s = uniform_ptr(a.scores + static_cast<size_t>(img) * count);
+  const float *in_b = uniform_ptr(a.boxes + static_cast<size_t>(img) * count * NB);
+  const float *in_c = uniform_ptr(a.classes + static_cast<size_t>(img) * count);
+  auto stamp = [&](int k) { if (a.trace && tid == 0) a.trace[(gridDim.x + blockIdx.x) * 8 + k] = wall_clock64(); };
   // debug: image 0's phases beyond the first round (id, time) pairs: 1 round selected, 2 boxes staged, 3 chunks / push done,
   // 4 filter done, 5 push over everything done
   uint32_t n_phase = 0;
   auto phase = [&](unsigned long long id) {
     if constexpr (NB == 4)                                   // (the rotated kernels have no register to spare for it)
-    if (a.trace && tid == 0 && img == 0 && n_phase < 48) {
+    if (a.trace && tid == 0 && blockIdx.x == 0 && n_phase < 48) {
       a.trace[4096 - 8 * 64 + 96 + 2 * n_phase] = id;
       a.trace[4096 - 8 * 64 + 97 + 2 * n_phase] = wall_clock64();
       ++n_phase;
@@ -417,8 +402,7 @@ __device__ __forceinline__ void nms_body(const NmsArgs &a, const int img, const 
 
   uint32_t left = 0;                 // candidates not yet handed to a round (block-uniform)
   uint32_t my_valid = 0;
-  if (runs && tid < 8 && static_cast<uint32_t>(tid) < n_runs) my_valid = kCoherent ? __hip_atomic_load(a.run_valid + static_cast<size_t>(img) * n_runs + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                         : a.run_valid[static_cast<size_t>(img) * n_runs + tid];
+  if (runs && tid < 8 && static_cast<uint32_t>(tid) < n_runs) my_valid = a.run_valid[static_cast<size_t>(img) * n_runs + tid];
   if constexpr (kStage == 2) {
     // Stage 1 selected and ordered the first round already: its keys, the boxes / classes of the candidates the matrix covers
     // (stage 1 exported them in order: coalesced, and not behind the keys as a gather is) and the matrix itself are requested
@@ -1014,7 +998,7 @@ __device__ __forceinline__ void nms_body(const NmsArgs &a, const int img, const 
       const int kept_before = kept;
       // debug: per-chunk timeline of image 0's first round (3 stamps per chunk: start, after the pair work, after the resolve)
       auto cstamp = [&](int k) {
-        if (a.trace && tid == 0 && img == 0 && first_round && c0 / kNmsChunk < 20)
+        if (a.trace && tid == 0 && blockIdx.x == 0 && first_round && c0 / kNmsChunk < 20)
           a.trace[4096 - 8 * 64 + (c0 / kNmsChunk) * 4 + k] = k == 3 ? static_cast<unsigned long long>(kept) : wall_clock64();
       };
       cstamp(0);
@@ -1233,9 +1217,9 @@ __device__ __forceinline__ void nms_body(const NmsArgs &a, const int img, const 
 
   stamp(4);
   if (a.trace && tid == 0) {
-    a.trace[(n_images + img) * 8 + 5] = examined;
-    a.trace[(n_images + img) * 8 + 6] = K;
-    a.trace[(n_images + img) * 8 + 7] = static_cast<unsigned long long>(clock64() - shader_clock0);
+    a.trace[(gridDim.x + blockIdx.x) * 8 + 5] = examined;
+    a.trace[(gridDim.x + blockIdx.x) * 8 + 6] = K;
+    a.trace[(gridDim.x + blockIdx.x) * 8 + 7] = static_cast<unsigned long long>(clock64() - shader_clock0);
   }
   // ---- outputs: kept boxes, then the zero-padded tail (box.py:322-324) ----
   if constexpr (kStage == 2) {
@@ -1253,12 +1237,6 @@ __device__ __forceinline__ void nms_body(const NmsArgs &a, const int img, const 
     for (int k = 0; k < NB; ++k) out_boxes[o * NB + k] = v ? s_kbox[t * NB + k] : 0.0f;
     if (out_indices) out_indices[o] = v ? s_ksrc[t] : -1;
   }
-}
-
-template <int NB, bool kGlobalKeys = false, int kStage = 0>
-__global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  nms_body<NB, kGlobalKeys, kStage, false>(a, static_cast<int>(blockIdx.x), static_cast<int>(gridDim.x), smem);
 }
 
 }  // namespace odtk

@@ -21,7 +21,6 @@
 #include "epilogue.hpp"
 #include "iou.hpp"
 #include "nms.hpp"
-#include "detect.hpp"
 #include "prefilter.hpp"
 #include "select_decode.hpp"
 #include "targets.hpp"
@@ -199,16 +198,9 @@ float logit_lower_bound(float thresh) {
   return static_cast<float>(std::log(t / (1.0 - t)) - 0.01);
 }
 
-// odtk_detect: the selection launch also runs every image's NMS (csrc/detect.hpp) -- `stage` 0: the whole axis-aligned NMS,
-// 1: rotated, the first round in order -- in `lds` bytes of dynamic LDS (the larger of the two bodies' carve-ups)
-struct FusedNms {
-  odtk::FusedNmsArgs args;
-  size_t lds;
-};
-
 template <typename T, bool kLogits>
 int launch_decode(bool rotated, bool aligned, uint32_t scan_blocks, uint32_t sel_blocks, uint32_t sort_cap, size_t scan_lds,
-                  const odtk::ScanArgs &sa, const odtk::DecodeArgs &da, hipStream_t stream, const FusedNms *fused = nullptr) {
+                  const odtk::ScanArgs &sa, const odtk::DecodeArgs &da, hipStream_t stream) {
   if (aligned)
     timed_launch(ODTK_KERNEL_PREFILTER, odtk::prefilter_scan_kernel<T, kLogits, true>, dim3(scan_blocks), dim3(odtk::kScanThreads), scan_lds, stream, sa);
   else
@@ -225,31 +217,19 @@ int launch_decode(bool rotated, bool aligned, uint32_t scan_blocks, uint32_t sel
     timed_launch(ODTK_KERNEL_SELECT, odtk::select_decode_kernel<NB_, T, kLogits, CAP_>, dim3(sel_blocks), dim3(odtk::kSelThreads), \
                  odtk::SelLds<CAP_>::total, stream, da);                                                                       \
   } while (0)
-#define ODTK_DETECT_LAUNCH(NB_, STAGE_)                                                                                        \
-  do {                                                                                                                         \
-    const int rc_ = allow_dynamic_lds(reinterpret_cast<const void *>(&odtk::detect_kernel<NB_, T, kLogits, STAGE_>), 160 * 1024 - 1024, \
-                                      "hipFuncSetAttribute(detect_kernel)");                                                   \
-    if (rc_ != ODTK_OK) return rc_;                                                                                            \
-    timed_launch(ODTK_KERNEL_DETECT, odtk::detect_kernel<NB_, T, kLogits, STAGE_>, dim3(sel_blocks), dim3(odtk::kSelThreads),   \
-                 fused->lds, stream, da, fused->args);                                                                         \
-  } while (0)
-  if (fused) {                                              // (top_n <= 4096: odtk_detect checked)
-    if (rotated) ODTK_DETECT_LAUNCH(6, 1); else ODTK_DETECT_LAUNCH(4, 0);
-  } else if (sort_cap > static_cast<uint32_t>(odtk::kSortCap)) {
+  if (sort_cap > static_cast<uint32_t>(odtk::kSortCap)) {
     if (rotated) ODTK_SELECT_LAUNCH(6, odtk::kSortCapBig); else ODTK_SELECT_LAUNCH(4, odtk::kSortCapBig);
   } else {
     if (rotated) ODTK_SELECT_LAUNCH(6, odtk::kSortCap); else ODTK_SELECT_LAUNCH(4, odtk::kSortCap);
   }
 #undef ODTK_SELECT_LAUNCH
-#undef ODTK_DETECT_LAUNCH
   ODTK_HIP_TRY(hipGetLastError());
   return ODTK_OK;
 }
 
 int decode_levels_impl(int batch, int n_levels, const odtk_level_t *levels, int A, int C, int dtype,
                        uint32_t flags, float thresh, int top_n, void *const *outputs, int n_outputs,
-                       void *workspace, size_t workspace_size, hipStream_t stream, uint32_t *run_valid = nullptr,
-                       const FusedNms *fused = nullptr) {
+                       void *workspace, size_t workspace_size, hipStream_t stream, uint32_t *run_valid = nullptr) {
   if (batch <= 0 || n_levels <= 0 || n_levels > ODTK_MAX_LEVELS || !levels) return ODTK_ERR_INVALID;
   if (A <= 0 || A > ODTK_MAX_ANCHORS || C <= 0 || top_n <= 0 || top_n > ODTK_MAX_TOP_N) return ODTK_ERR_INVALID;
   for (int l = 0; l < n_levels; ++l)
@@ -367,13 +347,13 @@ int decode_levels_impl(int batch, int n_levels, const odtk_level_t *levels, int 
   const uint32_t sort_cap = sort_cap_for(top_n);
   const bool rotated = (flags & ODTK_FLAG_ROTATED) != 0, logits = (flags & ODTK_FLAG_LOGITS) != 0;
   if (dtype == ODTK_F32)
-    return logits ? launch_decode<odtk::F32, true>(rotated, aligned, scan_blocks, sel_blocks, sort_cap, scan_lds, sa, da, stream, fused)
-                  : launch_decode<odtk::F32, false>(rotated, aligned, scan_blocks, sel_blocks, sort_cap, scan_lds, sa, da, stream, fused);
+    return logits ? launch_decode<odtk::F32, true>(rotated, aligned, scan_blocks, sel_blocks, sort_cap, scan_lds, sa, da, stream)
+                  : launch_decode<odtk::F32, false>(rotated, aligned, scan_blocks, sel_blocks, sort_cap, scan_lds, sa, da, stream);
   if (dtype == ODTK_BF16)
-    return logits ? launch_decode<odtk::BF16, true>(rotated, aligned, scan_blocks, sel_blocks, sort_cap, scan_lds, sa, da, stream, fused)
-                  : launch_decode<odtk::BF16, false>(rotated, aligned, scan_blocks, sel_blocks, sort_cap, scan_lds, sa, da, stream, fused);
-  return logits ? launch_decode<odtk::F16, true>(rotated, aligned, scan_blocks, sel_blocks, sort_cap, scan_lds, sa, da, stream, fused)
-                : launch_decode<odtk::F16, false>(rotated, aligned, scan_blocks, sel_blocks, sort_cap, scan_lds, sa, da, stream, fused);
+    return logits ? launch_decode<odtk::BF16, true>(rotated, aligned, scan_blocks, sel_blocks, sort_cap, scan_lds, sa, da, stream)
+                  : launch_decode<odtk::BF16, false>(rotated, aligned, scan_blocks, sel_blocks, sort_cap, scan_lds, sa, da, stream);
+  return logits ? launch_decode<odtk::F16, true>(rotated, aligned, scan_blocks, sel_blocks, sort_cap, scan_lds, sa, da, stream)
+                : launch_decode<odtk::F16, false>(rotated, aligned, scan_blocks, sel_blocks, sort_cap, scan_lds, sa, da, stream);
 }
 
 template <int NB, bool kGlobalKeys, int kStage = 0>
@@ -390,8 +370,8 @@ int nms_launch(const odtk::NmsArgs &na, int batch, size_t lds, hipStream_t strea
 
 // rotated boxes: first round in order -> pairwise suppression matrix on the whole chip -> resolve (csrc/nms.hpp)
 template <bool kGlobalKeys>
-int nms_rotated_staged(odtk::NmsArgs na, int batch, size_t lds, hipStream_t stream, bool stage1_done = false) {
-  int rc = stage1_done ? ODTK_OK : nms_launch<6, kGlobalKeys, 1>(na, batch, lds, stream);   // (detect_kernel ran stage 1 itself)
+int nms_rotated_staged(odtk::NmsArgs na, int batch, size_t lds, hipStream_t stream) {
+  int rc = nms_launch<6, kGlobalKeys, 1>(na, batch, lds, stream);
   if (rc != ODTK_OK) return rc;
   odtk::SupArgs sa;
   sa.first_box = na.first_box; sa.first_cls = na.first_cls; sa.first_n = na.first_n; sa.sup = na.sup;
@@ -446,9 +426,7 @@ uint32_t rotated_matrix_rows(size_t count, int ndet, int ways) {
 
 int nms_impl(int batch, const void *const *inputs, void *const *outputs, int n_outputs, size_t count,
              int ndet, float thresh, uint32_t flags, void *workspace, size_t workspace_size, hipStream_t stream,
-             uint32_t sorted_run_len = 0, const uint32_t *run_valid = nullptr, FusedNms *fuse_out = nullptr, bool fused = false) {
-  // fuse_out != null: do not launch -- report what a detect_kernel needs to run the first launch's work itself (fuse_out->lds == 0:
-  // this problem has no fused form).  fused: that kernel has run; launch only what follows it (rotated: matrix + resolve).
+             uint32_t sorted_run_len = 0, const uint32_t *run_valid = nullptr) {
   if (batch <= 0 || count == 0 || count > ODTK_MAX_NMS_COUNT_SCRATCH || ndet <= 0 || ndet > ODTK_MAX_NMS_DETECTIONS)
     return ODTK_ERR_INVALID;
   // up to ODTK_MAX_NMS_COUNT candidates per image everything is LDS-resident and the kernel needs no global scratch
@@ -495,15 +473,6 @@ int nms_impl(int batch, const void *const *inputs, void *const *outputs, int n_o
   na.key_scratch = global_keys ? static_cast<uint64_t *>(workspace) : nullptr;
   const size_t lds = odtk::NmsLds(na.count, ndet, nb, global_keys).total;   // same carve-up the kernel computes
   if (lds > 160 * 1024) return ODTK_ERR_INVALID;
-  if (fuse_out) fuse_out->lds = 0;
-  if (fuse_out && !global_keys && lds <= 160 * 1024 - 1024 && sorted_run_len && run_valid) {
-    const size_t sel_lds = odtk::SelLds<odtk::kSortCap>::total;
-    fuse_out->lds = lds > sel_lds ? lds : sel_lds;
-    odtk::FusedNmsArgs &f = fuse_out->args;
-    std::memset(&f, 0, sizeof f);
-    f.out_scores = na.out_scores; f.out_boxes = na.out_boxes; f.out_classes = na.out_classes; f.out_indices = na.out_indices;
-    f.ndet = ndet; f.thresh = thresh; f.flags = flags;
-  }
   if (nb == 6) {
     char *ws = static_cast<char *>(workspace);
     na.first_box = reinterpret_cast<float *>(ws + off_fb);
@@ -515,22 +484,9 @@ int nms_impl(int batch, const void *const *inputs, void *const *outputs, int n_o
     na.m_max = m_max;
     na.m_first = rotated_matrix_first(m_max, ndet);
     na.done = reinterpret_cast<uint32_t *>(ws + off_done);
-    if (fuse_out) {
-      odtk::FusedNmsArgs &f = fuse_out->args;
-      f.first_box = na.first_box; f.first_cls = na.first_cls; f.first_n = na.first_n; f.first_keys = na.first_keys;
-      f.first_state = na.first_state; f.m_max = na.m_max;
-      return ODTK_OK;
-    }
-    return global_keys ? nms_rotated_staged<true>(na, batch, lds, stream) : nms_rotated_staged<false>(na, batch, lds, stream, fused);
+    return global_keys ? nms_rotated_staged<true>(na, batch, lds, stream) : nms_rotated_staged<false>(na, batch, lds, stream);
   }
-  if (fuse_out || fused) return ODTK_OK;                     // (axis-aligned: the fused launch is the whole NMS)
   return global_keys ? nms_launch<4, true>(na, batch, lds, stream) : nms_launch<4, false>(na, batch, lds, stream);
-}
-
-// ODTK_NO_FUSED_NMS=1: odtk_detect as three launches (prefilter, select_decode, nms), as in round 4 -- A/B measurements
-bool fused_nms_enabled() {
-  static const bool v = [] { const char *e = std::getenv("ODTK_NO_FUSED_NMS"); return !(e && e[0] == '1'); }();
-  return v;
 }
 
 template <typename T, bool kRes, bool kRelu>
@@ -1166,23 +1122,12 @@ int odtk_detect(int batch_size, int n_levels, const odtk_level_t *levels, int nu
   char *ws = static_cast<char *>(workspace);
   void *cat[3] = {ws + off_s, ws + off_b, ws + off_c};
   uint32_t *run_valid = reinterpret_cast<uint32_t *>(ws + off_v);
-  // One launch for selection + decode + NMS (csrc/detect.hpp) where the problem has that form: top_n <= 4096 (the standard
-  // selection kernel), an LDS-resident NMS, no debug trace; otherwise the round-4 sequence of launches.
-  FusedNms fuse;
-  fuse.lds = 0;
-  if (fused_nms_enabled() && !g_trace && top_n <= odtk::kSortCap) {
-    const int prc = nms_impl(batch_size, cat, outputs, 3, count, detections_per_im, nms_thresh, flags, ws + off_n,
-                             static_cast<size_t>(nms_ws), static_cast<hipStream_t>(stream), static_cast<uint32_t>(top_n), run_valid, &fuse);
-    if (prc != ODTK_OK) return prc;
-  }
-  const bool fused = fuse.lds != 0;
   int rc = decode_levels_impl(batch_size, n_levels, levels, num_anchors, num_classes, dtype, flags, score_thresh,
-                              top_n, cat, 3, workspace, static_cast<size_t>(dec), static_cast<hipStream_t>(stream), run_valid,
-                              fused ? &fuse : nullptr);
+                              top_n, cat, 3, workspace, static_cast<size_t>(dec), static_cast<hipStream_t>(stream), run_valid);
   if (rc != ODTK_OK) return rc;
   // the candidates are decode_levels' own output: n_levels runs of top_n, each already in NMS order, run_valid of them positive
   return nms_impl(batch_size, cat, outputs, 3, count, detections_per_im, nms_thresh, flags, ws + off_n,
-                  static_cast<size_t>(nms_ws), static_cast<hipStream_t>(stream), static_cast<uint32_t>(top_n), run_valid, nullptr, fused);
+                  static_cast<size_t>(nms_ws), static_cast<hipStream_t>(stream), static_cast<uint32_t>(top_n), run_valid);
 }
 
 }  // extern "C"

@@ -59,8 +59,7 @@ constexpr uint32_t kListOverflow = 0xffffffffu;  // sub-list length: "more than 
 struct SelSeg {
   uint32_t surv_count;     // keys appended to the segment's survivor list
   uint32_t arrived;        // workgroups that have appended theirs (ticket)
-  uint32_t lists_done;     // (segment of level 0 only) candidate lists of this IMAGE written so far: detect_kernel's second ticket
-  uint32_t pad_;
+  uint32_t pad_[2];
   uint32_t hist[1 << 11];  // histogram (2048 equal bins of the key range, reversed) of the keys on the survivor list
 };
 
@@ -258,7 +257,7 @@ __global__ __launch_bounds__(kScanThreads, (!kAligned ? 2 : sizeof(typename T::s
     uint4 *h = reinterpret_cast<uint4 *>(S->hist) + 2 * tid;   // 2048 words = 256 threads x 2 x 16 bytes
     h[0] = make_uint4(0u, 0u, 0u, 0u);
     h[1] = make_uint4(0u, 0u, 0u, 0u);
-    if (tid == 0) { S->surv_count = 0; S->arrived = 0; S->lists_done = 0; S->pad_ = 0; }
+    if (tid == 0) { S->surv_count = 0; S->arrived = 0; S->pad_[0] = 0; S->pad_[1] = 0; }
   }
 
   // With a bias the logit of element r is raw[r] + bias[r % channels] (channels_last, channels % kPer == 0, checked by

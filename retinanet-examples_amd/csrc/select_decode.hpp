@@ -771,12 +771,9 @@ __device__ __forceinline__ SelState select_threshold(const Source &src, uint32_t
 // kLogits: cls holds logits (sigmoid fused, see prefilter.hpp score_of).
 // CAP: keys the LDS sort buffer holds -- kSortCap (static LDS) for top_n <= 4096, kSortCapBig (dynamic LDS, the launch
 // passes CAP * 8 bytes) beyond.
-// The body: what ONE workgroup of the launch does.  Returns true in the workgroup that wrote a segment's lists (exactly one per
-// (level, image)), *image = its image; false in workgroups that only contributed or had nothing to do.
-// kPublish (detect_kernel, csrc/detect.hpp): another workgroup of the SAME launch will read the lists -- they are stored
-// write-through (agent-scope stores, `sc1`), like the tournament's survivor lists.
-template <int NB, typename T, bool kLogits, int CAP, bool kPublish>
-__device__ __forceinline__ bool select_decode_body(const DecodeArgs &a, unsigned char *s_dyn_sel, uint32_t *image) {
+template <int NB, typename T, bool kLogits, int CAP = kSortCap>
+__global__ __launch_bounds__(kSelThreads) void select_decode_kernel(const DecodeArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn_sel[];
   using Lds = SelLds<CAP>;
   uint64_t *s_keys = reinterpret_cast<uint64_t *>(s_dyn_sel + Lds::keys);
   uint32_t *s_hist = reinterpret_cast<uint32_t *>(s_dyn_sel + Lds::hist);
@@ -836,7 +833,7 @@ __device__ __forceinline__ bool select_decode_body(const DecodeArgs &a, unsigned
   G = G < g_min ? g_min : G;
   G = G < 1u ? 1u : G;
   if (has_raw || G > P) G = P;
-  if (part >= G) return false;                                             // (block-uniform)
+  if (part >= G) return;                                                   // (block-uniform)
   stamp2(1, part == 0);
   if (part == G - 1) stamp(0);
   const uint32_t ns = part < spans ? (spans - part + G - 1) / G : 0u;
@@ -1004,7 +1001,7 @@ __device__ __forceinline__ bool select_decode_body(const DecodeArgs &a, unsigned
     if (tid == 0) s_misc[26] = atomicAdd(&S.arrived, 1u);
     __syncthreads();
     stamp2(6, part == 0);
-    if (s_misc[26] != G - 1) return false;                                 // (block-uniform) somebody else is last
+    if (s_misc[26] != G - 1) return;                                       // (block-uniform) somebody else is last
     stamp2(8, true);
     // Everything the finisher needs from memory in ONE round trip (agent-scope loads: ~2 us each way past this XCD's L2): the
     // survivor count, the segment's histogram, and -- before the count that bounds them is known -- the first kEarly x 1024
@@ -1106,15 +1103,11 @@ __device__ __forceinline__ bool select_decode_body(const DecodeArgs &a, unsigned
     bx[3] = clamp_like_torch(pcy + 0.5f * ph - 1.0f, lim_y);
     if constexpr (NB == 6) { bx[4] = d[4]; bx[5] = d[5]; }   // sin, cos pass through (decode_rotate.cu:152-162)
   };
-  auto put = [&](float *p, float v) {
-    if constexpr (kPublish) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else *p = v;
-  };
   auto emit = [&](uint32_t t, float score, float cls, const float (&bx)[NB], int32_t index) {
-    put(a.out_scores + out_row + t, score);
-    put(a.out_classes + out_row + t, cls);
+    a.out_scores[out_row + t] = score;
+    a.out_classes[out_row + t] = cls;
 #pragma unroll
-    for (int k = 0; k < NB; ++k) put(a.out_boxes + (out_row + t) * NB + k, bx[k]);
+    for (int k = 0; k < NB; ++k) a.out_boxes[(out_row + t) * NB + k] = bx[k];
     if (a.out_indices) a.out_indices[out_row + t] = index;
   };
   // Up to 2048 keys (always, at the default top_n): a thread keeps its key(s) through the rank-merge sort, requests their
@@ -1180,21 +1173,9 @@ __device__ __forceinline__ bool select_decode_body(const DecodeArgs &a, unsigned
   }
   if (a.run_valid) {
     __syncthreads();
-    if (tid == 0) {
-      if constexpr (kPublish) __hip_atomic_store(a.run_valid + static_cast<size_t>(b) * a.n_levels + l, s_misc[22], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      else a.run_valid[static_cast<size_t>(b) * a.n_levels + l] = s_misc[22];
-    }
+    if (tid == 0) a.run_valid[static_cast<size_t>(b) * a.n_levels + l] = s_misc[22];
   }
   stamp(4);
-  *image = b;
-  return true;
-}
-
-template <int NB, typename T, bool kLogits, int CAP = kSortCap>
-__global__ __launch_bounds__(kSelThreads) void select_decode_kernel(const DecodeArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn_sel[];
-  uint32_t image;
-  select_decode_body<NB, T, kLogits, CAP, false>(a, s_dyn_sel, &image);
 }
 
 }  // namespace odtk

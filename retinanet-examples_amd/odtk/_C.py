@@ -119,8 +119,7 @@ _SIGNATURES = {
 
 KERNEL_NAMES = ('prefilter_scan_kernel', 'select_decode_kernel', 'nms_kernel', 'iou_pairs_kernel', 'bias_act_kernel',
                 'snap_to_anchors_kernel', 'gemm_bias_act', 'retina_loss_kernel', 'select_hist_kernel', 'select_filter_kernel',
-                'nms_first_round_kernel', 'rotated_sup_matrix_kernel', 'bias_act_maxpool_kernel', 'upsample_nearest2x_kernel',
-                'detect_kernel')
+                'nms_first_round_kernel', 'rotated_sup_matrix_kernel', 'bias_act_maxpool_kernel', 'upsample_nearest2x_kernel')
 # HBM bytes the epilogue entry points move, per kernel name, while `traffic_count` is on (bench.py's epilogue_roofline: the
 # algorithmic bytes of every call -- each element read once and written once, + the skip input -- divided by the kernel time)
 traffic_count = False
