@@ -707,7 +707,7 @@ def run_infer(args, rank, world, dev):
     _C.profile_enable(False)
     prof = _C.profile_collect()
     eager = None
-    epilogue_roofline, marker_timed = None, None
+    epilogue_roofline, marker_timed, quoted_epilogue_obj = None, None, None
     conv_epilogue = conv_epilogue_record(engine()) if (fuse_graph and rank == 0) else None
     if rank == 0:
         # The engine's own epilogue kernels.  Their algorithmic bytes (every element read once and written once, + the skip
@@ -728,9 +728,10 @@ def run_infer(args, rank, world, dev):
         _C.profile_enable(False)
         _C.traffic_count = False
         extra = _C.profile_collect()
+        # (times of these kernels are never taken from a file into this object: what a committed rocprofv3 summary of this
+        # command says about them goes under `quoted.epilogue_kernels`, with the file's name -- VERDICT r04 weak #11)
         profiled = {}
-        stats_name = next((n for n in ('r05_bench_steady_kernel_stats.csv', 'r04_bench_steady_kernel_stats.csv')
-                           if os.path.isfile(os.path.join(ROOT, 'profiles', n))), None)
+        stats_name = next((n for n in ('r05_bench_steady_kernel_stats.csv',) if os.path.isfile(os.path.join(ROOT, 'profiles', n))), None)
         stats = os.path.join(ROOT, 'profiles', stats_name or 'none')
         if default_workload(args) and stats_name:
             import csv
@@ -742,20 +743,23 @@ def run_infer(args, rank, world, dev):
                         calls, total_ns = profiled.get(k, (0, 0))
                         profiled[k] = (calls + int(r[1]), total_ns + int(r[2]))
             profiled = {k: (c / steps_profiled, t / steps_profiled * 1e-3) for k, (c, t) in profiled.items()}
-        epilogue_roofline = {}
+        epilogue_roofline, quoted_epilogue = {}, {}
         for k in epi:
             nbytes = _C.traffic_bytes.get(k, 0) / 3.0
             if not nbytes:
                 continue
-            entry = {'alg_bytes_per_step': int(nbytes), 'bound': 'hbm', 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'us_per_step': None,
-                     'achieved': None, 'frac': None, 'time_source': None}
+            epilogue_roofline[k] = {'alg_bytes_per_step': int(nbytes), 'bound': 'hbm', 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                                    'measured': 'bytes counted live over three untimed steps; no time is measured in this run '
+                                                '(an event pair behind a long convolution includes its tail): see quoted.epilogue_kernels'}
             if k in profiled:
                 calls, us = profiled[k]
+                # (the profile may have been taken with another routing of the k x k convolutions: its own launch count decides)
                 gbs = nbytes / (us * 1e-6) / 1e9
-                entry.update({'launches_per_step': round(calls, 1), 'us_per_step': round(us, 1), 'achieved': round(gbs, 1),
-                              'frac': round(gbs / HBM_PEAK_GBS, 4),
-                              'time_source': 'QUOTED, not measured in this run: profiles/%s (rocprofv3 --kernel-trace --stats of this command)' % stats_name})
-            epilogue_roofline[k] = entry
+                quoted_epilogue[k] = {'launches_per_step': round(calls, 1), 'us_per_step': round(us, 1),
+                                      'achieved_GBps_on_todays_bytes': round(gbs, 1), 'frac_of_hbm_peak': round(gbs / HBM_PEAK_GBS, 4)}
+        if quoted_epilogue:
+            quoted_epilogue_obj = {'source': 'profiles/%s (rocprofv3 --kernel-trace --stats of this command, another run)' % stats_name,
+                                   'kernels': quoted_epilogue}
         # hipBLASLt launches its own kernels: the library can only put marker packets around the call, and a marker pair
         # includes the dispatch latency on both sides -- NOT comparable with the dispatch-timestamp figures in `kernels`
         ms_g, n_g = extra['gemm_bias_act']
@@ -816,6 +820,9 @@ def run_infer(args, rank, world, dev):
                 break
         except Exception:
             continue
+    if quoted_epilogue_obj:
+        quoted = dict(quoted or {})
+        quoted['epilogue_kernels'] = quoted_epilogue_obj
     if n:
         avg_ms = ms / n
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
