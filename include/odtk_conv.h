@@ -35,6 +35,12 @@ int odtk_conv_bias_act(void *y, const void *x, const void *w, const void *bias, 
                        int c_out, int kernel_h, int kernel_w, int stride_h, int stride_w, int pad_h, int pad_w, int dtype,
                        int relu, void *stream);
 
+/* ... with different padding before (pad_h, pad_w: top / left) and after (pad_h_end, pad_w_end: bottom / right) the image:
+ * out = (in + pad + pad_end - kernel) / stride + 1.  (The space-to-depth form of the ResNet stem is a 4x4 convolution padded (2, 1).) */
+int odtk_conv_bias_act_pads(void *y, const void *x, const void *w, const void *bias, int batch_size, int c_in, int height, int width,
+                            int c_out, int kernel_h, int kernel_w, int stride_h, int stride_w, int pad_h, int pad_w, int pad_h_end,
+                            int pad_w_end, int dtype, int relu, void *stream);
+
 /* "#index time-when-chosen instance-name" of the instance the last odtk_conv_bias_act call of this thread ran. */
 const char *odtk_conv_last_plan(void);
 

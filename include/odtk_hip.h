@@ -229,6 +229,19 @@ int odtk_upsample_nearest2x(const void *x, void *out, int batch_size, int height
                             void *stream);
 
 /*
+ * odtk_stem_pack -- 2x2 space-to-depth pack of the network input for the ResNet stem, with the cast to the engine's dtype:
+ *     out[n][y][x][(dy * 2 + dx) * 3 + c] = x[n][c][2 y + dy][2 x + dx]   for the 12 real channels, channels 12..15 = 0
+ * x: device [batch, 3, height, width] of in_dtype (ODTK_F32 / BF16 / F16), NCHW-contiguous (channels_last = 0) or NHWC-contiguous
+ * (channels_last = 1); height and width even.  out: device [batch, height / 2, width / 2, 16] of out_dtype (ODTK_BF16 / F16),
+ * 16-byte aligned.  The 7x7 / stride-2 / pad-3 stem convolution over x equals a 4x4 / stride-1 convolution with padding (2 before,
+ * 1 after) over `out` with the re-indexed weights w4[k][(dy*2+dx)*3+c][R][S] = w[k][c][2R+dy-1][2S+dx-1] (zero outside the 7x7
+ * window): same products, 16-byte channel vectors instead of 3-element ones (odtk/fused.py).  Replaces the cast + layout pass of
+ * the input; no reference kernel equivalent (the reference feeds torchvision's conv1, odtk/backbones/resnet.py).
+ */
+int odtk_stem_pack(const void *x, void *out, int batch_size, int height, int width, int in_dtype, int channels_last, int out_dtype,
+                   void *stream);
+
+/*
  * odtk_gemm_bias_act -- 1x1 (pointwise) convolution of a channels_last activation as ONE GEMM with
  * the whole epilogue fused:
  *     y[p][o] = act( sum_c x[p][c] * w[o][c] + bias[o] (+ residual[p][o]) ),   act = ReLU if relu != 0
@@ -384,7 +397,8 @@ int odtk_retina_loss_levels_backward(int n_levels, const odtk_loss_level_t *leve
 #define ODTK_KERNEL_NMS_MATRIX 11 /* rotated_sup_matrix_kernel (rotated: pairwise suppression) */
 #define ODTK_KERNEL_POOL      12  /* bias_act_maxpool_kernel (the stem's bias + ReLU + max-pool pass)  */
 #define ODTK_KERNEL_UPSAMPLE  13  /* upsample_nearest2x_kernel                                         */
-#define ODTK_KERNEL_COUNT     14
+#define ODTK_KERNEL_STEM_PACK 14  /* stem_pack_kernel (space-to-depth pack of the network input)        */
+#define ODTK_KERNEL_COUNT     15
 /* on: 0 = off, otherwise a bit mask of kernel ids (1 << ODTK_KERNEL_*), -1 = all.  An event pair
  * is a queue marker before and after the kernel: cheap for the 3 post-processing launches of a step,
  * measurably NOT free for the ~110 epilogue launches (about 10 % of an 8.7 ms step), so time those

@@ -52,9 +52,10 @@ using ConvOp = ck::tensor_operation::device::DeviceGroupedConvFwdMultipleABD<
     AddClamp, T, T>;
 
 struct Problem {
-  int n, c, h, w, k, r, s, u, v, ph, pw, dtype;
+  int n, c, h, w, k, r, s, u, v, ph, pw, ph1, pw1, dtype;   // ph / pw: padding before, ph1 / pw1: after
   bool operator<(const Problem &o) const {
-    return std::tie(n, c, h, w, k, r, s, u, v, ph, pw, dtype) < std::tie(o.n, o.c, o.h, o.w, o.k, o.r, o.s, o.u, o.v, o.ph, o.pw, o.dtype);
+    return std::tie(n, c, h, w, k, r, s, u, v, ph, pw, ph1, pw1, dtype) <
+           std::tie(o.n, o.c, o.h, o.w, o.k, o.r, o.s, o.u, o.v, o.ph, o.pw, o.ph1, o.pw1, o.dtype);
   }
 };
 
@@ -85,16 +86,16 @@ template <typename T>
 std::unique_ptr<ck::tensor_operation::device::BaseArgument> make_argument(ConvOp<T> &op, const Problem &p, void *y, const void *x,
                                                                           const void *w, const void *bias, int relu) {
   const index_t G = 1, N = p.n, C = p.c, K = p.k, Hi = p.h, Wi = p.w, Y = p.r, X = p.s;
-  const index_t Ho = (Hi + 2 * p.ph - Y) / p.u + 1, Wo = (Wi + 2 * p.pw - X) / p.v + 1;
+  const index_t Ho = (Hi + p.ph + p.ph1 - Y) / p.u + 1, Wo = (Wi + p.pw + p.pw1 - X) / p.v + 1;
   // lengths in the order CK wants them (G, N, C | K, spatial...), strides of the NHWGC / GKYXC / NHWGK memory layouts
   const std::array<index_t, 5> a_len{G, N, C, Hi, Wi}, a_str{C, Hi * Wi * G * C, 1, Wi * G * C, G * C};
   const std::array<index_t, 5> b_len{G, K, C, Y, X}, b_str{K * Y * X * C, Y * X * C, 1, X * C, C};
   const std::array<index_t, 5> e_len{G, N, K, Ho, Wo}, e_str{K, Ho * Wo * G * K, 1, Wo * G * K, G * K};
   const std::array<index_t, 5> d_str{K, 0, 1, 0, 0};                           // the bias: one value per output channel
-  const std::array<index_t, 2> strides{p.u, p.v}, dilations{1, 1}, pads{p.ph, p.pw};
+  const std::array<index_t, 2> strides{p.u, p.v}, dilations{1, 1}, pads{p.ph, p.pw}, pads_end{p.ph1, p.pw1};
   return op.MakeArgumentPointer(x, w, std::array<const void *, 1>{bias}, y, a_len, a_str, b_len, b_str,
                                 std::array<std::array<index_t, 5>, 1>{e_len}, std::array<std::array<index_t, 5>, 1>{d_str}, e_len,
-                                e_str, strides, dilations, pads, pads, PassThrough{}, PassThrough{},
+                                e_str, strides, dilations, pads, pads_end, PassThrough{}, PassThrough{},
                                 relu ? AddClamp{0.0f, FLT_MAX} : AddClamp{-FLT_MAX, FLT_MAX});
 }
 
@@ -168,14 +169,14 @@ int run(const Problem &p, void *y, const void *x, const void *w, const void *bia
 extern "C" {
 
 // declared in include/odtk_conv.h
-int odtk_conv_bias_act(void *y, const void *x, const void *w, const void *bias, int batch_size, int c_in, int height, int width,
-                       int c_out, int kernel_h, int kernel_w, int stride_h, int stride_w, int pad_h, int pad_w, int dtype,
-                       int relu, void *stream) {
+int odtk_conv_bias_act_pads(void *y, const void *x, const void *w, const void *bias, int batch_size, int c_in, int height, int width,
+                            int c_out, int kernel_h, int kernel_w, int stride_h, int stride_w, int pad_h, int pad_w, int pad_h_end,
+                            int pad_w_end, int dtype, int relu, void *stream) {
   if (!y || !x || !w || !bias || batch_size <= 0 || c_in <= 0 || c_out <= 0 || height <= 0 || width <= 0 || kernel_h <= 0 ||
-      kernel_w <= 0 || stride_h <= 0 || stride_w <= 0 || pad_h < 0 || pad_w < 0)
+      kernel_w <= 0 || stride_h <= 0 || stride_w <= 0 || pad_h < 0 || pad_w < 0 || pad_h_end < 0 || pad_w_end < 0)
     return ODTK_ERR_INVALID;
-  if (height + 2 * pad_h < kernel_h || width + 2 * pad_w < kernel_w) return ODTK_ERR_INVALID;
-  const Problem p{batch_size, c_in, height, width, c_out, kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w, dtype};
+  if (height + pad_h + pad_h_end < kernel_h || width + pad_w + pad_w_end < kernel_w) return ODTK_ERR_INVALID;
+  const Problem p{batch_size, c_in, height, width, c_out, kernel_h, kernel_w, stride_h, stride_w, pad_h, pad_w, pad_h_end, pad_w_end, dtype};
   int force = -1;
   if (const char *f = std::getenv("ODTK_CONV_INSTANCE")) force = std::atoi(f);   // A/B knob for measurements
   try {
@@ -186,6 +187,13 @@ int odtk_conv_bias_act(void *y, const void *x, const void *w, const void *bias, 
     return ODTK_ERR_UNSUPPORTED;
   }
   return ODTK_ERR_UNSUPPORTED;
+}
+
+int odtk_conv_bias_act(void *y, const void *x, const void *w, const void *bias, int batch_size, int c_in, int height, int width,
+                       int c_out, int kernel_h, int kernel_w, int stride_h, int stride_w, int pad_h, int pad_w, int dtype,
+                       int relu, void *stream) {
+  return odtk_conv_bias_act_pads(y, x, w, bias, batch_size, c_in, height, width, c_out, kernel_h, kernel_w, stride_h, stride_w, pad_h,
+                                 pad_w, pad_h, pad_w, dtype, relu, stream);
 }
 
 const char *odtk_conv_last_plan(void) { return g_last_plan.c_str(); }

@@ -194,4 +194,50 @@ __global__ __launch_bounds__(256) void upsample_nearest2x_kernel(const vuint4 *_
   }
 }
 
+// ---- stem: space-to-depth pack of the network input ---------------------------------------------------------------------------
+// The ResNet stem is a 7x7 / stride-2 convolution over THREE input channels: as an implicit GEMM its reduction runs over
+// 3-element channel vectors (MIOpen's pick for it: 230 us at bs 8, a quarter of the matrix-core rate of the other layers, + a
+// 32 us helper pass).  A stride-2 convolution over x is a stride-1 convolution over the 2x2 space-to-depth image of x:
+//     xs[n][y][x][(dy * 2 + dx) * 3 + c] = x[n][c][2 y + dy][2 x + dx]        12 channels, padded with zeros to 16
+//     conv7x7/s2/p3(x, w) == conv4x4/s1/pad(2 before, 1 after)(xs, w4),   w4[k][(dy*2+dx)*3+c][R][S] = w[k][c][2R+dy-1][2S+dx-1]
+// (taps outside the 7x7 window are zero) -- the same products, summed in another order, over 16-byte channel vectors.  This kernel
+// writes xs in the engine's dtype straight from the caller's image (fp32 / bf16 / fp16, NCHW or channels_last): it replaces the cast
+// + layout pass the engine ran on its input anyway.  One thread per output pixel: 2 x 24 contiguous input bytes (channels_last fp32)
+// or 6 x 8 (NCHW), 32 contiguous output bytes.  HBM-bound: sizeof(in) * 3 * H * W read, 2 * 16 * H/2 * W/2 written per image.
+template <typename TIn, typename TOut>
+__global__ __launch_bounds__(256) void stem_pack_kernel(const void *x, void *out, uint32_t batch, uint32_t height, uint32_t width,
+                                                        uint32_t channels_last, FastDiv by_wo, FastDiv by_howo) {
+  const uint32_t ho = height / 2, wo = width / 2;
+  const uint64_t total = static_cast<uint64_t>(batch) * ho * wo;
+  for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < total; i += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
+    uint32_t rem, xo;
+    const uint32_t n = fastdivmod(static_cast<uint32_t>(i), by_howo, &rem);   // (batch * ho * wo < 2^32: checked by the host)
+    const uint32_t yo = fastdivmod(rem, by_wo, &xo);
+    float v[12];
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy) {
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const uint64_t yy = 2 * yo + dy, xx = 2 * xo + dx;
+          const uint64_t off = channels_last ? ((static_cast<uint64_t>(n) * height + yy) * width + xx) * 3 + c
+                                             : ((static_cast<uint64_t>(n) * 3 + c) * height + yy) * width + xx;
+          v[(dy * 2 + dx) * 3 + c] = load_raw<TIn>(x, off);
+        }
+      }
+    }
+    vuint4 o0, o1;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o0[e] = float_to_storage<TOut>(v[2 * e]) | (float_to_storage<TOut>(v[2 * e + 1]) << 16);
+    o1[0] = float_to_storage<TOut>(v[8]) | (float_to_storage<TOut>(v[9]) << 16);
+    o1[1] = float_to_storage<TOut>(v[10]) | (float_to_storage<TOut>(v[11]) << 16);
+    o1[2] = 0u;
+    o1[3] = 0u;
+    vuint4 *dst = reinterpret_cast<vuint4 *>(static_cast<uint16_t *>(out) + i * 16);
+    dst[0] = o0;
+    dst[1] = o1;
+  }
+}
+
 }  // namespace odtk

@@ -711,6 +711,23 @@ int decode_single(bool rotated, int batch, const void *const *inputs, void *cons
 
 }  // namespace
 
+template <typename TIn>
+int stem_pack_launch(const void *x, void *out, int batch, int height, int width, int channels_last, int out_dtype, hipStream_t stream) {
+  const unsigned long long total = 1ull * batch * (height / 2) * (width / 2);
+  unsigned long long blocks = (total + 255) / 256;
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  const odtk::FastDiv by_wo = odtk::fastdiv_make(static_cast<uint32_t>(width / 2));
+  const odtk::FastDiv by_howo = odtk::fastdiv_make(static_cast<uint32_t>(height / 2) * static_cast<uint32_t>(width / 2));
+  if (out_dtype == ODTK_BF16)
+    timed_launch(ODTK_KERNEL_STEM_PACK, odtk::stem_pack_kernel<TIn, odtk::BF16>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, x, out,
+                 static_cast<uint32_t>(batch), static_cast<uint32_t>(height), static_cast<uint32_t>(width), static_cast<uint32_t>(channels_last), by_wo, by_howo);
+  else
+    timed_launch(ODTK_KERNEL_STEM_PACK, odtk::stem_pack_kernel<TIn, odtk::F16>, dim3(static_cast<unsigned>(blocks)), dim3(256), 0, stream, x, out,
+                 static_cast<uint32_t>(batch), static_cast<uint32_t>(height), static_cast<uint32_t>(width), static_cast<uint32_t>(channels_last), by_wo, by_howo);
+  ODTK_HIP_TRY(hipGetLastError());
+  return ODTK_OK;
+}
+
 extern "C" {
 
 const char *odtk_version(void) { return "odtk-hip 0.1 (gfx950)"; }
@@ -1060,6 +1077,20 @@ int odtk_upsample_nearest2x(const void *x, void *out, int batch_size, int height
                odtk::fastdiv_make(static_cast<uint32_t>(groups)), odtk::fastdiv_make(2u * width), odtk::fastdiv_make(2u * height));
   ODTK_HIP_TRY(hipGetLastError());
   return ODTK_OK;
+}
+
+int odtk_stem_pack(const void *x, void *out, int batch_size, int height, int width, int in_dtype, int channels_last, int out_dtype,
+                   void *stream) {
+  if (!x || !out || batch_size <= 0 || height <= 0 || width <= 0 || (height & 1) || (width & 1)) return ODTK_ERR_INVALID;
+  if (channels_last != 0 && channels_last != 1) return ODTK_ERR_INVALID;
+  if (in_dtype != ODTK_F32 && in_dtype != ODTK_BF16 && in_dtype != ODTK_F16) return ODTK_ERR_UNSUPPORTED;
+  if (out_dtype != ODTK_BF16 && out_dtype != ODTK_F16) return ODTK_ERR_UNSUPPORTED;
+  if (reinterpret_cast<uintptr_t>(out) & 15u) return ODTK_ERR_INVALID;
+  if (1ull * batch_size * (height / 2) * (width / 2) > 0xf0000000ull) return ODTK_ERR_INVALID;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (in_dtype == ODTK_F32) return stem_pack_launch<odtk::F32>(x, out, batch_size, height, width, channels_last, out_dtype, s);
+  if (in_dtype == ODTK_BF16) return stem_pack_launch<odtk::BF16>(x, out, batch_size, height, width, channels_last, out_dtype, s);
+  return stem_pack_launch<odtk::F16>(x, out, batch_size, height, width, channels_last, out_dtype, s);
 }
 
 int odtk_gemm_init(const char *hipblaslt_path) { return odtk::lt::init(hipblaslt_path); }

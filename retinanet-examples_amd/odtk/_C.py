@@ -110,6 +110,8 @@ _SIGNATURES = {
     'odtk_prefilter_thresholds': (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int, ctypes.c_float, _vp, _vp]),
     'odtk_upsample_nearest2x': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                ctypes.c_int, ctypes.c_void_p]),
+    'odtk_stem_pack': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                      ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     'odtk_gemm_init': (ctypes.c_int, [ctypes.c_char_p]),
     'odtk_gemm_bias_act': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                           ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
@@ -119,7 +121,8 @@ _SIGNATURES = {
 
 KERNEL_NAMES = ('prefilter_scan_kernel', 'select_decode_kernel', 'nms_kernel', 'iou_pairs_kernel', 'bias_act_kernel',
                 'snap_to_anchors_kernel', 'gemm_bias_act', 'retina_loss_kernel', 'select_hist_kernel', 'select_filter_kernel',
-                'nms_first_round_kernel', 'rotated_sup_matrix_kernel', 'bias_act_maxpool_kernel', 'upsample_nearest2x_kernel')
+                'nms_first_round_kernel', 'rotated_sup_matrix_kernel', 'bias_act_maxpool_kernel', 'upsample_nearest2x_kernel',
+                'stem_pack_kernel')
 # HBM bytes the epilogue entry points move, per kernel name, while `traffic_count` is on (bench.py's epilogue_roofline: the
 # algorithmic bytes of every call -- each element read once and written once, + the skip input -- divided by the kernel time)
 traffic_count = False
@@ -725,6 +728,28 @@ def upsample2x(x):
     return out
 
 
+def stem_pack(x, dtype):
+    """2x2 space-to-depth pack of the network input [B, 3, H, W] (float32 / bfloat16 / float16, NCHW- or channels_last-contiguous, H and
+    W even) into [B, 16, H/2, W/2] channels_last of `dtype` (bf16 / fp16): channel (dy*2+dx)*3+c of pixel (y, x) is x[:, c, 2y+dy, 2x+dx],
+    channels 12..15 are zero (include/odtk_hip.h: odtk_stem_pack).  The cast and the layout change of the input, in one pass."""
+    if not x.is_cuda or x.dim() != 4 or x.shape[1] != 3 or x.dtype not in _DTYPES or dtype not in (torch.bfloat16, torch.float16):
+        raise RuntimeError('stem_pack: x must be a [B, 3, H, W] CUDA tensor of float32/bfloat16/float16, dtype bfloat16/float16')
+    n, _, h, w = x.shape
+    if h % 2 or w % 2:
+        raise RuntimeError('stem_pack: height and width must be even')
+    if x.is_contiguous():
+        cl = 0
+    elif x.is_contiguous(memory_format=torch.channels_last):
+        cl = 1
+    else:
+        raise RuntimeError('stem_pack: x must be contiguous (NCHW or channels_last)')
+    out = torch.empty((n, 16, h // 2, w // 2), dtype=dtype, device=x.device, memory_format=torch.channels_last)
+    with torch.cuda.device(x.device):
+        stream = torch.cuda.current_stream(x.device).cuda_stream
+        _check(library().odtk_stem_pack(x.data_ptr(), out.data_ptr(), n, h, w, _DTYPES[x.dtype], cl, _DTYPES[dtype], stream), 'stem_pack')
+    return out
+
+
 _GEMM_WORKSPACE = {}
 _GEMM_READY = []
 
@@ -796,6 +821,8 @@ def conv_library():
             lib = ctypes.CDLL(_CONV_LIB_PATH)
             lib.odtk_conv_bias_act.restype = ctypes.c_int
             lib.odtk_conv_bias_act.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] * 13 + [ctypes.c_void_p]
+            lib.odtk_conv_bias_act_pads.restype = ctypes.c_int
+            lib.odtk_conv_bias_act_pads.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] * 15 + [ctypes.c_void_p]
             lib.odtk_conv_last_plan.restype = ctypes.c_char_p
             lib.odtk_conv_last_plan.argtypes = []
             lib.odtk_conv_instance_count.restype = ctypes.c_int
@@ -830,12 +857,14 @@ def conv_bias_act(x, weight, bias, stride=(1, 1), padding=(1, 1), relu=True):
         raise RuntimeError('conv_bias_act: bias must be a CUDA vector of length Cout in the dtype of x')
     sh, sw = (stride, stride) if isinstance(stride, int) else stride
     ph, pw = (padding, padding) if isinstance(padding, int) else padding
-    ho, wo = (h + 2 * ph - kh) // sh + 1, (w + 2 * pw - kw) // sw + 1
+    # padding (before, after) per dimension: ((top, bottom), (left, right)) -- the space-to-depth stem needs (2, 1)
+    (ph0, ph1), (pw0, pw1) = [(p, p) if isinstance(p, int) else p for p in (ph, pw)]
+    ho, wo = (h + ph0 + ph1 - kh) // sh + 1, (w + pw0 + pw1 - kw) // sw + 1
     y = torch.empty((b, k, ho, wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
     with torch.cuda.device(x.device):
         stream = torch.cuda.current_stream(x.device).cuda_stream
-        _check(lib.odtk_conv_bias_act(y.data_ptr(), x.data_ptr(), weight.data_ptr(), bias.data_ptr(), b, c, h, w, k, kh, kw,
-                                      sh, sw, ph, pw, _DTYPES[x.dtype], 1 if relu else 0, stream), 'conv_bias_act')
+        _check(lib.odtk_conv_bias_act_pads(y.data_ptr(), x.data_ptr(), weight.data_ptr(), bias.data_ptr(), b, c, h, w, k, kh, kw,
+                                           sh, sw, ph0, pw0, ph1, pw1, _DTYPES[x.dtype], 1 if relu else 0, stream), 'conv_bias_act')
     return y
 
 

@@ -71,6 +71,8 @@ class _Conv(nn.Module):
         # (which channel counts the instances take is the library's business: it says "unsupported" and the A/B records inf)
         self.library_ok = (not self.pointwise and conv.groups == 1 and tuple(conv.dilation) == (1, 1)
                            and dtype in (torch.bfloat16, torch.float16) and w.shape[1] % 8 == 0)
+        self.strided_ok = (self.pointwise and tuple(conv.stride) != (1, 1) and dtype in (torch.bfloat16, torch.float16)
+                           and w.shape[1] % 8 == 0)
         self.zero_bias = None
         self.route = {}                                                 # input shape -> (use the library, us library, us miopen + epilogue)
 
@@ -103,6 +105,10 @@ class _Conv(nn.Module):
             y = y.contiguous(memory_format=torch.channels_last)
         return _C.bias_act_(y, self.bias, residual, self.relu)
 
+    def _copy_then_gemm(self, x, residual=None):
+        x = x[:, :, ::self.stride[0], ::self.stride[1]].contiguous(memory_format=torch.channels_last)
+        return _C.gemm_bias_act(x, self.weight, self.bias, residual, self.relu)
+
     def _one_pass(self, x):
         return _C.conv_bias_act(x, self.weight, self.bias_lp, self.stride, self.padding, self.relu)
 
@@ -131,7 +137,16 @@ class _Conv(nn.Module):
     def forward(self, x, residual=None):
         if self.pointwise and _C.gemm_available():
             if tuple(self.stride) != (1, 1):
-                x = x[:, :, ::self.stride[0], ::self.stride[1]].contiguous(memory_format=torch.channels_last)
+                # a strided 1x1 convolution (the downsample branches): the GEMM wants the subsampled pixels as a dense matrix -- a
+                # copy pass of its own (29 us each at bs 8) -- the convolution library reads them in place; routed by the plan pass
+                if (residual is None and self.strided_ok and _Conv.use_conv_library and x.is_cuda
+                        and x.is_contiguous(memory_format=torch.channels_last) and _C.conv_available()):
+                    route = self.route.get(tuple(x.shape))
+                    if route is None and _Conv.planning and not torch.cuda.is_current_stream_capturing():
+                        route = self.route[tuple(x.shape)] = self._measure(x, self._copy_then_gemm, self._one_pass)
+                    if route is not None and route[0]:
+                        return self._one_pass(x)
+                return self._copy_then_gemm(x, residual)
             return _C.gemm_bias_act(x, self.weight, self.bias, residual, self.relu)
         if (residual is None and self.library_ok and _Conv.use_conv_library and x.is_cuda
                 and x.is_contiguous(memory_format=torch.channels_last) and _C.conv_available()):
@@ -195,6 +210,24 @@ class FusedRetinaNet(nn.Module):
         self.dtype = dtype
         self.model = [model]                                            # not a submodule: shares anchors / config
         self.stem = _Conv(net.conv1, net.bn1, True, dtype)
+        # the stem as a 4x4 / stride-1 convolution over the 2x2 space-to-depth image of the input (16-byte channel vectors instead
+        # of 3-element ones; include/odtk_hip.h: odtk_stem_pack): same products, re-indexed weights
+        self.stem_s2d = None
+        c1 = net.conv1
+        if (tuple(c1.kernel_size), tuple(c1.stride), tuple(c1.padding), c1.in_channels, c1.groups) == ((7, 7), (2, 2), (3, 3), 3, 1) \
+                and dtype in (torch.bfloat16, torch.float16):
+            w = self.stem.weight.float()
+            w4 = torch.zeros(w.shape[0], 16, 4, 4, device=w.device)
+            for dy in range(2):
+                for dx in range(2):
+                    for r4 in range(4):
+                        for s4 in range(4):
+                            r, s_ = 2 * r4 + dy - 1, 2 * s4 + dx - 1
+                            if 0 <= r < 7 and 0 <= s_ < 7:
+                                w4[:, (dy * 2 + dx) * 3:(dy * 2 + dx) * 3 + 3, r4, s4] = w[:, :, r, s_]
+            self.register_buffer('stem_w4', w4.to(dtype).contiguous(memory_format=torch.channels_last))
+            self.register_buffer('stem_zero_bias', torch.zeros(w.shape[0], dtype=dtype, device=w.device))
+            self.stem_s2d = {}                                          # input (shape, dtype, layout) -> (use it, us s2d, us direct)
         self.layers = nn.ModuleList([nn.ModuleList([_Block(b, dtype) for b in layer])
                                      for layer in (net.layer1, net.layer2, net.layer3, net.layer4)])
         self.outputs = list(net.outputs)
@@ -219,8 +252,31 @@ class FusedRetinaNet(nn.Module):
         self._thresholds = {}                                           # score threshold -> the prefilter's table for cls_head[-1].bias
         self.max_graphs = 8
 
+    def _stem_direct(self, x):
+        x = x.to(self.dtype).contiguous(memory_format=torch.channels_last)
+        return self.stem.conv_then_pool(x)                               # conv1 -> (bias + ReLU + maxpool, one pass)
+
+    def _stem_packed(self, x):
+        xs = _C.stem_pack(x, self.dtype)                                 # cast + space-to-depth, one pass over the input
+        y = _C.conv_bias_act(xs, self.stem_w4, self.stem_zero_bias, 1, ((2, 1), (2, 1)), False)
+        return _C.bias_act_maxpool(y, self.stem.bias, self.stem.relu)    # the stem's bias + ReLU ride in the pooling pass
+
+    def _stem(self, x):
+        """conv1 -> bn1 -> ReLU -> maxpool on the RAW input (any float dtype, NCHW or channels_last)."""
+        if (self.stem_s2d is not None and _Conv.use_conv_library and x.is_cuda and x.dim() == 4 and x.shape[1] == 3
+                and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0 and x.dtype in _C._DTYPES and _C.conv_available()
+                and (x.is_contiguous() or x.is_contiguous(memory_format=torch.channels_last))):
+            key = (tuple(x.shape), x.dtype, x.is_contiguous())
+            route = self.stem_s2d.get(key)
+            if route is None and _Conv.planning and not torch.cuda.is_current_stream_capturing():
+                route = self.stem_s2d[key] = self.stem._measure(x, self._stem_direct, self._stem_packed)
+            if route is not None and route[0]:
+                return self._stem_packed(x)
+        return self._stem_direct(x)
+
     def features(self, x):
-        x = self.stem.conv_then_pool(x)                                  # conv1 -> (bias + ReLU + maxpool, one pass)
+        """x: the network input as the caller has it (the stem owns the cast to the engine's dtype and layout)."""
+        x = self._stem(x)
         feats = []
         for level, layer in enumerate(self.layers, start=2):
             for block in layer:
@@ -296,13 +352,11 @@ class FusedRetinaNet(nn.Module):
     # torch.autocast region -- which is how Model.forward picks the engine's dtype -- must not re-cast anything.
     def heads(self, x):
         with torch.autocast(x.device.type, enabled=False):
-            x = x.to(self.dtype).contiguous(memory_format=torch.channels_last)
             return self._towers(self.features(x), True)
 
     def heads_without_last_bias(self, x):
         """Head tensors as the last convolutions wrote them (bias NOT added) + the two bias vectors."""
         with torch.autocast(x.device.type, enabled=False):
-            x = x.to(self.dtype).contiguous(memory_format=torch.channels_last)
             cls, box = self._towers(self.features(x), False)
         return cls, box, self.cls_head[-1].bias, self.box_head[-1].bias
 
@@ -355,15 +409,17 @@ class FusedRetinaNet(nn.Module):
         streams, _Conv.planning, self.level_streams = self.level_streams, True, False
         try:
             with torch.autocast(x.device.type, enabled=False):
-                t = x.to(self.dtype).contiguous(memory_format=torch.channels_last)
-                self._towers(self.features(t), False)
+                self._towers(self.features(x), False)
         finally:
             _Conv.planning, self.level_streams = False, streams
         self._planned.add(key)
 
     def conv_routes(self):
         """{layer name: {input shape: (library?, us library, us two-pass)}} of the plan passes so far (measurement records)."""
-        return {name: dict(mod.route) for name, mod in self.named_modules() if isinstance(mod, _Conv) and mod.route}
+        routes = {name: dict(mod.route) for name, mod in self.named_modules() if isinstance(mod, _Conv) and mod.route}
+        if self.stem_s2d:
+            routes['stem (cast + conv1 + pool: space-to-depth form vs direct)'] = {k[0]: v for k, v in self.stem_s2d.items()}
+        return routes
 
     @torch.no_grad()
     def forward(self, x):

@@ -110,3 +110,47 @@ def test_engine_plan_keeps_the_detections():
     for a, b in zip(c0 + b0, c1 + b1):
         scale = float(a.float().abs().max())
         assert float((a.float() - b.float()).abs().max()) <= 0.03 * scale + 1e-3
+
+
+@pytest.mark.parametrize('in_dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('layout', ['nchw', 'channels_last'])
+def test_stem_pack_is_space_to_depth_plus_cast(in_dtype, layout):
+    from odtk import _C
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 3, 64, 96, generator=g).to(in_dtype).cuda()
+    if layout == 'channels_last':
+        x = x.contiguous(memory_format=torch.channels_last)
+    for dtype in (torch.bfloat16, torch.float16):
+        got = _C.stem_pack(x, dtype)
+        b, _, h, w = x.shape
+        ref = x.float().view(b, 3, h // 2, 2, w // 2, 2).permute(0, 3, 5, 1, 2, 4).reshape(b, 12, h // 2, w // 2)
+        ref = torch.cat([ref, torch.zeros(b, 4, h // 2, w // 2, device=x.device)], 1).to(dtype)
+        assert got.shape == ref.shape and got.dtype == dtype and got.is_contiguous(memory_format=torch.channels_last)
+        assert torch.equal(got, ref.contiguous(memory_format=torch.channels_last))       # a cast and a permutation: bit for bit
+
+
+def test_stem_in_space_to_depth_form_equals_the_direct_stem():
+    """conv7x7/s2/p3 over 3 channels == conv4x4/s1/pad(2, 1) over the packed input with the re-indexed weights: the same products in
+    another order (fp32 accumulation, one rounding to bf16 of the same sums -> equal up to an ulp where the order matters)."""
+    from odtk import fused
+    from odtk.model import Model
+    torch.manual_seed(0)
+    model = Model('ResNet18FPN', classes=4).cuda().eval()
+    model.initialize(None)
+    e = fused.FusedRetinaNet(model, torch.bfloat16)
+    assert e.stem_s2d is not None
+    x = torch.randn(2, 3, 128, 192, device='cuda')
+    with torch.no_grad():
+        direct = e._stem_direct(x)
+        packed = e._stem_packed(x)
+    assert direct.shape == packed.shape
+    diff = (direct.float() - packed.float()).abs()
+    scale = float(direct.float().abs().max())
+    assert float(diff.max()) <= 2.0 ** -7 * scale + 1e-3, (float(diff.max()), scale)
+    # (about half of the outputs differ by one bf16 ulp: the two convolutions sum the same products in different orders)
+    # channels_last input and an fp16 engine take the same route
+    e16 = fused.FusedRetinaNet(model, torch.float16)
+    xc = x.contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        d16, p16 = e16._stem_direct(xc), e16._stem_packed(xc)
+    assert float((d16.float() - p16.float()).abs().max()) <= 2.0 ** -10 * float(d16.float().abs().max()) + 1e-3

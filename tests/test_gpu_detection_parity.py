@@ -221,9 +221,11 @@ def test_engines_agree_with_fp32_eager_plus_oracle():
     assert ap['reference'] > 0.5, ap
     assert abs(ap['engine_fp32'] - ap['reference']) <= 2e-3, ap          # the same detector
     # measured on MI355X (round 2): reference 1.0, engine_fp32 1.0, engine_bf16 0.9833, eager autocast bf16 0.7668
-    assert abs(ap['engine_bf16'] - ap['reference']) <= 0.05, ap          # bf16 arithmetic of the timed path
+    # (tolerances: largest deviation measured over three seeds and three rounds + a margin below one flipped object:
+    #  profiles/r05_detection_ap_seeds.txt -- bf16 0.037, fp16 0.029 on the hard seed, 0.000 on this one)
+    assert abs(ap['engine_bf16'] - ap['reference']) <= 0.045, ap         # bf16 arithmetic of the timed path
     assert ap['eager_autocast_bf16'] < ap['engine_bf16'] - 0.1, ap       # the eager graph's damped logits cost AP
     # round 3 (ADVICE): `infer()`'s mixed precision is fp16 like the reference's -- three more mantissa bits than bf16
     assert ap['engine_fp16'] >= ap['engine_bf16'] - 0.005, ap
-    assert abs(ap['engine_fp16'] - ap['reference']) <= 0.05, ap
+    assert abs(ap['engine_fp16'] - ap['reference']) <= 0.03, ap
     assert ap['eager_autocast_fp16'] > ap['eager_autocast_bf16'], ap     # the fallback for models without a fused engine
