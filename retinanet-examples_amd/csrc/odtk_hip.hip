@@ -298,8 +298,6 @@ int decode_levels_impl(int batch, int n_levels, const odtk_level_t *levels, int 
     da.lv[l].width = levels[l].width;
     da.lv[l].stride = static_cast<float>(levels[l].stride);
     da.lv[l].channels_last = static_cast<uint32_t>(levels[l].channels_last);
-    da.lv[l].by_hw = odtk::fastdiv_make(static_cast<uint32_t>(levels[l].height) * levels[l].width);
-    da.lv[l].by_w = odtk::fastdiv_make(static_cast<uint32_t>(levels[l].width));
     da.lv[l].cls_bias = levels[l].cls_bias;
     da.lv[l].box_bias = levels[l].box_bias;
     std::memcpy(da.lv[l].anchors, levels[l].anchors, sizeof(float) * 4 * A);
@@ -327,7 +325,6 @@ int decode_levels_impl(int batch, int n_levels, const odtk_level_t *levels, int 
   da.aligned = aligned ? 1u : 0u;
   da.raw_lo = sa.raw_lo;
   da.by_channels = odtk::fastdiv_make(static_cast<uint32_t>(A) * C);
-  da.by_classes = odtk::fastdiv_make(static_cast<uint32_t>(C));
   da.out_scores = static_cast<float *>(outputs[0]);
   da.out_boxes = static_cast<float *>(outputs[1]);
   da.out_classes = static_cast<float *>(outputs[2]);

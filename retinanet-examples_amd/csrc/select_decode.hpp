@@ -68,7 +68,6 @@ struct DecodeLevel {
   float stride;
   uint32_t channels_last;
   uint32_t pad_;
-  FastDiv by_hw, by_w;   // H*W and W (decode: flat index -> anchor, class, y, x by multiply-high, csrc/fastdiv.hpp)
   const float *cls_bias; // [A*C] added to the cls head values (logits) before the sigmoid, or null
   const float *box_bias; // [A*NB] added to the gathered deltas, or null
   float anchors[ODTK_MAX_ANCHORS * 4];
@@ -87,7 +86,6 @@ struct DecodeArgs {
   uint32_t aligned;                           // every image of every level starts on a 16-byte boundary (vector loads of raw spans)
   float raw_lo;                               // logits: conservative lower bound of a candidate's logit (as the prefilter's)
   FastDiv by_channels;                        // A*C
-  FastDiv by_classes;                         // C
   float *out_scores;     // [batch, n_levels*top_n]
   float *out_boxes;      // [batch, n_levels*top_n, NB]
   float *out_classes;    // [batch, n_levels*top_n]
@@ -97,8 +95,6 @@ struct DecodeArgs {
   float thresh;
   unsigned long long *trace;   // debug (odtk_debug_set_trace): 8 words per segment, or null
 };
-
-static_assert(sizeof(DecodeArgs) <= 4096, "kernel arguments of select_decode_kernel must stay below 4 KiB");
 
 // ---- key sources -------------------------------------------------------------------------
 struct LdsSource {    // keys already gathered into LDS
@@ -133,25 +129,6 @@ struct FlatSource {
       }
       f(k, v);
     }
-  }
-};
-
-// The survivor list with its first slots already in registers (requested before the list's length was known, together with the
-// length: the finisher's one round trip, see the kernel) and the rest, if any, walked as FlatSource does.
-template <int kEarly>
-struct EarlySource {
-  const uint64_t (&head)[kEarly];
-  uint32_t n_head;                   // slots the head covers: slot u * 1024 + tid is head[u] of thread tid
-  FlatSource rest;
-  uint32_t count;                    // keys in the whole list
-  template <typename F>
-  __device__ __forceinline__ void for_each(F &&f) const {
-    bool v[kEarly];
-    const uint32_t n = count < n_head ? count : n_head;
-#pragma unroll
-    for (int u = 0; u < kEarly; ++u) v[u] = static_cast<uint32_t>(u) * kSelThreads + threadIdx.x < n;
-    f(head, v);
-    if (count > n_head) rest.for_each(f);                                  // (block-uniform)
   }
 };
 
@@ -435,7 +412,8 @@ __device__ __forceinline__ void sort_keys_desc(uint64_t *s_keys, uint32_t n_vali
 // place in the union of its run and the partner run is its place in its own run plus the number of partner keys above
 // it -- one binary search in LDS (keys are unique: no ties) -- instead of the 34 further compare-exchange stages of the
 // network, ten of them through LDS with a barrier each.  Measured: 7.7 us for the full network, see DESIGN.md.
-// s_buf must hold 2 * 1024 keys (merge_sort_ranked<1>; <2>: twice that).  The work follows n_valid, not the capacity: slots beyond n_valid exist only inside the wave that
+// s_buf must hold 2 * 1024 keys; returns where the sorted keys are (s_buf or s_buf + 1024): n_valid of them, what lies
+// behind is unspecified.  The work follows n_valid, not the capacity: slots beyond n_valid exist only inside the wave that
 // holds the last key (as values below every real key -- a real key's score word is never 0 -- for its network); waves
 // behind it skip the network, no padding is ever merged, and a search looks at the real keys of the partner run only --
 // the keys lie in [0, n_valid) before and after every level, so run r of length R holds clamp(n_valid - r R, 0, R) of
@@ -446,77 +424,100 @@ __device__ __forceinline__ uint32_t keys_in_run(uint32_t n_valid, uint32_t run, 
   return n_valid <= first ? 0u : (n_valid - first < R ? n_valid - first : R);
 }
 
-// A barrier that orders LDS traffic only: `__syncthreads()` is a workgroup fence + s_barrier, and on gfx9-family parts the
-// fence waits for vmcnt(0) -- every global load a thread has in flight -- before the barrier.  The sort below runs with the
-// candidates' box gathers in flight; its phases exchange data through LDS and nothing else.
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-// The sort proper, E keys per thread (E = 1: up to 1024 keys, E = 2: up to 2048; the wave-local networks and the binary searches
-// of a level are E independent chains: their shuffle / LDS latencies overlap).  s_buf holds the keys at [0, n_valid) and room
-// for 2 * E * 1024.  Nothing is returned in LDS: every thread learns the final RANK g[h] of the key v[h] it read (real[h]:
-// it read one) -- a consumer that needs the h-th best key's data does its work on v[h] and writes to slot g[h].
-//   pre()  is called once a thread's keys are FINAL -- after the wave-local networks, which move keys between lanes; from then on
-//          only a key's place changes --: the place to REQUEST per-key data from memory (loads only);
-//   mid()  two merge levels later (~2 us: the requests have arrived): the place for per-key arithmetic.
-template <int E, typename Pre, typename Mid>
-__device__ __forceinline__ void merge_sort_ranked(uint64_t *s_buf, uint32_t n_valid, uint64_t (&v)[E], bool (&real)[E], uint32_t (&g)[E],
-                                                  Pre &&pre, Mid &&mid) {
-  constexpr uint32_t kCap = static_cast<uint32_t>(E) * kSelThreads;
+__device__ __forceinline__ const uint64_t *merge_sort_1024(uint64_t *s_buf, uint32_t n_valid) {
   const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1);
+  const bool real = tid < n_valid;
+  uint64_t v = real ? s_buf[tid] : static_cast<uint64_t>(kSelThreads - tid);
+  if ((tid & ~static_cast<uint32_t>(kWave - 1)) < n_valid) {   // (wave-uniform)
 #pragma unroll
-  for (int h = 0; h < E; ++h) {
+    for (uint32_t k = 2; k <= static_cast<uint32_t>(kWave); k <<= 1) {
+#pragma unroll
+      for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+        const uint64_t p = shfl_xor_u64(v, static_cast<int>(j));
+        const bool take_max = ((lane & j) == 0) == ((lane & k) == 0);   // lower element of a descending pair
+        v = take_max ? (v > p ? v : p) : (v < p ? v : p);
+      }
+    }
+  }
+  __syncthreads();                                         // every thread has read its key
+  uint64_t *src = s_buf, *dst = s_buf + kSelThreads;
+  if (real) src[tid] = v;                                  // (after its wave's network slot `tid` holds a real key iff tid < n_valid)
+  __syncthreads();
+  uint32_t g = tid;                                        // where this thread's key sits
+#pragma unroll
+  for (uint32_t R = kWave; R < static_cast<uint32_t>(kSelThreads); R <<= 1) {
+    if (real) {
+      const uint32_t run = g / R, p = g - run * R;
+      const uint64_t *other = src + (run ^ 1u) * R;        // the partner run, descending
+      const uint32_t c = keys_in_run(n_valid, run ^ 1u, R);
+      uint32_t above = 0;                                  // partner keys above mine
+#pragma unroll
+      for (uint32_t step = R >> 1; step > 0; step >>= 1)
+        if (above + step <= c && other[above + step - 1] > v) above += step;
+      above += (above < c && other[above] > v) ? 1u : 0u;
+      g = (run >> 1) * 2 * R + p + above;
+      dst[g] = v;
+    }
+    __syncthreads();
+    uint64_t *t = src; src = dst; dst = t;
+  }
+  return src;
+}
+
+// The same for up to 2048 keys, two per thread (the two wave-local networks and the two binary searches of a level are
+// independent chains: their shuffle / LDS latencies overlap).  s_buf must hold 2 * 2048 keys; five merge levels.
+__device__ __forceinline__ const uint64_t *merge_sort_2048(uint64_t *s_buf, uint32_t n_valid) {
+  const uint32_t tid = threadIdx.x, lane = tid & (kWave - 1);
+  uint64_t v[2];
+  bool real[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
     const uint32_t i = tid + h * kSelThreads;
-    v[h] = i < n_valid ? s_buf[i] : static_cast<uint64_t>(kCap - i);
+    real[h] = i < n_valid;
+    v[h] = real[h] ? s_buf[i] : static_cast<uint64_t>(2 * kSelThreads - i);
   }
 #pragma unroll
-  for (int h = 0; h < E; ++h) {
+  for (int h = 0; h < 2; ++h) {
     if ((tid & ~static_cast<uint32_t>(kWave - 1)) + h * kSelThreads < n_valid) {   // (wave-uniform)
 #pragma unroll
       for (uint32_t k = 2; k <= static_cast<uint32_t>(kWave); k <<= 1) {
 #pragma unroll
         for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-          const bool take_max = ((lane & j) == 0) == ((lane & k) == 0);           // lower element of a descending pair
+          const bool take_max = ((lane & j) == 0) == ((lane & k) == 0);
           const uint64_t p = shfl_xor_u64(v[h], static_cast<int>(j));
           v[h] = take_max ? (v[h] > p ? v[h] : p) : (v[h] < p ? v[h] : p);
         }
       }
     }
   }
-  // from here on a key stays with its thread (only its PLACE changes): slot i of the wave-sorted array holds a real key iff
-  // i < n_valid (padding is below every real key -- a real key's score word is never 0)
+  __syncthreads();                                         // every thread has read its keys
+  uint64_t *src = s_buf, *dst = s_buf + 2 * kSelThreads;
+  uint32_t g[2] = {tid, tid + static_cast<uint32_t>(kSelThreads)};
 #pragma unroll
-  for (int h = 0; h < E; ++h) {
-    g[h] = tid + h * kSelThreads;
-    real[h] = g[h] < n_valid;
-  }
-  pre();
-  lds_barrier();                                           // every thread has read its keys
-  uint64_t *src = s_buf, *dst = s_buf + kCap;
-#pragma unroll
-  for (int h = 0; h < E; ++h)
+  for (int h = 0; h < 2; ++h)
     if (real[h]) src[g[h]] = v[h];
-  lds_barrier();
+  __syncthreads();
 #pragma unroll
-  for (uint32_t R = kWave; R < kCap; R <<= 1) {
-    if (R == 4u * kWave) mid();                            // two levels (~2 us) behind the requests
+  for (uint32_t R = kWave; R < 2u * kSelThreads; R <<= 1) {
 #pragma unroll
-    for (int h = 0; h < E; ++h) {
+    for (int h = 0; h < 2; ++h) {
       if (real[h]) {
         const uint32_t run = g[h] / R, p = g[h] - run * R;
-        const uint64_t *other = src + (run ^ 1u) * R;      // the partner run, descending
+        const uint64_t *other = src + (run ^ 1u) * R;
         const uint32_t c = keys_in_run(n_valid, run ^ 1u, R);
-        uint32_t above = 0;                                // partner keys above mine
+        uint32_t above = 0;
 #pragma unroll
         for (uint32_t step = R >> 1; step > 0; step >>= 1)
           if (above + step <= c && other[above + step - 1] > v[h]) above += step;
         above += (above < c && other[above] > v[h]) ? 1u : 0u;
         g[h] = (run >> 1) * 2 * R + p + above;
-        if (2 * R < kCap) dst[g[h]] = v[h];                // (the last level's placement is the rank: nobody reads the array)
+        dst[g[h]] = v[h];
       }
     }
-    if (2 * R < kCap) lds_barrier();
+    __syncthreads();
     uint64_t *t = src; src = dst; dst = t;
   }
+  return src;
 }
 
 // Given a histogram in s_hist (kRadixBins bins, REVERSED: bin 0 = largest digit) finds the bin in which the running
@@ -1003,18 +1004,6 @@ __global__ __launch_bounds__(kSelThreads) void select_decode_kernel(const Decode
     stamp2(6, part == 0);
     if (s_misc[26] != G - 1) return;                                       // (block-uniform) somebody else is last
     stamp2(8, true);
-    // Everything the finisher needs from memory in ONE round trip (agent-scope loads: ~2 us each way past this XCD's L2): the
-    // survivor count, the segment's histogram, and -- before the count that bounds them is known -- the first kEarly x 1024
-    // slots of the survivor list (at most G * publish of them can have been written; slots beyond the count are requested and
-    // ignored).  Round 4 read count + histogram, scanned, and only then walked the list: two round trips in a row.
-    constexpr int kEarly = 16;
-    const uint32_t early_bound = G * publish < static_cast<uint32_t>(kEarly) * kSelThreads ? G * publish : static_cast<uint32_t>(kEarly) * kSelThreads;
-    uint64_t early[kEarly];
-#pragma unroll
-    for (int u = 0; u < kEarly; ++u) {
-      const uint32_t i = static_cast<uint32_t>(u) * kSelThreads + tid;
-      early[u] = i < early_bound ? __hip_atomic_load(surv + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
-    }
     if (tid == 0) s_misc[27] = __hip_atomic_load(&S.surv_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (uint32_t i = tid; i < kRadixBins; i += kSelThreads) {
       s_hist[i * Lds::copies] = __hip_atomic_load(&S.hist[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1022,9 +1011,7 @@ __global__ __launch_bounds__(kSelThreads) void select_decode_kernel(const Decode
       for (int q = 1; q < Lds::copies; ++q) s_hist[i * Lds::copies + q] = 0;
     }
     __syncthreads();
-    const uint32_t n_surv = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(s_misc[27]));
-    // the survivor list as a source: its first slots from the registers above, the rest (dense inputs: G > 8) walked as before
-    const EarlySource<kEarly> all{early, early_bound, FlatSource{surv + early_bound, n_surv > early_bound ? n_surv - early_bound : 0u}, n_surv};
+    const FlatSource all{surv, static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(s_misc[27]))};
     SelState st{k_lo, k_hi, top_n, 0u, 0u};
     advance_state<Lds::copies>(st, s_hist, s_misc, L.n, 0ull, ~0ull);
     stamp2(9, true);
@@ -1041,135 +1028,72 @@ __global__ __launch_bounds__(kSelThreads) void select_decode_kernel(const Decode
   n_sort = narrow_in_lds(n_sort, sort_limit, h_lo, &unused_bins);
   stamp(2);
   if (a.trace && tid == 0) { a.trace[seg * 8 + 5] = n_total; a.trace[seg * 8 + 6] = n_sort; a.trace[seg * 8 + 7] = (static_cast<unsigned long long>(G) << 1) | has_raw; }
+  const uint64_t *sorted = s_keys;                                       // the first k_out are the answer
+  if (n_sort <= static_cast<uint32_t>(kSelThreads)) sorted = merge_sort_1024(s_keys, n_sort);
+  else if (n_sort <= 2u * kSelThreads) sorted = merge_sort_2048(s_keys, n_sort);
+  else sort_keys_desc<CAP>(s_keys, n_sort);
+  stamp(3);
 
-  // ---- sort, decode, write this segment's slice of the concatenated outputs ----
+  // ---- decode + write this segment's slice of the concatenated outputs ----
   const float stride = L.stride;
   const float lim_x = static_cast<float>(W) * stride - 1.0f;   // box.py:106  M = size*stride - 1
   const float lim_y = static_cast<float>(H) * stride - 1.0f;
   const typename T::storage *box_image = static_cast<const typename T::storage *>(L.box) + static_cast<uint64_t>(b) * A * NB * hw;
   const uint64_t out_row = static_cast<uint64_t>(b) * a.n_levels * top_n + static_cast<uint64_t>(l) * top_n;
-  // the key canonicalises -0.0 to +0.0 for ordering; fp32 score tensors emit the stored value itself
-  constexpr bool kStoredScore = !kLogits && sizeof(typename T::storage) == 4;
 
-  // Decode of one candidate in two halves, so that the memory half can be issued BEFORE the candidate's rank is known (the
-  // values do not depend on the rank, only the output slot does): `request` turns the key into (anchor, class, pixel) --
-  // multiply-high, no division -- and issues the loads; `finish` is box.py:100-111 + :302 in its written order.
-  struct Gathered {
-    typename T::storage raw[NB];   // the deltas as stored
-    float bias[NB];                // head bias of the box convolution (folded in: fp32 add), if any
-    float anc[4];
-    float score;                   // kStoredScore only
-    uint32_t pix, an, c;
-  };
-  auto request = [&](uint64_t key, Gathered &q) {
-    const uint32_t i = key_index(key);
-    const uint32_t plane = fastdivmod(i, L.by_hw, &q.pix);               // anchor * C + class
-    q.an = fastdivmod(plane, a.by_classes, &q.c);
+  for (uint32_t t = tid; t < top_n; t += kSelThreads) {
+    float score = 0.0f, cls = 0.0f;
+    float bx[NB];
 #pragma unroll
-    for (int k = 0; k < NB; ++k) {
-      const uint64_t off = L.channels_last ? static_cast<uint64_t>(q.pix) * (A * NB) + q.an * NB + k
-                                           : (static_cast<uint64_t>(q.an) * NB + k) * hw + q.pix;
-      q.raw[k] = box_image[off];
-      q.bias[k] = L.box_bias ? L.box_bias[q.an * NB + k] : 0.0f;
+    for (int k = 0; k < NB; ++k) bx[k] = 0.0f;
+    int32_t index = -1;
+    if (t < k_out) {
+      const uint64_t key = sorted[t];
+      const uint32_t i = key_index(key);
+      index = static_cast<int32_t>(i);
+      const uint32_t pix = i % hw;
+      const uint32_t x = pix % W, y = pix / W;
+      const uint32_t c = (i / hw) % C;
+      const uint32_t an = i / (hw * C);
+      cls = static_cast<float>(c);
+      if (!kLogits && sizeof(typename T::storage) == 4)
+        // the key canonicalises -0.0 to +0.0 for ordering; emit the stored value itself
+        score = load_raw<T>(cls_image, memory_offset(i, channels, hw, L.channels_last));
+      else
+        score = key_score(key);
+      float d[NB];
+#pragma unroll
+      for (int k = 0; k < NB; ++k) {
+        const uint64_t off = L.channels_last ? static_cast<uint64_t>(pix) * (A * NB) + an * NB + k
+                                             : (static_cast<uint64_t>(an) * NB + k) * hw + pix;
+        d[k] = load_raw<T>(box_image, off);
+        if (L.box_bias) d[k] += L.box_bias[an * NB + k];                  // head bias folded in (fp32 add)
+      }
+      // box.py:302  grid = [x, y, x, y] * stride + anchors[a]
+      const float *anc = L.anchors + 4 * an;
+      const float fx = static_cast<float>(x) * stride, fy = static_cast<float>(y) * stride;
+      const float ax1 = fx + anc[0], ay1 = fy + anc[1], ax2 = fx + anc[2], ay2 = fy + anc[3];
+      // box.py:100-103
+      const float w = ax2 - ax1 + 1.0f, h = ay2 - ay1 + 1.0f;
+      const float cx = ax1 + 0.5f * w, cy = ay1 + 0.5f * h;
+      const float pcx = d[0] * w + cx, pcy = d[1] * h + cy;
+      const float pw = exp_cr(d[2]) * w, ph = exp_cr(d[3]) * h;
+      // box.py:108-111
+      bx[0] = clamp_like_torch(pcx - 0.5f * pw, lim_x);
+      bx[1] = clamp_like_torch(pcy - 0.5f * ph, lim_y);
+      bx[2] = clamp_like_torch(pcx + 0.5f * pw - 1.0f, lim_x);
+      bx[3] = clamp_like_torch(pcy + 0.5f * ph - 1.0f, lim_y);
+      if constexpr (NB == 6) { bx[4] = d[4]; bx[5] = d[5]; }   // sin, cos pass through (decode_rotate.cu:152-162)
     }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) q.anc[k] = L.anchors[4 * q.an + k];
-    q.score = 0.0f;
-    if constexpr (kStoredScore) q.score = load_raw<T>(cls_image, L.channels_last ? q.pix * channels + plane : i);
-  };
-  auto finish = [&](uint64_t key, const Gathered &q, float (&bx)[NB], float &score, float &cls) {
-    cls = static_cast<float>(q.c);
-    score = kStoredScore ? q.score : key_score(key);
-    float d[NB];
-#pragma unroll
-    for (int k = 0; k < NB; ++k) {
-      d[k] = storage_to_float<T>(q.raw[k]);
-      if (L.box_bias) d[k] += q.bias[k];                                  // head bias folded in (fp32 add)
+    if (a.run_valid) {                                                   // (block-uniform; the list is sorted: positives are a prefix)
+      const uint64_t positive = __ballot(score > 0.0f);
+      if (positive && lane_id() == 0) atomicAdd(&s_misc[22], static_cast<uint32_t>(__popcll(positive)));
     }
-    uint32_t x;
-    const uint32_t y = fastdivmod(q.pix, L.by_w, &x);
-    // box.py:302  grid = [x, y, x, y] * stride + anchors[a]
-    const float fx = static_cast<float>(x) * stride, fy = static_cast<float>(y) * stride;
-    const float ax1 = fx + q.anc[0], ay1 = fy + q.anc[1], ax2 = fx + q.anc[2], ay2 = fy + q.anc[3];
-    // box.py:100-103
-    const float w = ax2 - ax1 + 1.0f, h = ay2 - ay1 + 1.0f;
-    const float cx = ax1 + 0.5f * w, cy = ay1 + 0.5f * h;
-    const float pcx = d[0] * w + cx, pcy = d[1] * h + cy;
-    const float pw = exp_cr(d[2]) * w, ph = exp_cr(d[3]) * h;
-    // box.py:108-111
-    bx[0] = clamp_like_torch(pcx - 0.5f * pw, lim_x);
-    bx[1] = clamp_like_torch(pcy - 0.5f * ph, lim_y);
-    bx[2] = clamp_like_torch(pcx + 0.5f * pw - 1.0f, lim_x);
-    bx[3] = clamp_like_torch(pcy + 0.5f * ph - 1.0f, lim_y);
-    if constexpr (NB == 6) { bx[4] = d[4]; bx[5] = d[5]; }   // sin, cos pass through (decode_rotate.cu:152-162)
-  };
-  auto emit = [&](uint32_t t, float score, float cls, const float (&bx)[NB], int32_t index) {
     a.out_scores[out_row + t] = score;
     a.out_classes[out_row + t] = cls;
 #pragma unroll
     for (int k = 0; k < NB; ++k) a.out_boxes[(out_row + t) * NB + k] = bx[k];
     if (a.out_indices) a.out_indices[out_row + t] = index;
-  };
-  // Up to 2048 keys (always, at the default top_n): a thread keeps its key(s) through the rank-merge sort, requests their
-  // deltas as soon as the wave-local networks have fixed them -- the gather's latency (~2 us from the Infinity Cache) passes
-  // under the first merge levels --
-  // and writes each finished box to the slot its key's rank names.  (Round 4 sorted, then read the sorted keys back, then
-  // gathered: 4 us behind the sort.)
-  auto sort_and_decode = [&](auto e_tag) {
-    constexpr int E = decltype(e_tag)::value;
-    uint64_t v[E];
-    bool real[E];
-    uint32_t rank[E];
-    Gathered q[E];
-    float bx[E][NB], score[E], cls[E];
-    merge_sort_ranked<E>(
-        s_keys, n_sort, v, real, rank,
-        [&] {
-#pragma unroll
-          for (int h = 0; h < E; ++h)
-            if (real[h]) request(v[h], q[h]);
-        },
-        [&] {
-#pragma unroll
-          for (int h = 0; h < E; ++h)
-            if (real[h]) finish(v[h], q[h], bx[h], score[h], cls[h]);
-        });
-    stamp(3);
-#pragma unroll
-    for (int h = 0; h < E; ++h) {
-      const bool out = real[h] && rank[h] < top_n;
-      if (out) emit(rank[h], score[h], cls[h], bx[h], static_cast<int32_t>(key_index(v[h])));
-      if (a.run_valid) {                                                 // (block-uniform)
-        const uint64_t positive = __ballot(out && score[h] > 0.0f);
-        if (positive && lane_id() == 0) atomicAdd(&s_misc[22], static_cast<uint32_t>(__popcll(positive)));
-      }
-    }
-  };
-  if (n_sort <= static_cast<uint32_t>(kSelThreads)) {
-    sort_and_decode(std::integral_constant<int, 1>{});
-  } else if (n_sort <= 2u * kSelThreads) {
-    sort_and_decode(std::integral_constant<int, 2>{});
-  } else {                                                               // top_n > 2048: the bitonic network, then the sorted prefix
-    sort_keys_desc<CAP>(s_keys, n_sort);
-    stamp(3);
-    for (uint32_t t = tid; t < k_out; t += kSelThreads) {                // (t < k_out <= top_n)
-      const uint64_t key = s_keys[t];
-      Gathered q;
-      float bx[NB], score, cls;
-      request(key, q);
-      finish(key, q, bx, score, cls);
-      emit(t, score, cls, bx, static_cast<int32_t>(key_index(key)));
-      if (a.run_valid) {
-        const uint64_t positive = __ballot(score > 0.0f);
-        if (positive && lane_id() == 0) atomicAdd(&s_misc[22], static_cast<uint32_t>(__popcll(positive)));
-      }
-    }
-  }
-  {                                                                      // the tail of the list: fewer candidates than top_n
-    float zero[NB];
-#pragma unroll
-    for (int k = 0; k < NB; ++k) zero[k] = 0.0f;
-    for (uint32_t t = k_out + tid; t < top_n; t += kSelThreads) emit(t, 0.0f, 0.0f, zero, -1);
   }
   if (a.run_valid) {
     __syncthreads();
