@@ -6,7 +6,7 @@
 #   2. rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, as MI355X_MICROARCH.md prescribes) on the
 #      post-processing alone, bf16 fused (what the step runs) and fp32 (the reference boundary) -> traffic JSON
 #   3. rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE on a short bench run -> MFMA utilisation of the convolutions
-R=${1:-r02}
+R=${1:-r05}
 OUT=gpurun_out/prof_$R
 mkdir -p $OUT
 export TMPDIR=/tmp
