@@ -135,6 +135,18 @@ int scan_image_major() {
   return v;
 }
 
+// select_decode's cooperative route (csrc/select_decode.hpp): how long a workgroup waits for the partners of its segment, in ticks
+// of the 100 MHz wall clock, before the segment falls back to the tournament.  ODTK_SELECT_COOP_TICKS: 0 = route off (A/B),
+// 1 = every barrier times out at once unless the partners are already there (exercises the fall-back), default 3000 = 30 us.
+uint32_t select_coop_ticks() {
+  static const uint32_t v = [] {
+    const char *e = std::getenv("ODTK_SELECT_COOP_TICKS");
+    const long x = e ? std::atol(e) : 3000;
+    return static_cast<uint32_t>(x < 0 ? 0 : (x > 1000000 ? 1000000 : x));
+  }();
+  return v;
+}
+
 // Tiles per prefilter workgroup for 16-bit inputs (ODTK_SCAN_SPAN = 1, 2 or 4; A/B measurements)
 uint32_t scan_span_tiles() {
   static const uint32_t v = [] {
@@ -323,6 +335,7 @@ int decode_levels_impl(int batch, int n_levels, const odtk_level_t *levels, int 
   da.budget = lay.budget;
   da.span_elems = lay.span_elems;
   da.aligned = aligned ? 1u : 0u;
+  da.coop_ticks = select_coop_ticks();
   da.raw_lo = sa.raw_lo;
   da.by_channels = odtk::fastdiv_make(static_cast<uint32_t>(A) * C);
   da.out_scores = static_cast<float *>(outputs[0]);

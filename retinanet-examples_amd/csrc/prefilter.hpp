@@ -56,12 +56,16 @@ constexpr int kSpanCap = kScanWaves * kWaveStage;   // keys of a span's region i
 constexpr uint32_t kListOverflow = 0xffffffffu;  // sub-list length: "more than kWaveStage raw hits, read the span's raw scores"
 
 // Per-(level, image) segment state of select_decode's multi-workgroup route; zeroed by the prefilter (workgroup of span 0).
+constexpr uint32_t kSelMaxParts = 64;   // workgroups per segment at most (= select_decode.hpp kMaxParts)
 struct SelSeg {
-  uint32_t surv_count;     // keys appended to the segment's survivor list
-  uint32_t arrived;        // workgroups that have appended theirs (ticket)
-  uint32_t pad_[2];
-  uint32_t hist[1 << 11];  // histogram (2048 equal bins of the key range, reversed) of the keys on the survivor list
+  uint32_t surv_count;     // keys appended to the segment's survivor list (tournament route)
+  uint32_t arrived;        // workgroups whose slice histogram is in `hist` (first ticket: the segment-local barrier counts on it)
+  uint32_t route;          // 0 undecided | kRouteCoop | kRouteTournament: ONE compare-and-swap decides for the whole segment
+  uint32_t arrived2;       // workgroups that have published their keys (second ticket: the last one finishes the segment)
+  uint32_t hist[1 << 11];  // histogram (2048 equal bins of the key range, reversed) of the segment's keys
+  uint32_t run_len[kSelMaxParts];   // cooperative route: keys in workgroup g's published (sorted) run
 };
+constexpr uint32_t kRouteCoop = 1, kRouteTournament = 2;
 
 struct ScanLevel {
   const void *cls;       // level tensor, [batch][n] in its own layout
@@ -257,7 +261,7 @@ __global__ __launch_bounds__(kScanThreads, (!kAligned ? 2 : sizeof(typename T::s
     uint4 *h = reinterpret_cast<uint4 *>(S->hist) + 2 * tid;   // 2048 words = 256 threads x 2 x 16 bytes
     h[0] = make_uint4(0u, 0u, 0u, 0u);
     h[1] = make_uint4(0u, 0u, 0u, 0u);
-    if (tid == 0) { S->surv_count = 0; S->arrived = 0; S->pad_[0] = 0; S->pad_[1] = 0; }
+    if (tid == 0) { S->surv_count = 0; S->arrived = 0; S->route = 0; S->arrived2 = 0; }
   }
 
   // With a bias the logit of element r is raw[r] + bias[r % channels] (channels_last, channels % kPer == 0, checked by

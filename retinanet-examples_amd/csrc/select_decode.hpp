@@ -84,6 +84,7 @@ struct DecodeArgs {
   uint32_t budget;                            // keys a workgroup of the tournament route may pass on (>= top_n, <= sort capacity)
   uint32_t span_elems;                        // elements per span
   uint32_t aligned;                           // every image of every level starts on a 16-byte boundary (vector loads of raw spans)
+  uint32_t coop_ticks;                        // cooperative route: 100 MHz ticks a workgroup waits for its segment's partners (0: route off)
   float raw_lo;                               // logits: conservative lower bound of a candidate's logit (as the prefilter's)
   FastDiv by_channels;                        // A*C
   float *out_scores;     // [batch, n_levels*top_n]
@@ -780,7 +781,7 @@ __global__ __launch_bounds__(kSelThreads) void select_decode_kernel(const Decode
   uint32_t *s_hist = reinterpret_cast<uint32_t *>(s_dyn_sel + Lds::hist);
   uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_dyn_sel + Lds::cnt);
   uint16_t *s_raw = reinterpret_cast<uint16_t *>(s_dyn_sel + Lds::raw);
-  __shared__ uint32_t s_misc[96];
+  __shared__ uint32_t s_misc[96];   // [0..18] scan scratch, [20] cursors, [22] positives, [25..28] tickets, [32..63] wave sums / flags, [64] route
   __shared__ unsigned long long s_range[2];
 
   int l = 0;
@@ -959,64 +960,199 @@ __global__ __launch_bounds__(kSelThreads) void select_decode_kernel(const Decode
   const uint32_t sort_size = sort_size_for(top_n);
   uint32_t n_sort;   // number of valid keys placed in s_keys
   uint64_t h_lo;     // ... all of them >= h_lo, their histogram over [max(h_lo, k_lo), k_hi] in s_hist
+  bool coop_done = false;   // (debug trace) the segment went the cooperative route
   if (G == 1) {
     n_sort = fetch(slice, 0ull, !has_raw && n_total <= static_cast<uint32_t>(CAP), &h_lo);
     stamp2(4, true);
   } else {
-    // Tournament: this slice's best keys -- top_n of them or a few more -- go to the segment's survivor list, their
-    // histogram (first digit: 2048 bins of [k_lo, k_hi]) is added to the segment's; the workgroup that arrives last finds the
-    // threshold in the segment's histogram and fetches only the survivors at or above it -- no pass over all of them.
-    // (Any key of the segment's top_n is in its slice's top_n.)  The slice is sized to fit the sort buffer (kKeysPerPart):
-    // fetched once, cut down in LDS.
+    // Several workgroups share the segment.  Two routes, decided for the WHOLE segment by one compare-and-swap:
+    //
+    // cooperative (round 5; the normal case): every slice fits LDS whole.  Each workgroup adds its slice's histogram (first
+    //   digit: 2048 bins of [k_lo, k_hi]) to the segment's and takes a ticket; a SEGMENT-LOCAL BARRIER -- a bounded spin on the
+    //   ticket counter: the <= 64 partners have consecutive workgroup ids and are dispatched in order, nobody waits for a
+    //   workgroup that waits for him -- makes the sum complete, and every workgroup derives the SAME threshold T from it (the
+    //   boundary bin of top_n).  It then publishes only ITS keys >= T -- ~top_n / G of them instead of its local top_n, no
+    //   narrowing pass of its own -- and takes a second ticket; the last one loads exactly the segment's ~1.3 x top_n keys >= T
+    //   (one round trip: the first 2048 / G slots of every list are requested together with the lengths) into the sort
+    //   buffer: no pass over ~G x top_n survivors.  (Publishing the lists SORTED and merging them by rank was built first: G
+    //   binary searches per key are as many LDS steps as the merge sort's five levels -- 22 us for the ranking alone.)
+    // tournament (rounds 3-4; the fall-back, taken when a slice could not be held whole, when the boundary bin holds more
+    //   than the ranking route sorts (plateaus), or when the barrier timed out -- other kernels may occupy the CUs a partner
+    //   needs): each workgroup publishes its LOCAL top `publish` >= top_n keys (any key of the segment's top_n is in its
+    //   slice's top_n); the last to arrive finds the threshold in the segment's histogram and fetches the survivors >= T.
+    // Both routes are exact for any input and nobody waits without a bound.
     uint32_t n_mine = fetch(slice, 0ull, !has_raw, &h_lo);
     stamp2(2, part == 0);
-    const uint32_t publish = 2 * sort_size < a.budget ? 2 * sort_size : a.budget;   // >= top_n
-    uint32_t first_bins;
-    n_mine = narrow_in_lds(n_mine, publish, h_lo, &first_bins);
-    if (h_lo > k_lo || first_bins == 0) {                                  // (rare) s_hist is not the first digit of what is left: redo it
-      const LdsFlat mine{s_keys, n_mine};
-      hist_pass<Lds::copies, false>(mine, k_lo, k_hi, s_hist, s_range);
-      first_bins = kRadixBins;
-    }
-    stamp2(4, part == 0);
+    const bool whole = !has_raw && h_lo == 0ull;              // s_keys = EVERY key of the slice, s_hist = their first digit
     SelSeg &S = a.sel[seg];
     uint64_t *surv = a.surv + L.surv_off + static_cast<uint64_t>(b) * P * a.budget;
-    if (tid == 0) s_misc[25] = n_mine ? atomicAdd(&S.surv_count, n_mine) : 0u;
-    for (uint32_t i = tid; i < first_bins; i += kSelThreads) {
+    if (!whole) {                                              // (rare) s_hist is a later digit / another range: redo the first digit
+      const LdsFlat mine{s_keys, n_mine};
+      hist_pass<Lds::copies, false>(mine, k_lo, k_hi, s_hist, s_range);
+    }
+    for (uint32_t i = tid; i < kRadixBins; i += kSelThreads) {
       uint32_t c = 0;
 #pragma unroll
       for (int q = 0; q < Lds::copies; ++q) c += s_hist[i * Lds::copies + q];
       if (c) atomicAdd(&S.hist[i], c);
     }
+    const bool coop_try = CAP == kSortCap && a.coop_ticks != 0 && !has_raw && sort_size <= 2u * kSelThreads;   // (block- AND segment-uniform)
+    if (!whole && coop_try && tid == 0) atomicCAS(&S.route, 0u, kRouteTournament);   // no global threshold from a partial histogram
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the histogram's atomics (and the veto) have been performed
     __syncthreads();
-    const uint32_t g0 = s_misc[25];
-    // Publish: WRITE-THROUGH stores (agent-scope atomic stores: `sc1`), drained, then the ticket; the reader uses `sc1`
-    // loads.  A release / acquire fence pair here (`__threadfence()`) writes back and invalidates the XCD's whole L2: measured
-    // 40-90 us per segment with 2-8 workgroups taking part (profiles/r04_select_trace_fences.txt); MI355X_MICROARCH.md
-    // "publish-large" prices the same choice at 8.2 vs 3.0 us.
-    for (uint32_t i = tid; i < n_mine; i += kSelThreads)
-      __hip_atomic_store(surv + g0 + i, s_keys[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // (the histogram's atomics too)
-    __syncthreads();
-    stamp2(5, part == 0);
-    if (tid == 0) s_misc[26] = atomicAdd(&S.arrived, 1u);
-    __syncthreads();
-    stamp2(6, part == 0);
-    if (s_misc[26] != G - 1) return;                                       // (block-uniform) somebody else is last
-    stamp2(8, true);
-    if (tid == 0) s_misc[27] = __hip_atomic_load(&S.surv_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    for (uint32_t i = tid; i < kRadixBins; i += kSelThreads) {
-      s_hist[i * Lds::copies] = __hip_atomic_load(&S.hist[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-      for (int q = 1; q < Lds::copies; ++q) s_hist[i * Lds::copies + q] = 0;
+    if (tid == 0) {
+      atomicAdd(&S.arrived, 1u);
+      uint32_t route = kRouteTournament;
+      if (coop_try) {
+        const unsigned long long t0 = wall_clock64();
+        bool all = false;
+        for (int spin = 0; spin < (1 << 16); ++spin) {        // (bounded twice: by the clock and by the trip count)
+          if (__hip_atomic_load(&S.arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= G) { all = true; break; }
+          if (__hip_atomic_load(&S.route, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;   // somebody decided already
+          if (wall_clock64() - t0 > a.coop_ticks) break;
+          __builtin_amdgcn_s_sleep(2);
+        }
+        const uint32_t want = all ? kRouteCoop : kRouteTournament;
+        const uint32_t prev = atomicCAS(&S.route, 0u, want);
+        route = prev == 0u ? want : prev;                      // (kRouteCoop implies that all G histograms are in: its setter saw them)
+      }
+      s_misc[64] = route;
     }
     __syncthreads();
-    const FlatSource all{surv, static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(s_misc[27]))};
-    SelState st{k_lo, k_hi, top_n, 0u, 0u};
-    advance_state<Lds::copies>(st, s_hist, s_misc, L.n, 0ull, ~0ull);
-    stamp2(9, true);
-    n_sort = fetch(all, all.count > sort_size ? st.lo : 0ull, true, &h_lo);
-    stamp2(10, true);
+    stamp2(4, part == 0);
+    uint32_t route = __builtin_amdgcn_readfirstlane(s_misc[64]);
+    bool hist_clobbered = false;                               // s_hist no longer holds this slice's own first digit
+    if (route == kRouteCoop) {
+      hist_clobbered = true;
+      // ---- the global threshold, the same in every workgroup of the segment ----
+      for (uint32_t i = tid; i < kRadixBins; i += kSelThreads) {
+        s_hist[i * Lds::copies] = __hip_atomic_load(&S.hist[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int q = 1; q < Lds::copies; ++q) s_hist[i * Lds::copies + q] = 0;
+      }
+      __syncthreads();
+      SelState st{k_lo, k_hi, top_n, 0u, 0u};
+      const uint32_t seg_total = advance_state<Lds::copies>(st, s_hist, s_misc, L.n, 0ull, ~0ull);
+      const uint64_t T64 = seg_total <= top_n ? 0ull : st.lo;                 // fewer than top_n candidates: all of them
+      const uint32_t n_glob = seg_total <= top_n ? seg_total : st.taken + st.in_bin;   // #{keys of the segment >= T64}
+      if (n_glob > 2u * kSelThreads) {
+        route = kRouteTournament;                              // a plateau wider than the ranking route sorts: every partner sees the same
+      } else {
+        // ---- my keys >= T, sorted, published as run `part` ----
+        if (tid == 0) s_misc[20] = 0;
+        for (uint32_t base = 0; base < n_mine; base += 4 * kSelThreads) {   // in-place compaction (narrow_in_lds's)
+          uint64_t mine[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const uint32_t i = base + u * kSelThreads + tid;
+            mine[u] = i < n_mine ? s_keys[i] : 0;
+          }
+          __syncthreads();
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const bool keep = mine[u] != 0 && mine[u] >= T64;
+            const uint32_t slot = wave_append_slot(&s_misc[20], keep);
+            if (keep) s_keys[slot] = mine[u];
+          }
+        }
+        __syncthreads();
+        const uint32_t n_g = __builtin_amdgcn_readfirstlane(s_misc[20]);   // (<= n_glob <= 2048)
+        uint64_t *my_run = surv + static_cast<uint64_t>(part) * a.budget;
+        for (uint32_t i = tid; i < n_g; i += kSelThreads) __hip_atomic_store(my_run + i, s_keys[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) __hip_atomic_store(&S.run_len[part], n_g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        stamp2(5, part == 0);
+        if (tid == 0) s_misc[26] = atomicAdd(&S.arrived2, 1u);
+        __syncthreads();
+        stamp2(6, part == 0);
+        if (s_misc[26] != G - 1) return;                       // (block-uniform) somebody else is last
+        stamp2(8, true);
+        // ---- the finisher: the G lists -- exactly the segment's keys >= T, n_glob <= 2048 of them -- into the sort buffer.
+        // ONE round trip: slot p of list q is requested for every p below `spec` = 2048 / G together with the lengths (a list
+        // longer than that -- a skewed segment -- takes a second, exact trip for its tail)
+        uint32_t *s_len = s_cnt, *s_off = s_cnt + kMaxParts;   // (the sub-list lengths are no longer needed)
+        const uint32_t spec = (2u * kSelThreads) / G;          // (G <= 64: >= 32)
+        uint64_t early[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const uint32_t f = tid + h * kSelThreads, q = f / spec, p = f - q * spec;
+          early[h] = q < G ? __hip_atomic_load(surv + static_cast<uint64_t>(q) * a.budget + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+        }
+        if (tid < G) s_len[tid] = __hip_atomic_load(&S.run_len[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (tid == 0) {
+          uint32_t acc = 0;
+          for (uint32_t q = 0; q < G; ++q) { s_off[q] = acc; acc += s_len[q]; }
+          s_off[G] = acc;
+        }
+        __syncthreads();
+        const uint32_t total = __builtin_amdgcn_readfirstlane(s_off[G]);      // (= n_glob)
+        bool tails = false;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const uint32_t f = tid + h * kSelThreads, q = f / spec, p = f - q * spec;
+          if (q < G) {
+            const uint32_t len = s_len[q];
+            if (p < len) s_keys[s_off[q] + p] = early[h];
+            tails = tails || (p == 0 && len > spec);
+          }
+        }
+        if (__syncthreads_or(tails ? 1 : 0)) {                 // (rare) the tails of the long lists
+          for (uint32_t q = 0; q < G; ++q) {
+            const uint32_t len = s_len[q];
+            for (uint32_t p = spec + tid; p < len; p += kSelThreads)
+              s_keys[s_off[q] + p] = __hip_atomic_load(surv + static_cast<uint64_t>(q) * a.budget + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          __syncthreads();
+        }
+        stamp2(9, true);
+        stamp2(10, true);
+        n_sort = total;                                        // (<= 2048: the standard sort below takes them as they are)
+        coop_done = true;
+      }
+    }
+    if (route != kRouteCoop) {
+      const uint32_t publish = 2 * sort_size < a.budget ? 2 * sort_size : a.budget;   // >= top_n
+      if (n_mine > publish && (hist_clobbered || !whole)) {   // narrow_in_lds reads s_hist as the first digit of s_keys over [h_lo | k_lo, k_hi]
+        const LdsFlat mine{s_keys, n_mine};
+        hist_pass<Lds::copies, false>(mine, h_lo > k_lo ? h_lo : k_lo, k_hi, s_hist, s_range);
+      }
+      uint32_t first_bins;
+      n_mine = narrow_in_lds(n_mine, publish, h_lo, &first_bins);
+      if (tid == 0) s_misc[25] = n_mine ? atomicAdd(&S.surv_count, n_mine) : 0u;
+      __syncthreads();
+      const uint32_t g0 = s_misc[25];
+      // Publish: WRITE-THROUGH stores (agent-scope atomic stores: `sc1`), drained, then the ticket; the reader uses `sc1`
+      // loads.  A release / acquire fence pair here (`__threadfence()`) writes back and invalidates the XCD's whole L2: measured
+      // 40-90 us per segment with 2-8 workgroups taking part (profiles/r04_select_trace_fences.txt); MI355X_MICROARCH.md
+      // "publish-large" prices the same choice at 8.2 vs 3.0 us.
+      for (uint32_t i = tid; i < n_mine; i += kSelThreads)
+        __hip_atomic_store(surv + g0 + i, s_keys[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      stamp2(5, part == 0);
+      if (tid == 0) s_misc[26] = atomicAdd(&S.arrived2, 1u);
+      __syncthreads();
+      stamp2(6, part == 0);
+      if (s_misc[26] != G - 1) return;                                     // (block-uniform) somebody else is last
+      stamp2(8, true);
+      // (the segment's histogram counts every key a slice held, not only the published ones: the threshold it gives has at
+      //  least top_n keys at or above it, all of them among the top_n of their slices, i.e. published)
+      if (tid == 0) s_misc[27] = __hip_atomic_load(&S.surv_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (uint32_t i = tid; i < kRadixBins; i += kSelThreads) {
+        s_hist[i * Lds::copies] = __hip_atomic_load(&S.hist[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int q = 1; q < Lds::copies; ++q) s_hist[i * Lds::copies + q] = 0;
+      }
+      __syncthreads();
+      const FlatSource all{surv, static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(s_misc[27]))};
+      SelState st{k_lo, k_hi, top_n, 0u, 0u};
+      advance_state<Lds::copies>(st, s_hist, s_misc, L.n, 0ull, ~0ull);
+      stamp2(9, true);
+      n_sort = fetch(all, all.count > sort_size ? st.lo : 0ull, true, &h_lo);
+      stamp2(10, true);
+    }
   }
   const uint32_t k_out = n_sort < top_n ? n_sort : top_n;                 // fewer than top_n candidates: all of them are here
   stamp(1);
@@ -1025,9 +1161,9 @@ __global__ __launch_bounds__(kSelThreads) void select_decode_kernel(const Decode
   // (up to 2048 keys the rank-merge sort takes them as they are: two per thread)
   const uint32_t sort_limit = sort_size <= 2u * kSelThreads ? 2u * kSelThreads : sort_size;
   uint32_t unused_bins;
-  n_sort = narrow_in_lds(n_sort, sort_limit, h_lo, &unused_bins);
+  n_sort = narrow_in_lds(n_sort, sort_limit, h_lo, &unused_bins);   // (cooperative route: <= 2048 keys, nothing to cut)
   stamp(2);
-  if (a.trace && tid == 0) { a.trace[seg * 8 + 5] = n_total; a.trace[seg * 8 + 6] = n_sort; a.trace[seg * 8 + 7] = (static_cast<unsigned long long>(G) << 1) | has_raw; }
+  if (a.trace && tid == 0) { a.trace[seg * 8 + 5] = n_total; a.trace[seg * 8 + 6] = n_sort; a.trace[seg * 8 + 7] = (static_cast<unsigned long long>(coop_done ? 1u : 0u) << 16) | (static_cast<unsigned long long>(G) << 1) | has_raw; }
   const uint64_t *sorted = s_keys;                                       // the first k_out are the answer
   if (n_sort <= static_cast<uint32_t>(kSelThreads)) sorted = merge_sort_1024(s_keys, n_sort);
   else if (n_sort <= 2u * kSelThreads) sorted = merge_sort_2048(s_keys, n_sort);

@@ -42,7 +42,7 @@ for l in range(5):
     r = fine[l * 8]
     rel = lambda k: ('%6.1f' % ((int(r[k]) - int(r[0])) / 100.0)) if int(r[k]) else '     -'
     print('  P%d: ' % (l + 3) + ' '.join(rel(k) for k in (1, 2, 3, 4, 5, 6)) + ' || ' + ' '.join(rel(k) for k in (8, 9, 10)),
-          ' G =', int(t[l * 8][7]) >> 1)
+          ' G =', (int(t[l * 8][7]) >> 1) & 0x7fff, '(cooperative route)' if (int(t[l * 8][7]) >> 16) & 1 else '')
 n = t[64 + 8:64 + 16]
 print('nms phases (us): compact | select round 0 | sort | chunks   consumed/K')
 for b in range(8):
