@@ -185,6 +185,9 @@ int odtk_conv_bias_act_pads(void *y, const void *x, const void *w, const void *b
   } catch (const std::exception &e) {                                            // CK throws on arguments it cannot run
     g_last_plan = std::string("exception: ") + e.what();
     return ODTK_ERR_UNSUPPORTED;
+  } catch (...) {                                                                // nothing may cross the C boundary
+    g_last_plan = "exception";
+    return ODTK_ERR_UNSUPPORTED;
   }
   return ODTK_ERR_UNSUPPORTED;
 }
