@@ -46,6 +46,29 @@ def fold_conv_bn(conv, bn=None):
     return w, b
 
 
+def stem_space_to_depth_weights(w):
+    """[K, 3, 7, 7] weights of a 7x7 / stride-2 / pad-3 convolution -> [K, 16, 4, 4] weights of the 4x4 / stride-1 convolution with
+    padding (2 before, 1 after) over the 2x2 space-to-depth image xs[n, (dy*2+dx)*3+c, y, x] = x[n, c, 2y+dy, 2x+dx] (channels 12..15
+    zero) that computes the same outputs: tap (R, S) of sub-pixel (dy, dx) is tap (2R+dy-1, 2S+dx-1) of the 7x7 window, taps outside
+    it are zero (include/odtk_hip.h: odtk_stem_pack; tests/test_stem_space_to_depth.py checks the identity in plain torch)."""
+    w4 = torch.zeros(w.shape[0], 16, 4, 4, dtype=w.dtype, device=w.device)
+    for dy in range(2):
+        for dx in range(2):
+            for r4 in range(4):
+                for s4 in range(4):
+                    r, s_ = 2 * r4 + dy - 1, 2 * s4 + dx - 1
+                    if 0 <= r < 7 and 0 <= s_ < 7:
+                        w4[:, (dy * 2 + dx) * 3:(dy * 2 + dx) * 3 + 3, r4, s4] = w[:, :, r, s_]
+    return w4
+
+
+def space_to_depth_pack(x):
+    """Reference (plain torch) of odtk_stem_pack without the cast: [B, 3, H, W] -> [B, 16, H/2, W/2]."""
+    b, _, h, w = x.shape
+    xs = x.view(b, 3, h // 2, 2, w // 2, 2).permute(0, 3, 5, 1, 2, 4).reshape(b, 12, h // 2, w // 2)
+    return torch.cat([xs, torch.zeros(b, 4, h // 2, w // 2, dtype=x.dtype, device=x.device)], 1)
+
+
 class _Conv(nn.Module):
     """Convolution + bias (+ residual) (+ ReLU).  Three native routes, by kernel shape:
       * 1x1: ONE hipBLASLt GEMM with the whole epilogue (`odtk_gemm_bias_act`);
@@ -217,14 +240,7 @@ class FusedRetinaNet(nn.Module):
         if (tuple(c1.kernel_size), tuple(c1.stride), tuple(c1.padding), c1.in_channels, c1.groups) == ((7, 7), (2, 2), (3, 3), 3, 1) \
                 and dtype in (torch.bfloat16, torch.float16):
             w = self.stem.weight.float()
-            w4 = torch.zeros(w.shape[0], 16, 4, 4, device=w.device)
-            for dy in range(2):
-                for dx in range(2):
-                    for r4 in range(4):
-                        for s4 in range(4):
-                            r, s_ = 2 * r4 + dy - 1, 2 * s4 + dx - 1
-                            if 0 <= r < 7 and 0 <= s_ < 7:
-                                w4[:, (dy * 2 + dx) * 3:(dy * 2 + dx) * 3 + 3, r4, s4] = w[:, :, r, s_]
+            w4 = stem_space_to_depth_weights(w)
             self.register_buffer('stem_w4', w4.to(dtype).contiguous(memory_format=torch.channels_last))
             self.register_buffer('stem_zero_bias', torch.zeros(w.shape[0], dtype=dtype, device=w.device))
             self.stem_s2d = {}                                          # input (shape, dtype, layout) -> (use it, us s2d, us direct)
