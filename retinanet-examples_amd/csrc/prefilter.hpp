@@ -63,7 +63,7 @@ struct SelSeg {
   uint32_t route;          // 0 undecided | kRouteCoop | kRouteTournament: ONE compare-and-swap decides for the whole segment
   uint32_t arrived2;       // workgroups that have published their keys (second ticket: the last one finishes the segment)
   uint32_t hist[1 << 11];  // histogram (2048 equal bins of the key range, reversed) of the segment's keys
-  uint32_t run_len[kSelMaxParts];   // cooperative route: keys in workgroup g's published (sorted) run
+  uint32_t run_len[kSelMaxParts];   // cooperative route: keys in workgroup g's published list (its keys >= the segment's threshold)
 };
 constexpr uint32_t kRouteCoop = 1, kRouteTournament = 2;
 

@@ -977,7 +977,7 @@ __global__ __launch_bounds__(kSelThreads) void select_decode_kernel(const Decode
     //   buffer: no pass over ~G x top_n survivors.  (Publishing the lists SORTED and merging them by rank was built first: G
     //   binary searches per key are as many LDS steps as the merge sort's five levels -- 22 us for the ranking alone.)
     // tournament (rounds 3-4; the fall-back, taken when a slice could not be held whole, when the boundary bin holds more
-    //   than the ranking route sorts (plateaus), or when the barrier timed out -- other kernels may occupy the CUs a partner
+    //   than the sort takes (2048 keys: plateaus), or when the barrier timed out -- other kernels may occupy the CUs a partner
     //   needs): each workgroup publishes its LOCAL top `publish` >= top_n keys (any key of the segment's top_n is in its
     //   slice's top_n); the last to arrive finds the threshold in the segment's histogram and fetches the survivors >= T.
     // Both routes are exact for any input and nobody waits without a bound.
@@ -1036,9 +1036,9 @@ __global__ __launch_bounds__(kSelThreads) void select_decode_kernel(const Decode
       const uint64_t T64 = seg_total <= top_n ? 0ull : st.lo;                 // fewer than top_n candidates: all of them
       const uint32_t n_glob = seg_total <= top_n ? seg_total : st.taken + st.in_bin;   // #{keys of the segment >= T64}
       if (n_glob > 2u * kSelThreads) {
-        route = kRouteTournament;                              // a plateau wider than the ranking route sorts: every partner sees the same
+        route = kRouteTournament;                              // a plateau wider than the sort buffer's two keys per thread: every partner sees the same
       } else {
-        // ---- my keys >= T, sorted, published as run `part` ----
+        // ---- my keys >= T, compacted in place and published as list `part` (unsorted: the finisher sorts the union) ----
         if (tid == 0) s_misc[20] = 0;
         for (uint32_t base = 0; base < n_mine; base += 4 * kSelThreads) {   // in-place compaction (narrow_in_lds's)
           uint64_t mine[4];
