@@ -105,6 +105,33 @@ bool stream_is_capturing(hipStream_t stream) {
   return st != hipStreamCaptureStatusNone;
 }
 
+// The plan of the planned problem closest in size among those with the same channels, kernel, stride and padding, if its pixel
+// count is within a factor of two of this problem's (a batch of another size is tuned on its own) and its instance takes this
+// problem too.
+template <typename T>
+bool adopt_sibling(Instances<T> &inst, const Problem &p, void *y, const void *x, const void *w, const void *bias, int relu, Plan *out) {
+  const double pixels = static_cast<double>(p.n) * p.h * p.w;
+  const Plan *best = nullptr;
+  double best_ratio = 2.0;
+  for (const auto &kv : inst.plans) {
+    const Problem &q = kv.first;
+    if (kv.second.index < 0 || !kv.second.timed) continue;
+    if (std::tie(q.c, q.k, q.r, q.s, q.u, q.v, q.ph, q.pw, q.ph1, q.pw1, q.dtype) !=
+        std::tie(p.c, p.k, p.r, p.s, p.u, p.v, p.ph, p.pw, p.ph1, p.pw1, p.dtype))
+      continue;
+    const double other = static_cast<double>(q.n) * q.h * q.w;
+    const double ratio = other > pixels ? other / pixels : pixels / other;
+    if (ratio <= best_ratio) { best_ratio = ratio; best = &kv.second; }
+  }
+  if (!best) return false;
+  auto &op = *inst.ops[best->index];
+  auto arg = make_argument<T>(op, p, y, x, w, bias, relu);
+  if (!op.IsSupportedArgument(arg.get()) || op.GetWorkSpaceSize(arg.get()) != 0) return false;
+  *out = *best;
+  out->us = 0.0f;                                           // (not measured on this problem)
+  return true;
+}
+
 template <typename T>
 int run(const Problem &p, void *y, const void *x, const void *w, const void *bias, int relu, hipStream_t stream, int force_index) {
   std::lock_guard<std::mutex> lock(g_mutex);
@@ -122,6 +149,10 @@ int run(const Problem &p, void *y, const void *x, const void *w, const void *bia
     }
     if (plan.index < 0) return ODTK_ERR_UNSUPPORTED;
     plan.name = inst.ops[plan.index]->GetTypeString();
+  } else if (it == inst.plans.end() && adopt_sibling<T>(inst, p, y, x, w, bias, relu, &plan)) {
+    // a problem that differs from a planned one in its extents only (a data set's batches are padded to the largest image of
+    // the batch: dozens of geometries) runs on that sibling's instance -- no second tuning pass of 237 candidates per layer
+    inst.plans[p] = plan;
   } else if (it == inst.plans.end() || (!plan.timed && !capturing && plan.index >= 0)) {
     // first call for this problem (or the first eager call after a capture chose blindly): time every instance that
     // supports it -- one warm-up + three timed launches each on the caller's stream, then one synchronisation per candidate

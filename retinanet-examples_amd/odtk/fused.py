@@ -97,6 +97,7 @@ class _Conv(nn.Module):
         self.strided_ok = (self.pointwise and tuple(conv.stride) != (1, 1) and dtype in (torch.bfloat16, torch.float16)
                            and w.shape[1] % 8 == 0)
         self.zero_bias = None
+        self.learned = {}                                               # kind ('act' | 'only') -> the last measured decision: unplanned geometries follow it
         self.route = {}                                                 # input shape -> (use the library, us library, us miopen + epilogue)
 
     def conv_only(self, x):
@@ -106,13 +107,13 @@ class _Conv(nn.Module):
         if (self.library_ok and _Conv.use_conv_library and x.is_cuda and x.is_contiguous(memory_format=torch.channels_last)
                 and _C.conv_available()):
             key = ('only',) + tuple(x.shape)
-            route = self.route.get(key)
-            if route is None and _Conv.planning and not torch.cuda.is_current_stream_capturing():
-                if self.zero_bias is None:
-                    self.zero_bias = torch.zeros_like(self.bias_lp)
-                route = self.route[key] = self._measure(x, self._miopen_only, self._library_only)
-            if route is not None and route[0]:
-                return self._library_only(x)
+            if self.zero_bias is None:
+                self.zero_bias = torch.zeros_like(self.bias_lp)
+            if self._routed(key, 'only', x, self._miopen_only, self._library_only):
+                try:
+                    return self._library_only(x)
+                except RuntimeError:
+                    self.route[key] = (False, float('inf'), 0.0)
         return self._miopen_only(x)
 
     def _miopen_only(self, x):
@@ -164,21 +165,33 @@ class _Conv(nn.Module):
                 # copy pass of its own (29 us each at bs 8) -- the convolution library reads them in place; routed by the plan pass
                 if (residual is None and self.strided_ok and _Conv.use_conv_library and x.is_cuda
                         and x.is_contiguous(memory_format=torch.channels_last) and _C.conv_available()):
-                    route = self.route.get(tuple(x.shape))
-                    if route is None and _Conv.planning and not torch.cuda.is_current_stream_capturing():
-                        route = self.route[tuple(x.shape)] = self._measure(x, self._copy_then_gemm, self._one_pass)
-                    if route is not None and route[0]:
-                        return self._one_pass(x)
+                    if self._routed(tuple(x.shape), 'act', x, self._copy_then_gemm, self._one_pass):
+                        try:
+                            return self._one_pass(x)
+                        except RuntimeError:
+                            self.route[tuple(x.shape)] = (False, float('inf'), 0.0)
                 return self._copy_then_gemm(x, residual)
             return _C.gemm_bias_act(x, self.weight, self.bias, residual, self.relu)
         if (residual is None and self.library_ok and _Conv.use_conv_library and x.is_cuda
                 and x.is_contiguous(memory_format=torch.channels_last) and _C.conv_available()):
-            route = self.route.get(tuple(x.shape))
-            if route is None and _Conv.planning and not torch.cuda.is_current_stream_capturing():
-                route = self.route[tuple(x.shape)] = self._measure(x)
-            if route is not None and route[0]:
-                return self._one_pass(x)
+            if self._routed(tuple(x.shape), 'act', x, self._two_pass, self._one_pass):
+                try:
+                    return self._one_pass(x)
+                except RuntimeError:                                    # an unplanned geometry no instance takes: remember, fall through
+                    self.route[tuple(x.shape)] = (False, float('inf'), 0.0)
         return self._two_pass(x, residual)
+
+    def _routed(self, key, kind, x, two, one):
+        """Does this input go through the convolution library?  Measured during a plan pass; a geometry no plan pass has seen (the
+        engine plans the first few only: a data set's batches come in dozens of padded sizes) follows the layer's last measured
+        decision."""
+        route = self.route.get(key)
+        if route is None and _Conv.planning and not torch.cuda.is_current_stream_capturing():
+            route = self.route[key] = self._measure(x, two, one)
+            self.learned[kind] = route[0]
+        if route is None:
+            return self.learned.get(kind, False)
+        return route[0]
 
     def conv_then_pool(self, x):
         """conv -> bias -> ReLU -> maxpool 3x3/s2 with the epilogue folded into the pooling pass."""
@@ -244,6 +257,7 @@ class FusedRetinaNet(nn.Module):
             self.register_buffer('stem_w4', w4.to(dtype).contiguous(memory_format=torch.channels_last))
             self.register_buffer('stem_zero_bias', torch.zeros(w.shape[0], dtype=dtype, device=w.device))
             self.stem_s2d = {}                                          # input (shape, dtype, layout) -> (use it, us s2d, us direct)
+        self.stem_learned = False                                       # the last measured stem decision (unplanned geometries follow it)
         self.layers = nn.ModuleList([nn.ModuleList([_Block(b, dtype) for b in layer])
                                      for layer in (net.layer1, net.layer2, net.layer3, net.layer4)])
         self.outputs = list(net.outputs)
@@ -264,6 +278,7 @@ class FusedRetinaNet(nn.Module):
         self._streams = None
         self.tower_plan = 0
         self._planned = set()                                           # input geometries whose k x k convolutions were routed (plan pass)
+        self.max_plans = 4                                              # ... at most so many: a data set's batches come in dozens of padded sizes
         self._graphs = {}                                               # input geometry + bias state -> (hipGraph, static input, outputs, tables kept alive)
         self._thresholds = {}                                           # score threshold -> the prefilter's table for cls_head[-1].bias
         self.max_graphs = 8
@@ -286,8 +301,12 @@ class FusedRetinaNet(nn.Module):
             route = self.stem_s2d.get(key)
             if route is None and _Conv.planning and not torch.cuda.is_current_stream_capturing():
                 route = self.stem_s2d[key] = self.stem._measure(x, self._stem_direct, self._stem_packed)
-            if route is not None and route[0]:
-                return self._stem_packed(x)
+                self.stem_learned = route[0]
+            if route[0] if route is not None else self.stem_learned:
+                try:
+                    return self._stem_packed(x)
+                except RuntimeError:
+                    self.stem_s2d[key] = (False, float('inf'), 0.0)
         return self._stem_direct(x)
 
     def features(self, x):
@@ -420,6 +439,8 @@ class FusedRetinaNet(nn.Module):
         key = (tuple(x.shape), x.device)
         if key in self._planned or not x.is_cuda or not _C.conv_available() or not _Conv.use_conv_library:
             return
+        if len(self._planned) >= self.max_plans:
+            return                                                      # later geometries follow the layers' last measured decisions
         if torch.cuda.is_current_stream_capturing():
             return                                                      # (replay() warms up eagerly first: planned by then)
         streams, _Conv.planning, self.level_streams = self.level_streams, True, False

@@ -154,3 +154,35 @@ def test_stem_in_space_to_depth_form_equals_the_direct_stem():
     with torch.no_grad():
         d16, p16 = e16._stem_direct(xc), e16._stem_packed(xc)
     assert float((d16.float() - p16.float()).abs().max()) <= 2.0 ** -10 * float(d16.float().abs().max()) + 1e-3
+
+
+def test_many_input_geometries_plan_a_few_and_follow_the_rest():
+    """A data set's batches are padded to the largest image of the batch: dozens of geometries.  The engine plans the first
+    `max_plans`, later ones follow the layers' last measured decisions (and the library adopts a sibling problem's instance
+    instead of tuning again); the head tensors stay those of the two-launch graph either way."""
+    from odtk import fused
+    from odtk.model import Model
+    torch.manual_seed(0)
+    model = Model('ResNet18FPN', classes=6).cuda().eval()
+    model.initialize(None)
+    sizes = [(256, 320), (256, 384), (320, 320), (192, 256), (320, 384), (256, 256), (384, 384)]
+    e = fused.FusedRetinaNet(model, torch.bfloat16)
+    e.max_plans = 3
+    xs = [torch.randn(2, 3, h, w, device='cuda') for h, w in sizes]
+    outs = []
+    with torch.no_grad():
+        for x in xs:
+            e.plan(x)                                                   # (what forward() does first)
+            outs.append(e.heads(x))
+    assert len(e._planned) == 3                                         # the rest ran without a plan pass
+    fused._Conv.use_conv_library = False
+    try:
+        ref_engine = fused.FusedRetinaNet(model, torch.bfloat16)
+        with torch.no_grad():
+            refs = [ref_engine.heads(x) for x in xs]
+    finally:
+        fused._Conv.use_conv_library = True
+    for (c, b), (rc, rb) in zip(outs, refs):
+        for got, ref in zip(c + b, rc + rb):
+            scale = float(ref.float().abs().max())
+            assert float((got.float() - ref.float()).abs().max()) <= 0.03 * scale + 1e-3
