@@ -24,6 +24,7 @@ Measured on MI355X those passes cost more than the convolutions between them.  H
 the folded weights (tests/test_gpu_fused_model.py).
 """
 import os
+import threading
 
 import torch
 import torch.nn as nn
@@ -32,6 +33,9 @@ import torch.nn.functional as F
 from . import _C
 from . import box as box_ops
 from .backbones.resnet import BasicBlock, Bottleneck
+
+
+_PLAN_LOCK = threading.Lock()     # one plan pass at a time per process: `_Conv.planning` is class-wide state
 
 
 def fold_conv_bn(conv, bn=None):
@@ -443,13 +447,14 @@ class FusedRetinaNet(nn.Module):
             return                                                      # later geometries follow the layers' last measured decisions
         if torch.cuda.is_current_stream_capturing():
             return                                                      # (replay() warms up eagerly first: planned by then)
-        streams, _Conv.planning, self.level_streams = self.level_streams, True, False
-        try:
-            with torch.autocast(x.device.type, enabled=False):
-                self._towers(self.features(x), False)
-        finally:
-            _Conv.planning, self.level_streams = False, streams
-        self._planned.add(key)
+        with _PLAN_LOCK:
+            streams, _Conv.planning, self.level_streams = self.level_streams, True, False
+            try:
+                with torch.autocast(x.device.type, enabled=False):
+                    self._towers(self.features(x), False)
+            finally:
+                _Conv.planning, self.level_streams = False, streams
+            self._planned.add(key)
 
     def conv_routes(self):
         """{layer name: {input shape: (library?, us library, us two-pass)}} of the plan passes so far (measurement records)."""
