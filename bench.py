@@ -46,6 +46,7 @@ for p in (ROOT, os.path.join(ROOT, 'retinanet-examples_amd')):
 # `hipIpcGetMemHandle: invalid argument`); the launcher's environment normally carries it already
 os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 
+import numpy as np                # noqa: E402
 import torch                      # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
@@ -287,7 +288,7 @@ def build_parser():
     ap.add_argument('--no-other-configs', action='store_true',
                     help="default 1-GPU run: skip the legs for BASELINE.json's other configurations (`other_configs` on the line)")
     ap.add_argument('--other-steps', type=int, default=10, help='timed steps of each other_configs leg')
-    ap.add_argument('--leg-budget-s', type=float, default=100.0,
+    ap.add_argument('--leg-budget-s', type=float, default=330.0,
                     help='wall-clock budget of the other_configs legs together: a leg only starts while budget is left (its typical '
                          'cost included); the rest are reported as skipped.  0 = no limit (tools/profile_round.sh)')
     ap.add_argument('--device', default='cuda', choices=['cuda', 'cpu'],
@@ -378,6 +379,11 @@ def headline(full):
                 e['latency_ratio'] = {k: v.get('ratio') for k, v in leg['latency_bound'].items()}
             if isinstance(leg.get('loss'), dict):
                 e['loss'] = pick(leg['loss'], 'focal', 'box', 'finite')
+            if 'exposed_allreduce_ms' in leg:                # training legs: null at N = 1 (no collective to expose)
+                e['exposed_allreduce_ms'] = leg['exposed_allreduce_ms']
+            if isinstance(leg.get('hip_kernels'), dict):     # ... and the HIP loss / target kernels against the HBM peak
+                e['hip_kernels_frac'] = {k: v.get('frac_of_hbm_peak') for k, v in leg['hip_kernels'].items()
+                                         if isinstance(v, dict) and v.get('frac_of_hbm_peak') is not None}
             h['other_configs'][leg.get('key', leg.get('leg', '?'))] = e
     h['detail'] = full.get('detail')
     return h
@@ -512,20 +518,22 @@ def leg_args(args, **over):
     return leg
 
 
-# (key, name, typical wall seconds on a fresh box [MIOpen find + model build dominate], builder of the leg).  Order = priority:
-# the legs run while --leg-budget-s lasts.
+# (key, name, typical wall seconds on a fresh box [MIOpen find + model build dominate; the leg_wall_s of the last three detail
+# files of round 5 and round 4's full run, profiles/bench_r05_detail_final{,2,3}.json, bench_r04_default_with_legs.json], builder of
+# the leg).  Order = priority (BASELINE.json's configurations first: 4, 5, 3; then the fp16 twin of config 2, the batch-1 latency and
+# the variants); the legs run while --leg-budget-s lasts -- the default budget takes all of them (sum of the typical costs 302 s).
 def leg_table(args, rank, local_rank, world, dev):
     return [
-        ('cfg4_rn101_bs16', 'config 4: ResNet101FPN bf16 inference bs 16', 40,
+        ('cfg4_rn101_bs16', 'config 4: ResNet101FPN bf16 inference bs 16', 43,
          lambda: run_infer(leg_args(args, backbone='ResNet101FPN', batch=16), rank, world, dev)),
-        ('cfg5_rotated_bs8', 'config 5: ResNet50FPN --rotated-bbox bf16 inference bs 8', 42,
+        ('cfg5_rotated_bs8', 'config 5: ResNet50FPN --rotated-bbox bf16 inference bs 8', 45,
          lambda: run_infer(leg_args(args, rotated_bbox=True), rank, world, dev)),
-        ('bs1_latency_ms', 'batch-1 latency: ResNet50FPN bf16', 12, lambda: run_latency(leg_args(args, batch=1), dev)),
+        ('cfg3_train_fp32_2img', 'config 3 (per-GPU share): ResNet50FPN fp32 training, 2 images per GPU', 127,
+         lambda: run_train(leg_args(args, mode='train', batch=2, dtype='fp32'), rank, local_rank, world, dev)),
         # the precision `odtk infer` runs by default (fp16 autocast, as the reference's mixed precision)
         ('cfg2_fp16', 'config 2 in fp16: ResNet50FPN fp16 inference bs 8', 22,
          lambda: run_infer(leg_args(args, dtype='fp16'), rank, world, dev)),
-        ('cfg3_train_fp32_2img', 'config 3 (per-GPU share): ResNet50FPN fp32 training, 2 images per GPU', 125,
-         lambda: run_train(leg_args(args, mode='train', batch=2, dtype='fp32'), rank, local_rank, world, dev)),
+        ('bs1_latency_ms', 'batch-1 latency: ResNet50FPN bf16', 13, lambda: run_latency(leg_args(args, batch=1), dev)),
         # (unit (sin, cos) head bias: with the reference's own initialisation -- the -4.6 class prior on all six box outputs,
         # model.py:121-122 -- SGD diverges within 6-7 steps in the reference's arithmetic exactly as in the fused kernels:
         # profiles/r05_rotated_train_trajectory.txt, tools/rotated_train_probe.py --bench-like)
@@ -903,9 +911,16 @@ def run_infer(args, rank, world, dev):
             got = [t.float().cpu() for t in got]
             ref = [torch.cat([o[k] for o in oracle_out]) for k in range(3)]
             diff = (got[1] - ref[1]).abs()
+            # what oracle/box_check.py's exp-rounding escape would have to excuse on these boxes: coordinates beyond 1e-4,
+            # split into those beyond one fp32 ulp of the coordinate (counted against its bound of 2 per call) and the
+            # one-ulp deviations at >= 1024 px (one ulp IS 1.2e-4 there: proven, not counted) -- VERDICT r05 weak #1
+            over = diff > box_check.NORTH_STAR_ATOL
+            one_ulp = torch.from_numpy(np.spacing(ref[1].abs().numpy())).to(diff.dtype)
             parity = {'images': args.batch, 'scores_bit_exact': bool(torch.equal(got[0], ref[0])),
                       'classes_bit_exact': bool(torch.equal(got[2], ref[2])), 'max_box_abs_diff': float(diff.max()),
-                      'box_coords_beyond_1e-4': int((diff > box_check.NORTH_STAR_ATOL).sum()), 'box_coords': int(diff.numel()),
+                      'box_coords_beyond_1e-4': int(over.sum()), 'box_coords': int(diff.numel()),
+                      'proven': {'beyond_one_ulp': int((over & (diff > one_ulp * (1 + 1e-6))).sum()),
+                                 'one_ulp_only': int((over & ~(diff > one_ulp * (1 + 1e-6))).sum())},
                       'checker': 'oracle/box_oracle.py (restatement of reference odtk/box.py, pinned) on the captured heads'}
         except Exception as e:                               # noqa: BLE001 -- the check reports, it never takes the line down
             parity = {'error': '%s: %s' % (type(e).__name__, e)}
