@@ -354,7 +354,7 @@ def headline(full):
     if full.get('eager'):
         h['eager'] = pick(full['eager'], 'value', 'ms_per_step')
     if full.get('conv_epilogue'):
-        h['conv_epilogue'] = pick(full['conv_epilogue'], 'layers_routed_to_library', 'layers_measured', 'us_saved_per_step')
+        h['conv_epilogue'] = pick(full['conv_epilogue'], 'layers_routed_to_library', 'layers_measured', 'us_saved_per_step', 'plan_hash')
     cb = full.get('cpu_baseline')
     if cb:
         h['cpu_baseline'] = pick(cb, 'value', 'unit', 'cores', 'kind', 'sample')
@@ -1012,19 +1012,30 @@ def conv_epilogue_record(engine):
     routes = engine.conv_routes()
     if not routes:
         return None
-    layers, one, two, saved, n_lib = {}, 0.0, 0.0, 0.0, 0
+    layers, one, two, saved, n_lib, n_timed = {}, 0.0, 0.0, 0.0, 0, 0
     for name, per_shape in sorted(routes.items()):
         for shape, (use, t_one, t_two) in per_shape.items():
-            layers['%s %s' % (name, ('conv only ' if shape[0] == 'only' else '') + 'x'.join(str(v) for v in shape if v != 'only'))] = {
-                'library': bool(use), 'us_one_launch': None if t_one == float('inf') else round(t_one, 1), 'us_two_launches': round(t_two, 1)}
+            key = '%s %s' % (name, ('conv only ' if shape[0] == 'only' else '') + 'x'.join(str(v) for v in shape if v != 'only'))
             n_lib += bool(use)
+            if t_one is None or t_two is None:               # pinned by a loaded plan / ODTK_CONV_ROUTE: nothing was timed
+                layers[key] = {'library': bool(use), 'pinned': True}
+                continue
+            layers[key] = {'library': bool(use), 'us_one_launch': None if t_one == float('inf') else round(t_one, 1),
+                           'us_two_launches': round(t_two, 1)}
+            n_timed += 1
             two += t_two
             one += min(t_one, t_two)
             saved += max(t_two - t_one, 0.0)
-    return {'layers_routed_to_library': n_lib, 'layers_measured': len(layers), 'us_per_step_two_launch_form': round(two, 1),
-            'us_per_step_as_routed': round(one, 1), 'us_saved_per_step': round(saved, 1),
+    from odtk import fused
+    state = engine.plan_state()
+    return {'layers_routed_to_library': n_lib, 'layers_measured': len(layers), 'layers_timed_here': n_timed,
+            'us_per_step_two_launch_form': round(two, 1), 'us_per_step_as_routed': round(one, 1), 'us_saved_per_step': round(saved, 1),
+            # the plan the step ran: routes + the instance / solution each library problem runs on (odtk/fused.py: plan_state);
+            # ODTK_CONV_PLAN=<file> replays it on another box bit for bit where the libraries still offer those kernels
+            'plan_hash': engine.plan_hash(state), 'plan_source': ('file ' + os.environ['ODTK_CONV_PLAN']) if os.environ.get('ODTK_CONV_PLAN')
+            else 'route mode ' + fused._Conv.route_mode, 'library_lines': len(state['libraries']),
             'note': 'per-layer A/B of the plan pass (median of 5, back to back, caller stream only): shared tower layers run once '
-                    'per pyramid level and are listed per input shape', 'layers': layers}
+                    'per pyramid level and are listed per input shape', 'layers': layers, 'plan': state}
 
 
 if __name__ == '__main__':

@@ -14,6 +14,8 @@
 #ifndef ODTK_CONV_H
 #define ODTK_CONV_H
 
+#include <stddef.h>
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -43,6 +45,26 @@ int odtk_conv_bias_act_pads(void *y, const void *x, const void *w, const void *b
 
 /* "#index time-when-chosen instance-name" of the instance the last odtk_conv_bias_act call of this thread ran. */
 const char *odtk_conv_last_plan(void);
+
+/*
+ * Reproducible plans.  The instance a problem runs on is picked by a stopwatch at its first call, and two instances accumulate in
+ * different orders: the same weights then give different bits on different boxes.  odtk_conv_plan_export writes one line per timed
+ * problem -- "conv dtype n c h w k r s u v pad_h pad_w pad_h_end pad_w_end index instance-name" -- and returns the bytes the text
+ * needs (NUL included; at most `capacity` are written); odtk_conv_plan_import takes such lines (others are ignored) and returns
+ * how many it took: the problem then runs on that instance without any timing.  A line whose instance name is not what this
+ * build's list has at that index is NOT taken (another ROCm release: the problem is timed as usual).  The engine's plan file
+ * carries these lines (odtk/fused.py: plan_state / load_plan, ODTK_CONV_PLAN).
+ */
+size_t odtk_conv_plan_export(char *text, size_t capacity);
+int odtk_conv_plan_import(const char *text);
+
+/*
+ * Non-finite accumulators.  The epilogue is composable_kernel's AddClamp, `a > floor ? (a < ceil ? a : ceil) : floor`: a NaN
+ * accumulator comes out as `floor` -- 0 on a ReLU layer, -FLT_MAX (-inf after the rounding to 16 bits) on a linear one -- where
+ * MIOpen + odtk_bias_act and the reference's PyTorch graph hand the NaN on.  A diverged checkpoint therefore shows up as
+ * "no detections", not as NaN scores, on library-routed layers; `ODTK_CHECK_FINITE=1` makes the engine assert that its head
+ * tensors are finite (odtk/fused.py).
+ */
 
 /* Instances linked for `dtype` (237 bf16, 228 fp16 with ROCm 7.2's archive); 0 for any other dtype. */
 int odtk_conv_instance_count(int dtype);

@@ -261,6 +261,19 @@ int odtk_stem_pack(const void *x, void *out, int batch_size, int height, int wid
  * copy PyTorch ships (torch/lib/libhipblaslt.so) so that only one copy of the soname is in use.
  */
 int odtk_gemm_init(const char *hipblaslt_path);
+/*
+ * Reproducible plans.  Which hipBLASLt solution a problem runs on is decided by a stopwatch at its first call; the choice is not
+ * the same on every box, and two solutions add up in different orders.  odtk_gemm_plan_export writes one line per tuned problem
+ * ("gemm m n k dtype relu residual solution-index"; returns the bytes the text needs, NUL included, and writes at most
+ * `capacity`), odtk_gemm_plan_import takes such lines (others are ignored; returns how many it took): a problem first seen after
+ * the import runs on the named solution without timing, if the library still offers it for the problem (otherwise it is timed as
+ * usual and counted by odtk_gemm_plan_pin_misses).  The engine's plan file (odtk/fused.py: plan_state / load_plan, ODTK_CONV_PLAN)
+ * carries these lines next to libodtk_conv.so's (include/odtk_conv.h).  No reference equivalent (one deterministic PyTorch graph,
+ * odtk/model.py:125-165).
+ */
+size_t odtk_gemm_plan_export(char *text, size_t capacity);
+int odtk_gemm_plan_import(const char *text);
+int odtk_gemm_plan_pin_misses(void);
 int odtk_gemm_bias_act(void *y, const void *x, const void *w, const float *bias, const void *residual,
                        size_t m, int n, int k, int dtype, int relu,
                        void *workspace, size_t workspace_size, void *stream);

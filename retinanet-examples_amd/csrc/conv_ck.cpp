@@ -157,31 +157,41 @@ int run(const Problem &p, void *y, const void *x, const void *w, const void *bia
     // first call for this problem (or the first eager call after a capture chose blindly): time every instance that
     // supports it -- one warm-up + three timed launches each on the caller's stream, then one synchronisation per candidate
     plan = Plan{};
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (!capturing && (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)) return ODTK_ERR_HIP;
+    struct Events {                                           // (RAII: a throwing candidate must not leak them)
+      hipEvent_t e0 = nullptr, e1 = nullptr;
+      ~Events() {
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+      }
+    } ev;
+    if (!capturing && (hipEventCreate(&ev.e0) != hipSuccess || hipEventCreate(&ev.e1) != hipSuccess)) return ODTK_ERR_HIP;
     float best = 0.0f;
     for (size_t i = 0; i < inst.ops.size(); ++i) {
-      auto &op = *inst.ops[i];
-      auto arg = make_argument<T>(op, p, y, x, w, bias, relu);
-      if (!op.IsSupportedArgument(arg.get()) || op.GetWorkSpaceSize(arg.get()) != 0) continue;
-      if (capturing) { plan.index = static_cast<int>(i); break; }          // no timing inside a capture: the first that fits
-      auto invoker = op.MakeInvokerPointer();
-      const StreamConfig cfg{stream, false};
-      invoker->Run(arg.get(), cfg);
-      (void)hipEventRecord(e0, stream);
-      for (int rep = 0; rep < 3; ++rep) invoker->Run(arg.get(), cfg);
-      (void)hipEventRecord(e1, stream);
-      if (hipEventSynchronize(e1) != hipSuccess) { (void)hipGetLastError(); continue; }
-      float ms = 0.0f;
-      (void)hipEventElapsedTime(&ms, e0, e1);
-      if (plan.index < 0 || ms < best) { best = ms; plan.index = static_cast<int>(i); }
+      try {                                                   // CK throws on arguments an instance cannot run: next candidate
+        auto &op = *inst.ops[i];
+        auto arg = make_argument<T>(op, p, y, x, w, bias, relu);
+        if (!op.IsSupportedArgument(arg.get()) || op.GetWorkSpaceSize(arg.get()) != 0) continue;
+        if (capturing) { plan.index = static_cast<int>(i); break; }          // no timing inside a capture: the first that fits
+        auto invoker = op.MakeInvokerPointer();
+        const StreamConfig cfg{stream, false};
+        invoker->Run(arg.get(), cfg);
+        if (hipEventRecord(ev.e0, stream) != hipSuccess) { (void)hipGetLastError(); continue; }
+        for (int rep = 0; rep < 3; ++rep) invoker->Run(arg.get(), cfg);
+        if (hipEventRecord(ev.e1, stream) != hipSuccess) { (void)hipGetLastError(); continue; }
+        if (hipEventSynchronize(ev.e1) != hipSuccess) { (void)hipGetLastError(); continue; }
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, ev.e0, ev.e1) != hipSuccess || !(ms > 0.0f)) { (void)hipGetLastError(); continue; }   // (0 ms: a launch that did not run)
+        if (plan.index < 0 || ms < best) { best = ms; plan.index = static_cast<int>(i); }
+      } catch (...) {
+        continue;
+      }
     }
-    if (e0) (void)hipEventDestroy(e0);
-    if (e1) (void)hipEventDestroy(e1);
     if (plan.index >= 0) {
       plan.us = best * 1000.0f / 3.0f;
       plan.timed = !capturing;
       plan.name = inst.ops[plan.index]->GetTypeString();
+    } else if (!capturing) {
+      plan.timed = true;                                      // nothing takes the problem: remembered, never enumerated again
     }
     inst.plans[p] = plan;
   }
@@ -195,6 +205,32 @@ int run(const Problem &p, void *y, const void *x, const void *w, const void *bia
   return hipGetLastError() == hipSuccess ? ODTK_OK : ODTK_ERR_HIP;
 }
 
+}  // namespace
+
+namespace {
+template <typename T>
+void export_plans(std::string *out) {
+  for (const auto &kv : instances<T>().plans) {
+    const Problem &p = kv.first;
+    if (kv.second.index < 0 || !kv.second.timed) continue;
+    char line[256];
+    std::snprintf(line, sizeof line, "conv %d %d %d %d %d %d %d %d %d %d %d %d %d %d %d ", p.dtype, p.n, p.c, p.h, p.w, p.k, p.r, p.s, p.u, p.v,
+                  p.ph, p.pw, p.ph1, p.pw1, kv.second.index);
+    *out += line + kv.second.name + "\n";
+  }
+}
+template <typename T>
+bool import_plan(const Problem &p, int index, const std::string &name) {
+  Instances<T> &inst = instances<T>();
+  if (index < 0 || index >= static_cast<int>(inst.ops.size())) return false;
+  if (inst.ops[index]->GetTypeString() != name) return false;            // another build of the instance archive: not the same kernel
+  Plan plan;
+  plan.index = index;
+  plan.timed = true;
+  plan.name = name;
+  inst.plans[p] = plan;
+  return true;
+}
 }  // namespace
 
 extern "C" {
@@ -231,6 +267,48 @@ int odtk_conv_bias_act(void *y, const void *x, const void *w, const void *bias, 
 }
 
 const char *odtk_conv_last_plan(void) { return g_last_plan.c_str(); }
+
+// declared in include/odtk_conv.h
+size_t odtk_conv_plan_export(char *text, size_t capacity) {
+  std::string out;
+  try {
+    std::lock_guard<std::mutex> lock(g_mutex);
+    export_plans<ck::bhalf_t>(&out);
+    export_plans<ck::half_t>(&out);
+  } catch (...) {
+    out.clear();
+  }
+  if (text && capacity) {
+    const size_t n = out.size() < capacity - 1 ? out.size() : capacity - 1;
+    std::memcpy(text, out.data(), n);
+    text[n] = 0;
+  }
+  return out.size() + 1;
+}
+
+int odtk_conv_plan_import(const char *text) {
+  if (!text) return 0;
+  int taken = 0;
+  try {
+    std::lock_guard<std::mutex> lock(g_mutex);
+    for (const char *q = text; *q;) {
+      Problem p{};
+      int index = -1, used = 0;
+      if (std::sscanf(q, "conv %d %d %d %d %d %d %d %d %d %d %d %d %d %d %d %n", &p.dtype, &p.n, &p.c, &p.h, &p.w, &p.k, &p.r, &p.s, &p.u,
+                      &p.v, &p.ph, &p.pw, &p.ph1, &p.pw1, &index, &used) == 15 && used > 0) {
+        const char *name = q + used, *end = std::strchr(name, '\n');
+        const std::string nm = end ? std::string(name, end) : std::string(name);
+        if (p.dtype == ODTK_BF16 ? import_plan<ck::bhalf_t>(p, index, nm) : (p.dtype == ODTK_F16 && import_plan<ck::half_t>(p, index, nm)))
+          ++taken;
+      }
+      const char *nl = std::strchr(q, '\n');
+      if (!nl) break;
+      q = nl + 1;
+    }
+  } catch (...) {
+  }
+  return taken;
+}
 
 int odtk_conv_instance_count(int dtype) {
   try {

@@ -16,7 +16,10 @@
 #include <hip/hip_runtime.h>
 #include <hipblaslt/hipblaslt.h>
 
+#include <cstdio>
+#include <cstring>
 #include <map>
+#include <string>
 #include <mutex>
 #include <tuple>
 #include <vector>
@@ -95,6 +98,25 @@ inline std::map<Key, Plan> &plans() {
   return p;
 }
 
+// Reproducible plans (odtk_gemm_plan_export / _import, include/odtk_hip.h): the choice made for a problem is the library's
+// solution index -- what hipblaslt_ext::getIndexFromAlgo returns: the int at the head of the opaque algo struct.  An imported
+// index is honoured when the heuristic offers that solution for the problem again (same library build: the candidate list is
+// deterministic); then nothing is timed.  Otherwise the problem is timed as usual and counted in `pin_misses`.
+using PinKey = std::tuple<uint64_t, uint32_t, uint32_t, int, int, int>;      // m, n, k, dtype, relu, residual
+inline std::map<PinKey, int> &pinned() {
+  static std::map<PinKey, int> p;
+  return p;
+}
+inline int &pin_misses() {
+  static int n = 0;
+  return n;
+}
+inline int algo_index(const hipblasLtMatmulAlgo_t &algo) {
+  int idx;
+  std::memcpy(&idx, algo.data, sizeof idx);
+  return idx;
+}
+
 // Build the descriptors and choose the algorithm: ask the heuristic for its candidates and TIME them on
 // the caller's stream with the caller's buffers (the result in `y` is recomputed by the real call right
 // after).  The default pick is tuned for square LLM shapes; these are tall-skinny (m up to 512 000, k and
@@ -131,6 +153,19 @@ inline int make_plan(Plan *p, void *y, const void *x, const void *w, const float
 
   const float alpha = 1.0f, beta = residual ? 1.0f : 0.0f;
   const void *c_ptr = residual ? residual : y;
+  {
+    const auto pin = pinned().find(PinKey{m, n, k, dtype, relu ? 1 : 0, residual ? 1 : 0});
+    if (pin != pinned().end()) {                                         // an imported plan names the solution: no stopwatch
+      for (int i = 0; i < n_found; ++i) {
+        if (found[i].state != HIPBLAS_STATUS_SUCCESS || found[i].workspaceSize > workspace_size) continue;
+        if (algo_index(found[i].algo) != pin->second) continue;
+        p->algo = found[i].algo;
+        p->workspace = found[i].workspaceSize;
+        return ODTK_OK;
+      }
+      ++pin_misses();                                                    // (another library build: time the candidates as usual)
+    }
+  }
   // A stream that is being captured into a hipGraph cannot be timed (hipEventSynchronize would invalidate the capture):
   // a shape first seen during a capture takes the heuristic's first usable candidate and is NOT remembered as tuned -- the
   // caller (gemm_bias_act) keeps the plan only for the graph's own launches and re-plans on the next eager call.
@@ -217,6 +252,53 @@ inline int gemm_bias_act(void *y, const void *x, const void *w, const float *bia
   const hipblasStatus_t st = a.Matmul(a.handle, p.desc, &alpha, w, p.a, x, p.b, &beta, residual ? residual : y, p.c, y,
                                       p.c, &p.algo, workspace, workspace_size, stream);
   return st == HIPBLAS_STATUS_SUCCESS ? ODTK_OK : ODTK_ERR_HIP;
+}
+
+// "gemm m n k dtype relu residual solution-index" per tuned problem (any device).  Returns the bytes the text needs (NUL included);
+// writes at most `cap` of them.
+inline size_t plan_export(char *buf, size_t cap) {
+  std::lock_guard<std::mutex> lock(mutex());
+  std::string out;
+  std::map<PinKey, int> seen;
+  for (const auto &kv : plans()) {
+    if (!kv.second.tuned) continue;
+    const Key &q = kv.first;
+    seen[PinKey{std::get<1>(q), std::get<2>(q), std::get<3>(q), std::get<4>(q), std::get<5>(q), std::get<6>(q)}] = algo_index(kv.second.algo);
+  }
+  for (const auto &kv : seen) {
+    char line[160];
+    std::snprintf(line, sizeof line, "gemm %llu %u %u %d %d %d %d\n", static_cast<unsigned long long>(std::get<0>(kv.first)),
+                  std::get<1>(kv.first), std::get<2>(kv.first), std::get<3>(kv.first), std::get<4>(kv.first), std::get<5>(kv.first),
+                  kv.second);
+    out += line;
+  }
+  if (buf && cap) {
+    const size_t n = out.size() < cap - 1 ? out.size() : cap - 1;
+    std::memcpy(buf, out.data(), n);
+    buf[n] = 0;
+  }
+  return out.size() + 1;
+}
+
+// Lines of plan_export (others are ignored): problems not planned yet in this process will take the named solution.  Returns how
+// many were taken.
+inline int plan_import(const char *text) {
+  if (!text) return 0;
+  std::lock_guard<std::mutex> lock(mutex());
+  int n_in = 0;
+  for (const char *p = text; *p;) {
+    unsigned long long m;
+    unsigned n, k;
+    int dtype, relu, res, idx;
+    if (std::sscanf(p, "gemm %llu %u %u %d %d %d %d", &m, &n, &k, &dtype, &relu, &res, &idx) == 7) {
+      pinned()[PinKey{m, n, k, dtype, relu, res}] = idx;
+      ++n_in;
+    }
+    const char *nl = std::strchr(p, '\n');
+    if (!nl) break;
+    p = nl + 1;
+  }
+  return n_in;
 }
 
 }  // namespace lt

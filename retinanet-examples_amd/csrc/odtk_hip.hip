@@ -1105,6 +1105,10 @@ int odtk_stem_pack(const void *x, void *out, int batch_size, int height, int wid
 
 int odtk_gemm_init(const char *hipblaslt_path) { return odtk::lt::init(hipblaslt_path); }
 
+size_t odtk_gemm_plan_export(char *text, size_t capacity) { return odtk::lt::plan_export(text, capacity); }
+int odtk_gemm_plan_import(const char *text) { return odtk::lt::plan_import(text); }
+int odtk_gemm_plan_pin_misses(void) { return odtk::lt::pin_misses(); }
+
 int odtk_gemm_bias_act(void *y, const void *x, const void *w, const float *bias, const void *residual, size_t m,
                        int n, int k, int dtype, int relu, void *workspace, size_t workspace_size, void *stream) {
   if (!y || !x || !w || !bias || n <= 0 || k <= 0 || residual == y) return ODTK_ERR_INVALID;

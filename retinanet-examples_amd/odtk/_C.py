@@ -113,6 +113,9 @@ _SIGNATURES = {
     'odtk_stem_pack': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                       ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     'odtk_gemm_init': (ctypes.c_int, [ctypes.c_char_p]),
+    'odtk_gemm_plan_export': (ctypes.c_size_t, [ctypes.c_char_p, ctypes.c_size_t]),
+    'odtk_gemm_plan_import': (ctypes.c_int, [ctypes.c_char_p]),
+    'odtk_gemm_plan_pin_misses': (ctypes.c_int, []),
     'odtk_gemm_bias_act': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                           ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                           ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
@@ -827,6 +830,10 @@ def conv_library():
             lib.odtk_conv_last_plan.argtypes = []
             lib.odtk_conv_instance_count.restype = ctypes.c_int
             lib.odtk_conv_instance_count.argtypes = [ctypes.c_int]
+            lib.odtk_conv_plan_export.restype = ctypes.c_size_t
+            lib.odtk_conv_plan_export.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
+            lib.odtk_conv_plan_import.restype = ctypes.c_int
+            lib.odtk_conv_plan_import.argtypes = [ctypes.c_char_p]
         _conv_lib.append(lib)
     return _conv_lib[0]
 
@@ -872,6 +879,38 @@ def conv_last_plan():
     """'#index time name' of the instance the last conv_bias_act call of this thread ran (measurement records)."""
     lib = conv_library()
     return lib.odtk_conv_last_plan().decode() if lib is not None else ''
+
+
+def _export_text(fn):
+    need = fn(None, 0)
+    buf = ctypes.create_string_buffer(int(need))
+    fn(buf, need)
+    return buf.value.decode()
+
+
+def library_plans_export():
+    """The choices the two kernel libraries under the engine made by stopwatch in this process, as text lines: hipBLASLt
+    solutions ('gemm ...', include/odtk_hip.h: odtk_gemm_plan_export) and convolution instances ('conv ...', include/odtk_conv.h:
+    odtk_conv_plan_export)."""
+    text = _export_text(library().odtk_gemm_plan_export)
+    lib = conv_library()
+    if lib is not None:
+        text += _export_text(lib.odtk_conv_plan_export)
+    return text
+
+
+def library_plans_import(text):
+    """-> (gemm lines taken, conv lines taken): problems not yet planned in this process run on the named solution / instance
+    without being timed."""
+    data = text.encode()
+    gemm_available()                                          # (binds hipBLASLt: the import itself only records)
+    n_gemm = library().odtk_gemm_plan_import(data)
+    lib = conv_library()
+    return n_gemm, (lib.odtk_conv_plan_import(data) if lib is not None else 0)
+
+
+def gemm_plan_pin_misses():
+    return library().odtk_gemm_plan_pin_misses()
 
 
 def loss_tuning(which, fp32_heads, threads, blocks_per_cu, unroll, box_blocks):

@@ -23,6 +23,8 @@ Measured on MI355X those passes cost more than the convolutions between them.  H
 `FusedRetinaNet(model)` is a drop-in for `model.eval()` inference: same outputs up to the rounding of
 the folded weights (tests/test_gpu_fused_model.py).
 """
+import hashlib
+import json
 import os
 import threading
 
@@ -35,7 +37,25 @@ from . import box as box_ops
 from .backbones.resnet import BasicBlock, Bottleneck
 
 
-_PLAN_LOCK = threading.Lock()     # one plan pass at a time per process: `_Conv.planning` is class-wide state
+_PLAN_LOCK = threading.Lock()     # one plan pass at a time per process (the A/B timings must not run beside each other)
+_TLS = threading.local()          # .planning: THIS thread is inside a plan pass -> undecided k x k shapes are measured (A/B).  Thread-
+                                  # local: a forward() on another thread never times anything in its hot path
+
+
+def _planning():
+    return getattr(_TLS, 'planning', False)
+
+
+def _key_str(key):
+    """Route key -> the string a plan file holds: tuple(x.shape) -> 'act:8x256x100x160', ('only',) + shape -> 'only:...'."""
+    kind, shape = ('only', key[1:]) if key and key[0] == 'only' else ('act', key)
+    return kind + ':' + 'x'.join(str(int(v)) for v in shape)
+
+
+def _str_key(text):
+    kind, shape = text.split(':')
+    shape = tuple(int(v) for v in shape.split('x'))
+    return (('only',) + shape) if kind == 'only' else shape
 
 
 def fold_conv_bn(conv, bn=None):
@@ -80,8 +100,12 @@ class _Conv(nn.Module):
         epilogue (`odtk_conv_bias_act`, csrc/conv_ck.cpp) -- where the engine's plan pass measured it faster than
       * the MIOpen convolution followed by the HIP epilogue pass `odtk_bias_act` (in place)."""
 
-    planning = False          # class-wide: the engine's plan pass is running -> undecided k x k shapes are measured (A/B)
     use_conv_library = True   # set False to A/B the whole engine against round 4's graph
+    # 'auto': every undecided k x k shape is measured both ways by the plan pass (a stopwatch: the routes -- and with them the
+    # engine's bits, the library epilogue adds its bias in the activation dtype -- can differ from box to box); 'library' /
+    # 'two_pass': no measurement, every layer the library supports / no layer goes through it (deterministic; ODTK_CONV_ROUTE).
+    # A loaded plan (FusedRetinaNet.load_plan, ODTK_CONV_PLAN) pins the routes of its geometries whatever the mode.
+    route_mode = os.environ.get('ODTK_CONV_ROUTE', 'auto')
 
     def __init__(self, conv, bn=None, relu=False, dtype=torch.bfloat16):
         super().__init__()
@@ -190,7 +214,9 @@ class _Conv(nn.Module):
         engine plans the first few only: a data set's batches come in dozens of padded sizes) follows the layer's last measured
         decision."""
         route = self.route.get(key)
-        if route is None and _Conv.planning and not torch.cuda.is_current_stream_capturing():
+        if route is None and _Conv.route_mode != 'auto':
+            route = self.route[key] = (_Conv.route_mode == 'library', None, None)
+        if route is None and _planning() and not torch.cuda.is_current_stream_capturing():
             route = self.route[key] = self._measure(x, two, one)
             self.learned[kind] = route[0]
         if route is None:
@@ -282,6 +308,9 @@ class FusedRetinaNet(nn.Module):
         self._streams = None
         self.tower_plan = 0
         self._planned = set()                                           # input geometries whose k x k convolutions were routed (plan pass)
+        self._loaded_geometries = set()                                 # input shapes routed by a loaded plan (load_plan): never measured
+        self._plan_file_seen = False                                    # ODTK_CONV_PLAN was looked at
+        self.libraries_taken = None                                     # (gemm, conv) lines the libraries took from the last loaded plan
         self.max_plans = 4                                              # ... at most so many: a data set's batches come in dozens of padded sizes
         self._graphs = {}                                               # input geometry + bias state -> (hipGraph, static input, outputs, tables kept alive)
         self._thresholds = {}                                           # score threshold -> the prefilter's table for cls_head[-1].bias
@@ -303,7 +332,9 @@ class FusedRetinaNet(nn.Module):
                 and (x.is_contiguous() or x.is_contiguous(memory_format=torch.channels_last))):
             key = (tuple(x.shape), x.dtype, x.is_contiguous())
             route = self.stem_s2d.get(key)
-            if route is None and _Conv.planning and not torch.cuda.is_current_stream_capturing():
+            if route is None and _Conv.route_mode != 'auto':
+                route = self.stem_s2d[key] = (_Conv.route_mode == 'library', None, None)
+            if route is None and _planning() and not torch.cuda.is_current_stream_capturing():
                 route = self.stem_s2d[key] = self.stem._measure(x, self._stem_direct, self._stem_packed)
                 self.stem_learned = route[0]
             if route[0] if route is not None else self.stem_learned:
@@ -345,7 +376,7 @@ class FusedRetinaNet(nn.Module):
             t = c(t)
         return t
 
-    def _towers(self, feats, last_bias):
+    def _towers(self, feats, last_bias, level_streams=None):
         """Both head towers on every pyramid level.  The levels are independent and the small ones (P5-P7:
         8000 / 2080 / 560 pixels at bs 8) cannot fill 256 CUs on their own, so they run on side HIP streams
         next to P3's convolutions: [P3] on the caller's stream, [P4] and [P5, P6, P7] on two others."""
@@ -355,7 +386,9 @@ class FusedRetinaNet(nn.Module):
             return (self.cls_head[-1].conv_only(self._run(self.cls_head[:-1], t)),
                     self.box_head[-1].conv_only(self._run(self.box_head[:-1], t)))
 
-        if not self.level_streams or not feats[0].is_cuda or len(feats) < 3:
+        if level_streams is None:
+            level_streams = self.level_streams
+        if not level_streams or not feats[0].is_cuda or len(feats) < 3:
             out = [level(t) for t in feats]
             return [o[0] for o in out], [o[1] for o in out]
         main = torch.cuda.current_stream(feats[0].device)
@@ -439,22 +472,95 @@ class FusedRetinaNet(nn.Module):
     def plan(self, x):
         """Routes every k x k convolution for this input geometry: one pass over the graph on the caller's stream (no side
         streams: nothing runs beside a convolution while it is timed) in which each such convolution is run both ways -- the
-        convolution library's fused epilogue vs MIOpen + `odtk_bias_act` -- and keeps the faster (`_Conv.route`)."""
+        convolution library's fused epilogue vs MIOpen + `odtk_bias_act` -- and keeps the faster (`_Conv.route`).
+        ODTK_CONV_PLAN=<file>: the file's plan is loaded before anything is measured (its geometries are then never timed,
+        neither here nor inside the two kernel libraries); what a plan pass adds is written back to it."""
+        path = os.environ.get('ODTK_CONV_PLAN')
+        if path and not self._plan_file_seen:
+            self._plan_file_seen = True
+            if os.path.isfile(path):
+                with open(path) as f:
+                    self.load_plan(json.load(f))
         key = (tuple(x.shape), x.device)
         if key in self._planned or not x.is_cuda or not _C.conv_available() or not _Conv.use_conv_library:
+            return
+        if tuple(x.shape) in self._loaded_geometries:
+            self._planned.add(key)                                      # routed by a loaded plan: nothing to measure
             return
         if len(self._planned) >= self.max_plans:
             return                                                      # later geometries follow the layers' last measured decisions
         if torch.cuda.is_current_stream_capturing():
             return                                                      # (replay() warms up eagerly first: planned by then)
         with _PLAN_LOCK:
-            streams, _Conv.planning, self.level_streams = self.level_streams, True, False
+            _TLS.planning = True
             try:
                 with torch.autocast(x.device.type, enabled=False):
-                    self._towers(self.features(x), False)
+                    self._towers(self.features(x), False, level_streams=False)
             finally:
-                _Conv.planning, self.level_streams = False, streams
+                _TLS.planning = False
             self._planned.add(key)
+        if path:
+            self.save_plan(path)
+
+    # ---- reproducible plans (VERDICT r05 #4): the engine's bits depend on three stopwatches -- this file's A/B per layer, the
+    # convolution library's instance per problem, hipBLASLt's solution per problem -- none of which picks the same on every box
+    # (68 vs 70 of 75 layers routed to the library on two boxes of round 5), and the two routes of a layer round differently (the
+    # library's epilogue takes its bias in the activation dtype, `odtk_bias_act` adds it in fp32).  A plan names all three.
+    def plan_state(self):
+        """Everything the plan passes of this engine (and the libraries under it, process-wide) decided so far, as a JSON-able
+        dict: layer -> input geometry -> route, the stem's form, and the libraries' own lines."""
+        layers, learned = {}, {}
+        for name, mod in self.named_modules():
+            if isinstance(mod, _Conv):
+                if mod.route:
+                    layers[name] = {_key_str(k): int(bool(v[0])) for k, v in sorted(mod.route.items(), key=lambda kv: _key_str(kv[0]))}
+                if mod.learned:
+                    learned[name] = {k: bool(v) for k, v in sorted(mod.learned.items())}
+        stem = {}
+        for (shape, dtype, contiguous), v in (self.stem_s2d or {}).items():
+            stem['%s:%s:%d' % ('x'.join(str(int(d)) for d in shape), str(dtype).replace('torch.', ''), int(contiguous))] = int(bool(v[0]))
+        geometries = sorted({tuple(k[0]) for k in self._planned} | set(self._loaded_geometries))
+        return {'format': 'odtk-conv-plan-1', 'dtype': str(self.dtype).replace('torch.', ''), 'geometries': [list(g) for g in geometries],
+                'layers': layers, 'learned': learned, 'stem': dict(sorted(stem.items())), 'stem_learned': bool(self.stem_learned),
+                'libraries': sorted(line for line in _C.library_plans_export().splitlines() if line)}
+
+    def plan_hash(self, state=None):
+        """16 hex digits naming the active plan: routes + library lines (bench.py prints it next to `conv_epilogue`)."""
+        state = state or self.plan_state()
+        text = json.dumps({k: state[k] for k in ('dtype', 'layers', 'stem', 'libraries')}, sort_keys=True)
+        return hashlib.sha256(text.encode()).hexdigest()[:16]
+
+    def load_plan(self, state):
+        """Pins what `plan_state()` of an engine of the same architecture and dtype recorded: its geometries are never measured
+        again, neither by `plan()` nor -- for problems this process has not planned yet -- inside the two libraries."""
+        if state.get('format') != 'odtk-conv-plan-1':
+            raise ValueError('not an odtk conv plan: format %r' % (state.get('format'),))
+        if state.get('dtype') != str(self.dtype).replace('torch.', ''):
+            raise ValueError('the plan was made for %s, this engine runs %s' % (state.get('dtype'), self.dtype))
+        mods = {name: mod for name, mod in self.named_modules() if isinstance(mod, _Conv)}
+        unknown = sorted(set(state.get('layers', {})) - set(mods))
+        if unknown:
+            raise ValueError('the plan names layers this engine does not have: %s' % ', '.join(unknown[:4]))
+        for name, routes in state.get('layers', {}).items():
+            for text, use in routes.items():
+                mods[name].route[_str_key(text)] = (bool(use), None, None)
+        for name, kinds in state.get('learned', {}).items():
+            if name in mods:
+                mods[name].learned.update({k: bool(v) for k, v in kinds.items()})
+        if self.stem_s2d is not None:
+            for text, use in state.get('stem', {}).items():
+                shape, dtype, contiguous = text.split(':')
+                self.stem_s2d[(tuple(int(v) for v in shape.split('x')), getattr(torch, dtype), bool(int(contiguous)))] = (bool(use), None, None)
+            self.stem_learned = bool(state.get('stem_learned', self.stem_learned))
+        self._loaded_geometries.update(tuple(g) for g in state.get('geometries', []))
+        self.libraries_taken = _C.library_plans_import('\n'.join(state.get('libraries', [])) + '\n')
+        return self.libraries_taken
+
+    def save_plan(self, path):
+        tmp = '%s.%d.tmp' % (path, os.getpid())
+        with open(tmp, 'w') as f:
+            json.dump(self.plan_state(), f, indent=1, sort_keys=True)
+        os.replace(tmp, path)
 
     def conv_routes(self):
         """{layer name: {input shape: (library?, us library, us two-pass)}} of the plan passes so far (measurement records)."""
@@ -484,5 +590,12 @@ class FusedRetinaNet(nn.Module):
             if table is None and not torch.cuda.is_current_stream_capturing():
                 self._thresholds.clear()
                 table = self._thresholds[key] = _C.prefilter_thresholds(cls_bias, self.dtype, m.threshold)
+        if os.environ.get('ODTK_CHECK_FINITE'):
+            # debug: the library epilogue (AddClamp) turns a NaN accumulator into 0 / -inf where the two-pass route and the
+            # reference's graph hand the NaN on (include/odtk_conv.h) -- a diverged checkpoint must not pass as "no detections"
+            for name, heads in (('cls', cls_heads), ('box', box_heads)):
+                for i, t in enumerate(heads):
+                    if not bool(torch.isfinite(t).all()):
+                        raise FloatingPointError('FusedRetinaNet: non-finite values in the %s head tensor of level %d' % (name, i))
         return box_ops.detect(cls_heads, box_heads, strides, m.anchors, m.threshold, m.top_n, m.nms, m.detections,
                               m.rotated_bbox, logits=True, cls_bias=cls_bias, box_bias=box_bias, cls_thresholds=table)
