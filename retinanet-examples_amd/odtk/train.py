@@ -75,9 +75,13 @@ def lr_schedule(warmup, milestones, gamma):
 
 
 def prepare(model, device, lr=0.01, world=1, rank=0, warmup=1000, milestones=(), gamma=0.1, state=None,
-            bucket_cap_mb=25, weight_decay=0.0001):
-    """Frozen-BN conversion, channels_last, optimizer, DDP wrapper, LR schedule (reference train.py:29-59)."""
-    model = convert_fixedbn_model(model)
+            bucket_cap_mb=25, weight_decay=0.0001, frozen_bn=True):
+    """Frozen-BN conversion, channels_last, optimizer, DDP wrapper, LR schedule (reference train.py:29-59).
+    frozen_bn=False (not a reference option): the batch-norm layers stay live -- what training a backbone from its random
+    initialisation needs; the reference never does that (it starts from ImageNet weights, resnet.py:20-22), this image has no
+    weights to start from (tests/test_gpu_trained_ap.py pre-trains its detector this way, then fine-tunes frozen)."""
+    if frozen_bn:
+        model = convert_fixedbn_model(model)
     model = model.to(device)
     if device.type == 'cuda':
         model = model.to(memory_format=torch.channels_last)
@@ -133,7 +137,7 @@ def reduce_losses(cls_loss, box_loss, world, extra=None):
 
 def train_batches(model, state, batches, iterations, device, lr=0.01, warmup=1000, milestones=(), gamma=0.1, world=1,
                   rank=0, mixed_precision=True, log_every=60.0, save_path=None, verbose=True, log_interval=None,
-                  weight_decay=0.0001, validate=None, val_iterations=None, on_report=None):
+                  weight_decay=0.0001, validate=None, val_iterations=None, on_report=None, frozen_bn=True):
     """The training loop of reference train.py:18-214 over any source of (images, targets) batches.
 
     `validate(net, iteration)` is called on EVERY rank (it gathers detections) after iteration `iterations` and after every
@@ -149,7 +153,7 @@ def train_batches(model, state, batches, iterations, device, lr=0.01, warmup=100
     RANK 0's measured step time (target: one report per `log_every` seconds) and handed to every rank
     inside the loss all-reduce itself."""
     model, net, optimizer, scheduler = prepare(model, device, lr, world, rank, warmup, milestones, gamma, state,
-                                              weight_decay=weight_decay)
+                                              weight_decay=weight_decay, frozen_bn=frozen_bn)
     amp_dtype = torch.float16 if (mixed_precision and device.type == 'cuda') else None
     scaler = torch.amp.GradScaler('cuda', enabled=amp_dtype is not None) if amp_dtype is not None else None
     iteration = state.get('iteration', 0) if state else 0
