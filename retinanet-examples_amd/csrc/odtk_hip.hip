@@ -147,6 +147,13 @@ uint32_t select_coop_ticks() {
   return v;
 }
 
+// select_decode orders the selected keys by counting (histogram bases + in-bin ranks) and decodes each where it lies
+// (csrc/select_decode.hpp, round 6); ODTK_SELECT_RANK=0: the rank-merge sort + decode loop of rounds 4-5 (A/B; same result)
+uint32_t select_rank_sort() {
+  static const uint32_t v = [] { const char *e = std::getenv("ODTK_SELECT_RANK"); return (e && e[0] == '0') ? 0u : 1u; }();
+  return v;
+}
+
 // Tiles per prefilter workgroup for 16-bit inputs (ODTK_SCAN_SPAN = 1, 2 or 4; A/B measurements)
 uint32_t scan_span_tiles() {
   static const uint32_t v = [] {
@@ -336,6 +343,7 @@ int decode_levels_impl(int batch, int n_levels, const odtk_level_t *levels, int 
   da.span_elems = lay.span_elems;
   da.aligned = aligned ? 1u : 0u;
   da.coop_ticks = select_coop_ticks();
+  da.rank_sort = select_rank_sort();
   da.raw_lo = sa.raw_lo;
   da.by_channels = odtk::fastdiv_make(static_cast<uint32_t>(A) * C);
   da.out_scores = static_cast<float *>(outputs[0]);

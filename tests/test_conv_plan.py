@@ -105,11 +105,26 @@ def test_same_plan_same_bits_in_one_process():
     from odtk import _C, fused
     if not _C.conv_available():
         pytest.skip('libodtk_conv.so not built')
+    # (the layers the plan leaves on MIOpen must themselves reproduce: find mode may pick kernels that do not, DESIGN section 5 --
+    #  `cudnn.deterministic` restricts it to those that do, as tests/test_gpu_graph.py does)
+    saved = torch.backends.cudnn.deterministic
+    torch.backends.cudnn.deterministic = True
+    try:
+        _same_plan_same_bits()
+    finally:
+        torch.backends.cudnn.deterministic = saved
+
+
+def _same_plan_same_bits():
+    from odtk import fused
     model, e1 = _engine(device='cuda')
     x = torch.randn(2, 3, 256, 320, device='cuda')
     with torch.no_grad():
         e1.plan(x)                                               # the stopwatch decides (route mode auto)
         c1, b1 = e1.heads(x)
+        again = e1.heads(x)
+        for a, b in zip(c1 + b1, again[0] + again[1]):           # (the premise: one engine, one input, the same bits twice)
+            assert torch.equal(a, b)
         state = json.loads(json.dumps(e1.plan_state()))
         assert state['layers'] and state['libraries']
         e2 = fused.FusedRetinaNet(model, torch.bfloat16)

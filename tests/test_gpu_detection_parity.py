@@ -211,21 +211,15 @@ def test_engines_agree_with_fp32_eager_plus_oracle():
     assert same['matched'] < 0.5 * same['eligible'], same
     assert wide['matched'] >= 0.98 * wide['eligible'] and wide['max_dscore'] > MARGIN['engine_bf16'], wide
 
-    # the acceptance metric itself (COCO AP, odtk/cocoeval.py) with the planted objects as ground truth = the reference
-    # pipeline's detections scoring >= 0.15: every path is scored against the same truth, the reference pipeline included
-    # (its own low-score detections are its false positives)
+    # The AP of this construction is NO LONGER asserted (round 6).  Rounds 2-5 scored COCO AP against the planted objects and
+    # tolerated 0.045 (bf16) / 0.03 (fp16): the ridge-fitted last layer on random features is ill-conditioned (the same seed moved
+    # 2.5 AP points between boxes), and it overstated every low-precision path by an order of magnitude -- on a detector TRAINED by
+    # the product's own loop and scored against TRUE boxes (tests/test_gpu_trained_ap.py, profiles/r06_trained_ap.txt, two
+    # training seeds) fp16 is within 0.0002 AP of the fp32 reference pipeline, the timed bf16 engine within 0.0032, the eager
+    # graph under bf16 autocast within 0.0016 (this proxy said 0.67-0.81 for the last).  The figures are still printed.
     planted = ref[0] >= 0.15
     truth = (ref[0] * planted, ref[1] * planted[..., None], ref[2] * planted)
     ap = {name: coco_ap(truth, dets) for name, dets in [('reference', ref)] + list(paths.items())}
-    print('COCO AP against the planted objects:', {k: round(v, 4) for k, v in ap.items()})
+    print('COCO AP against the planted objects (proxy, not asserted beyond fp32):', {k: round(v, 4) for k, v in ap.items()})
     assert ap['reference'] > 0.5, ap
     assert abs(ap['engine_fp32'] - ap['reference']) <= 2e-3, ap          # the same detector
-    # measured on MI355X (round 2): reference 1.0, engine_fp32 1.0, engine_bf16 0.9833, eager autocast bf16 0.7668
-    # (tolerances: largest deviation measured over three seeds and three rounds + a margin below one flipped object:
-    #  profiles/r05_detection_ap_seeds.txt -- bf16 0.037, fp16 0.029 on the hard seed, 0.000 on this one)
-    assert abs(ap['engine_bf16'] - ap['reference']) <= 0.045, ap         # bf16 arithmetic of the timed path
-    assert ap['eager_autocast_bf16'] < ap['engine_bf16'] - 0.1, ap       # the eager graph's damped logits cost AP
-    # round 3 (ADVICE): `infer()`'s mixed precision is fp16 like the reference's -- three more mantissa bits than bf16
-    assert ap['engine_fp16'] >= ap['engine_bf16'] - 0.005, ap
-    assert abs(ap['engine_fp16'] - ap['reference']) <= 0.03, ap
-    assert ap['eager_autocast_fp16'] > ap['eager_autocast_bf16'], ap     # the fallback for models without a fused engine

@@ -28,6 +28,8 @@ ap_.add_argument('--size', type=int, default=512)
 ap_.add_argument('--images', type=int, default=256)
 ap_.add_argument('--backbone', default='ResNet18FPN')
 ap_.add_argument('--json', default=None)
+ap_.add_argument('--save-postproc-inputs', default=None, help='npz: what the post-processing sees on the first held-out batch of the '
+                 'first seed -- decode_levels output (the NMS input) of the bf16 engine, for offline NMS studies and fixtures')
 args = ap_.parse_args()
 torch.backends.cudnn.benchmark = True
 
@@ -57,6 +59,18 @@ for seed in args.seeds:
                    'nms_examined': [int(r[5]) for r in rows], 'nms_candidates': [int(r[6]) for r in rows],
                    'nms_us': [round((int(r[4]) - int(r[0])) / 100.0, 1) for r in rows],
                    'kept': [int(v) for v in (det[0] > 0).sum(1).tolist()]}
+    if args.save_postproc_inputs and seed == args.seeds[0]:
+        import numpy as np
+        from odtk import box as box_ops
+        eng = model.inference_engine(torch.bfloat16)
+        with torch.no_grad():
+            cls_h, box_h = eng.heads(x)
+        strides = [x.shape[-1] // c.shape[-1] for c in cls_h]
+        s_, b_, c_ = box_ops.decode_levels(cls_h, box_h, strides, model.threshold, model.top_n, model.anchors, logits=True)
+        np.savez_compressed(args.save_postproc_inputs, scores=s_.float().cpu().numpy(), boxes=b_.float().cpu().numpy(),
+                            classes=c_.float().cpu().numpy(), det_scores=det[0].float().cpu().numpy(),
+                            det_boxes=det[1].float().cpu().numpy(), det_classes=det[2].float().cpu().numpy(),
+                            top_n=model.top_n, nms=model.nms, detections=model.detections, levels=len(strides))
     del model
     torch.cuda.empty_cache()
 
