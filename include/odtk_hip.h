@@ -188,6 +188,19 @@ int odtk_nms_ex(int batch_size, const void *const *inputs, void *const *outputs,
                 void *workspace, size_t workspace_size, void *stream);
 
 /*
+ * odtk_nms_sorted_runs -- odtk_nms_ex for a caller who KNOWS how its candidates are ordered: `count` = n_runs (<= 8) runs of
+ * `run_len` candidates, each run sorted by (score desc, position asc) with its non-positive scores at the end -- what decode
+ * writes per level and `torch.cat(per_level, 1)` lays side by side (reference odtk/model.py:153-164) -- and run_valid DEVICE
+ * uint32 [batch, n_runs] = the entries with a positive score at the head of every run.  The kernel then takes its rounds as
+ * prefixes of the runs (no compaction, no radix selection, no sort: csrc/nms.hpp "sorted runs"); odtk_detect calls the same
+ * code with what its own decode wrote.  Same outputs as odtk_nms_ex on the same candidates; a run that is NOT sorted is the
+ * caller's bug.  (Also what tools/nms_clustered_probe.py replays a trained detector's candidates through.)
+ */
+int odtk_nms_sorted_runs(int batch_size, const void *const *inputs, void *const *outputs, int n_outputs, size_t count,
+                         int run_len, const uint32_t *run_valid, int detections_per_im, float nms_thresh, uint32_t flags,
+                         void *workspace, size_t workspace_size, void *stream);
+
+/*
  * odtk_detect -- decode_levels + nms back to back on one stream (the whole post-processing of
  * odtk/model.py:153-165 in 3 launches).  outputs as odtk_nms; workspace holds the candidates.
  */

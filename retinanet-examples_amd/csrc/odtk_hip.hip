@@ -847,6 +847,15 @@ int odtk_nms_ex(int batch_size, const void *const *inputs, void *const *outputs,
                   workspace, workspace_size, static_cast<hipStream_t>(stream));
 }
 
+int odtk_nms_sorted_runs(int batch_size, const void *const *inputs, void *const *outputs, int n_outputs, size_t count,
+                         int run_len, const uint32_t *run_valid, int detections_per_im, float nms_thresh, uint32_t flags,
+                         void *workspace, size_t workspace_size, void *stream) {
+  if (run_len <= 0 || count % static_cast<size_t>(run_len) != 0 || count / run_len > 8) return ODTK_ERR_INVALID;
+  if (workspace && workspace_size && !run_valid) return ODTK_ERR_INVALID;
+  return nms_impl(batch_size, inputs, outputs, n_outputs, count, detections_per_im, nms_thresh, flags, workspace, workspace_size,
+                  static_cast<hipStream_t>(stream), static_cast<uint32_t>(run_len), run_valid);
+}
+
 int odtk_iou(const void *const *inputs, void *const *outputs, int num_boxes, int num_anchors, void *stream) {
   if (num_boxes < 0 || num_anchors < 0) return ODTK_ERR_INVALID;
   const long long pairs = 1ll * num_boxes * num_anchors;

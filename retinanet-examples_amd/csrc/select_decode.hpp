@@ -43,7 +43,8 @@ constexpr uint32_t kKeysPerPart = 3072;         // candidates per workgroup: a s
 constexpr uint32_t kCntSlots = 2048;            // sub-list lengths a workgroup keeps in LDS (512 spans)
 constexpr uint32_t kSpansPerPart = 44;          // host: workgroups provided per segment = ceil(spans / this), <= kMaxParts
 constexpr uint32_t kMaxParts = 64;
-constexpr uint32_t kMaxInBin = 128;              // rank-by-counting: keys one histogram bin may hold (more: a plateau -> the rank-merge sort)
+constexpr uint32_t kMaxInBin = 640;              // rank-by-counting: keys one histogram bin may hold ...
+constexpr uint32_t kMaxInBinSquares = 500000;    // ... and the sum over the bins of their squared counts = in-bin comparisons (more: plateaus -> the rank-merge sort)
 constexpr int kHistCopies = 4;                  // sub-histograms of select_threshold (standard kernel): lane l adds to copy l % 4
 
 // LDS carve-up of select_decode_kernel (one dynamic allocation: more than the 64 KiB a kernel may declare statically)
@@ -1253,22 +1254,30 @@ __global__ __launch_bounds__(kSelThreads) void select_decode_kernel(const Decode
       c1 = 2 * tid + 1 < hist_bins ? c1 : 0u;
       const uint32_t inc = wave_inclusive_sum_dpp(c0 + c1);
       uint32_t mx = c0 > c1 ? c0 : c1;
+      uint32_t sq = (c0 > kMaxInBin ? kMaxInBinSquares : c0 * c0) + (c1 > kMaxInBin ? kMaxInBinSquares : c1 * c1);   // (no overflow)
 #pragma unroll
-      for (int dlt = 32; dlt > 0; dlt >>= 1) { const uint32_t o = __shfl_xor(mx, dlt, kWave); mx = o > mx ? o : mx; }
+      for (int dlt = 32; dlt > 0; dlt >>= 1) {
+        const uint32_t o = __shfl_xor(mx, dlt, kWave);
+        mx = o > mx ? o : mx;
+        sq += __shfl_xor(sq, dlt, kWave);
+        sq = sq > 4u * kMaxInBinSquares ? 4u * kMaxInBinSquares : sq;
+      }
       const int wv = tid >> 6;
       if (lane_id() == kWave - 1) s_misc[wv] = inc;
-      if (lane_id() == 0) s_misc[32 + wv] = mx;
+      if (lane_id() == 0) { s_misc[32 + wv] = mx; s_misc[48 + wv] = sq; }
       __syncthreads();                                       // every thread has read its bins: s_hist may be rewritten
-      uint32_t woff = 0, all = 0, worst = 0;
+      uint32_t woff = 0, all = 0, worst = 0, squares = 0;
       for (int i = 0; i < kSelWaves; ++i) {
         const uint32_t tt = s_misc[i];
         woff += i < wv ? tt : 0u;
         all += tt;
         worst = s_misc[32 + i] > worst ? s_misc[32 + i] : worst;
+        squares += s_misc[48 + i];
       }
       all = __builtin_amdgcn_readfirstlane(all);
       worst = __builtin_amdgcn_readfirstlane(worst);
-      if (all == n_sort && worst <= kMaxInBin) {             // (block-uniform) the histogram IS the buffer's, no plateau
+      squares = __builtin_amdgcn_readfirstlane(squares);
+      if (all == n_sort && worst <= kMaxInBin && squares <= kMaxInBinSquares) {   // (block-uniform) the histogram IS the buffer's, no wide plateau
         ranked = true;
         uint32_t *s_base = s_hist, *s_cur = s_hist + kRadixBins;          // bin -> first slot | keys placed so far (= its count, in the end)
         uint64_t *s_grp = s_keys + 2 * kSelThreads;                      // the keys grouped by bin (second half of the sort buffer)
@@ -1303,7 +1312,13 @@ __global__ __launch_bounds__(kSelThreads) void select_decode_kernel(const Decode
           if (have[hh]) {
             const uint32_t base = s_base[bin[hh]], cnt = s_cur[bin[hh]];
             uint32_t rank = base;
-            for (uint32_t j = 0; j < cnt; ++j) rank += s_grp[base + j] > key[hh] ? 1u : 0u;
+            for (uint32_t j = 0; j < cnt; j += 8) {          // eight independent LDS reads per trip (a one-read trip pays the LDS latency per key of the bin)
+              uint64_t o[8];
+#pragma unroll
+              for (int u = 0; u < 8; ++u) o[u] = s_grp[base + (j + u < cnt ? j + u : cnt - 1)];
+#pragma unroll
+              for (int u = 0; u < 8; ++u) rank += (j + u < cnt && o[u] > key[hh]) ? 1u : 0u;
+            }
             if (rank < k_out) pos = emit(key[hh], rank, true) > 0.0f;
           }
           positives += static_cast<uint32_t>(__popcll(__ballot(pos)));

@@ -112,6 +112,8 @@ _SIGNATURES = {
                                                ctypes.c_int, ctypes.c_void_p]),
     'odtk_stem_pack': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                       ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    'odtk_nms_sorted_runs': (ctypes.c_int, [ctypes.c_int, _vpp, _vpp, ctypes.c_int, _sz, ctypes.c_int, _vp, ctypes.c_int, ctypes.c_float,
+                                            ctypes.c_uint32, _vp, _sz, _vp]),
     'odtk_gemm_init': (ctypes.c_int, [ctypes.c_char_p]),
     'odtk_gemm_plan_export': (ctypes.c_size_t, [ctypes.c_char_p, ctypes.c_size_t]),
     'odtk_gemm_plan_import': (ctypes.c_int, [ctypes.c_char_p]),
@@ -287,6 +289,34 @@ def nms(scores, boxes, classes, nms_thresh, detections_per_im, rotated=False, re
         _check(lib.odtk_nms_ex(batch, _ptrs([scores, boxes, classes]), _ptrs(out), len(out), count,
                                int(detections_per_im), float(nms_thresh), flags, ws.data_ptr(), ws.numel(), stream),
                'nms')
+    return out
+
+
+def nms_sorted_runs(scores, boxes, classes, run_len, nms_thresh, detections_per_im, rotated=False):
+    """`nms` for candidates that are n_runs = count / run_len runs, each already in NMS order with its non-positive scores at
+    the end -- the concatenation of per-level `decode` outputs (include/odtk_hip.h: odtk_nms_sorted_runs).  Same result as
+    `nms`, without its compaction / selection / sort rounds."""
+    _check_input(scores, 'scores')
+    _check_input(boxes, 'boxes')
+    _check_input(classes, 'classes')
+    lib = library()
+    nb = 6 if rotated else 4
+    batch, count = scores.shape
+    if boxes.shape != (batch, count, nb) or classes.shape != (batch, count) or count % int(run_len):
+        raise RuntimeError('nms_sorted_runs: inconsistent shapes')
+    dev = scores.device
+    with torch.cuda.device(dev):
+        run_valid = (scores.view(batch, count // int(run_len), int(run_len)) > 0).sum(2).to(torch.int32).contiguous()
+        out = [torch.empty((batch, detections_per_im), dtype=torch.float32, device=dev),
+               torch.empty((batch, detections_per_im, nb), dtype=torch.float32, device=dev),
+               torch.empty((batch, detections_per_im), dtype=torch.float32, device=dev)]
+        flags = FLAG_ROTATED if rotated else 0
+        size = _check(lib.odtk_nms_sorted_runs(batch, None, None, 3, count, int(run_len), None, int(detections_per_im),
+                                               float(nms_thresh), flags, None, 0, None), 'nms_sorted_runs (workspace query)')
+        ws, stream = _workspace(dev, size)
+        _check(lib.odtk_nms_sorted_runs(batch, _ptrs([scores, boxes, classes]), _ptrs(out), 3, count, int(run_len),
+                                        run_valid.data_ptr(), int(detections_per_im), float(nms_thresh), flags, ws.data_ptr(),
+                                        ws.numel(), stream), 'nms_sorted_runs')
     return out
 
 

@@ -101,6 +101,18 @@ def test_nms_vs_reference_fixture(path):
     assert_bits(out[2], g['out_classes'], 'classes')
 
 
+@pytest.mark.parametrize('path', _cases('nms_ties'), ids=os.path.basename)
+def test_nms_on_a_trained_detectors_tied_candidates(path):
+    """The NMS input of a TRAINED detector's bf16 engine (clusters of overlapping same-class candidates, 16-bit scores tying in the
+    hundreds; oracle/gen_golden_trained_nms.py): the canonical rule (score desc, position asc), bit for bit -- through the
+    stand-alone op (arbitrary order in, generic rounds) and with the candidates handed over in `detect`'s sorted-run form."""
+    g = _load(path)
+    out = box.nms(cuda(g['scores']), cuda(g['boxes']), cuda(g['classes']), float(g['nms']), int(g['detections']))
+    assert_bits(out[0], g['out_scores'], 'scores')
+    assert_bits(out[1], g['out_boxes'], 'boxes')
+    assert_bits(out[2], g['out_classes'], 'classes')
+
+
 @pytest.mark.parametrize('path', _cases('pipeline'), ids=os.path.basename)
 def test_pipeline_vs_reference_fixture(path):
     g = _load(path)

@@ -69,6 +69,21 @@ def test_nms_matches_reference_fixture(path):
         assert _bit_equal(o, g[k])
 
 
+@pytest.mark.parametrize('path', _cases('nms_ties'), ids=os.path.basename)
+def test_oracle_nms_on_tied_scores_follows_the_canonical_rule(path):
+    """What a trained detector's bf16 engine hands the NMS (tests/golden/nms_trained_scenes_ties.npz, oracle/gen_golden_trained_nms.py):
+    hundreds of candidates per distinct score.  The reference's CPU branch leaves ties to an unstable sort; the expected outputs
+    follow the canonical rule (score desc, position asc = the reference's CUDA path, nms.cu:136-137) -- the oracle and the product's
+    own CPU branch (odtk/box.py:_nms_cpu) must both produce them."""
+    from odtk import box as product_box
+    g = np.load(path)
+    args = (torch.from_numpy(g['scores']), torch.from_numpy(g['boxes']), torch.from_numpy(g['classes']), float(g['nms']), int(g['detections']))
+    for name, fn in (('oracle', box_oracle.nms), ('odtk.box CPU branch', product_box.nms)):
+        out = fn(*args)
+        for got, key in zip(out, ('out_scores', 'out_boxes', 'out_classes')):
+            assert torch.equal(got, torch.from_numpy(g[key])), (name, key)
+
+
 @pytest.mark.parametrize('path', _cases('pipeline'), ids=os.path.basename)
 def test_pipeline_matches_reference_fixture(path):
     g = _load(path)
