@@ -48,6 +48,7 @@ constexpr int kNmsRound = 1024;        // keys selected + ordered per round (one
 constexpr int kNmsChunk = 64;          // candidates resolved per chunk: one wave-width
 constexpr int kPairQueue = kRadixBins; // rotated: (box, box) pairs per queue slab -- the queue lives in the histogram's 8 KiB
 constexpr int kNmsMisc = 160;          // words of s_misc
+constexpr uint32_t kNmsFlagChunks = 0x80000000u;   // internal (NmsArgs::flags): axis-aligned rounds through the chunk loop of rounds 3-5 (A/B)
 
 struct NmsArgs {
   uint64_t *key_scratch;   // [batch, count] keys in the workspace when count > ODTK_MAX_NMS_COUNT (else unused)
@@ -563,7 +564,7 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsArgs a) {
     // "best alive candidate next") and one parallel test of every alive candidate against it -- ~0.7 us per kept box, where a
     // round costs ~10 us of selection and sorting before its first box.
     if constexpr (NB == 4) {
-      if (!runs && !first_round && left <= 4u * kNmsThreads && list_n <= 4u * kNmsThreads &&
+      if ((a.flags & kNmsFlagChunks) && !runs && !first_round && left <= 4u * kNmsThreads && list_n <= 4u * kNmsThreads &&
           static_cast<uint32_t>(last_round_kept) * 20u < last_round_size) {
         constexpr int kOwn = 4;
         static_assert(kOwn == 4, "the pull below is written out four times");
@@ -922,7 +923,117 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsArgs a) {
     // round, and per KEPT box one parallel pass -- the first candidate still alive is kept and every alive candidate behind
     // it of its class tests itself against it (~0.6 us per kept box: one LDS-broadcast box, one IoU, one ballot).
     bool pushed = false;
+    // ---- axis-aligned, round 6: BATCHED PUSH -- the round is resolved 64 ALIVE candidates at a time ----
+    // What a trained detector hands the NMS is not what the synthetic heads of the bench are: clusters of dozens of overlapping
+    // same-class candidates around every object, 50-100 % of all candidates examined, 2-100 kept (profiles/r06_trained_ap.txt:
+    // 20-240 us per image with the chunk loop below, which walks the round 64 RANKS at a time, dead candidates included, and
+    // pays two barriers, a pull and a serial resolve per chunk for a handful of kept boxes).  Here thread <-> candidate for the
+    // whole round; per trip (a) the first 64 candidates still alive are compacted (ballots + a prefix over the sixteen words),
+    // (b) the sixteen waves compute their pairwise suppression rows, (c) wave 0 resolves them in rank order with scalar bit
+    // arithmetic exactly as a chunk is resolved, and (d) every candidate behind the batch tests itself against the boxes the
+    // batch kept -- so a kept box clears its whole cluster out of the round at once, and the next batch starts at the next
+    // candidate that is really still alive.  Same verdicts in the same order as the greedy loop (a batch member has survived
+    // every box kept before the batch; inside the batch the rows are resolved in rank order; everything behind is tested against
+    // what the batch kept before it is looked at).  kNmsFlagChunks (ODTK_NMS_CHUNKS=1): rounds 3-5's chunk loop, A/B.
     if constexpr (NB == 4) {
+      if (!(a.flags & kNmsFlagChunks) && !first_round) {     // (the first round stays with the chunk loop: on a detector that keeps most of what it examines -- one round, 100 kept of ~230 -- that form is the faster one)
+        pushed = true;
+        const uint32_t r = static_cast<uint32_t>(tid);
+        float jb[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) jb[k] = r < n_round ? s_box[r * 4 + k] : 0.0f;
+        const float jc = r < n_round ? s_cls[r] : 0.0f;
+        bool alive = r < n_round;
+        if (alive && kept > pulled) alive = pull_against_kept(s_kcls, s_kbox, pulled, kept, 1, jb, jc, true, thr);
+        uint32_t *s_bidx = reinterpret_cast<uint32_t *>(s_sup + kNmsChunk);   // the batch's ranks (the second rows buffer is idle in this mode)
+        while (kept < ndet) {                                  // block-uniform trip count
+          // (a) the first 64 candidates still alive, in rank order
+          const uint64_t word = __ballot(alive);
+          if (lane == 0) s_alive[wave] = word;
+          __syncthreads();
+          uint32_t before = 0, total = 0;
+          for (int w = 0; w < kNmsThreads / kWave; ++w) {
+            const uint32_t cw = static_cast<uint32_t>(__popcll(s_alive[w]));
+            before += w < wave ? cw : 0u;
+            total += cw;
+          }
+          total = __builtin_amdgcn_readfirstlane(total);
+          if (total == 0) break;                               // (block-uniform) nobody left in this round
+          const uint32_t n_b = total < static_cast<uint32_t>(kNmsChunk) ? total : static_cast<uint32_t>(kNmsChunk);
+          const uint32_t slot = before + static_cast<uint32_t>(__popcll(word & ((1ull << lane) - 1ull)));
+          const bool member = alive && slot < n_b;
+          if (member) s_bidx[slot] = r;
+          __syncthreads();
+          phase(10);
+          // (b) suppression rows of the batch: lane <-> batch slot j, wave w takes the rows i = w, w + 16, ...
+          {
+            const uint32_t rj = static_cast<uint32_t>(lane) < n_b ? s_bidx[lane] : 0u;
+            float qb[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) qb[k] = s_box[rj * 4 + k];
+            const float qc = s_cls[rj];
+            for (uint32_t i = static_cast<uint32_t>(wave); i < n_b; i += static_cast<uint32_t>(kNmsThreads / kWave)) {
+              const uint32_t ri = s_bidx[i];                   // same address in every lane: LDS broadcast
+              const float ic = s_cls[ri];
+              const bool rival = static_cast<uint32_t>(lane) > i && static_cast<uint32_t>(lane) < n_b && qc == ic;
+              uint64_t row = 0;
+              if (__ballot(rival)) {                           // wave-uniform
+                float ib[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) ib[k] = s_box[ri * 4 + k];
+                row = __ballot(rival && axis_suppresses(ib, qb, thr));
+              }
+              if (lane == 0) s_sup[i] = row;
+            }
+          }
+          __syncthreads();
+          phase(11);
+          // (c) wave 0 resolves the batch in rank order (scalar bit operations; the chunk loop's resolve)
+          const int kept_before = kept;
+          if (wave == 0) {
+            const uint64_t my_row = static_cast<uint32_t>(lane) < n_b ? s_sup[lane] : 0;
+            const uint32_t row_lo = static_cast<uint32_t>(my_row), row_hi = static_cast<uint32_t>(my_row >> 32);
+            uint64_t mask = n_b >= 64u ? ~0ull : ((1ull << n_b) - 1ull);
+            uint64_t kept_mask = 0;
+            int k_cnt = kept_before;
+            while (mask && k_cnt < ndet) {
+              const uint64_t hot = __ballot((my_row & mask) != 0) & mask;
+              uint64_t run = hot ? mask & ((hot & (0ull - hot)) - 1ull) : mask;
+              const int room = ndet - k_cnt;
+              while (__popcll(run) > room) run &= ~(1ull << (63 - __clzll(static_cast<long long>(run))));
+              kept_mask |= run;
+              k_cnt += __popcll(run);
+              mask &= ~run;
+              if (!hot || k_cnt >= ndet) break;
+              const int l0 = __ffsll(static_cast<unsigned long long>(hot)) - 1;
+              const uint64_t row = (static_cast<uint64_t>(static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(row_hi), l0))) << 32) |
+                                   static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(row_lo), l0));
+              kept_mask |= 1ull << l0;
+              mask &= ~(row | (1ull << l0));
+              ++k_cnt;
+            }
+            if ((kept_mask >> lane) & 1ull) {
+              const int my_rank = kept_before + __popcll(kept_mask & ((1ull << lane) - 1ull));
+              const uint32_t rr = s_bidx[lane];
+              const uint64_t key = s_sel[rr];
+#pragma unroll
+              for (int k = 0; k < 4; ++k) s_kbox[my_rank * 4 + k] = s_box[rr * 4 + k];
+              s_kcls[my_rank] = s_cls[rr];
+              s_kscore[my_rank] = key_score(key);
+              s_ksrc[my_rank] = static_cast<int32_t>(key_index(key));
+            }
+            if (lane == 0) s_misc[34] = static_cast<uint32_t>(k_cnt);
+          }
+          __syncthreads();
+          kept = __builtin_amdgcn_readfirstlane(static_cast<int>(s_misc[34]));
+          phase(12);
+          // (d) the batch is settled; everybody behind it meets the boxes it kept
+          if (member) alive = false;
+          else if (alive && kept > kept_before) alive = pull_against_kept(s_kcls, s_kbox, kept_before, kept, 1, jb, jc, true, thr);
+          phase(13);
+        }
+        __syncthreads();                                       // (s_alive / the batch buffers are reused by whatever follows)
+      } else
       if (!first_round && static_cast<uint32_t>(last_round_kept) * 20u < last_round_size) {
         pushed = true;
         const uint32_t r = static_cast<uint32_t>(tid);

@@ -137,20 +137,32 @@ int scan_image_major() {
 
 // select_decode's cooperative route (csrc/select_decode.hpp): how long a workgroup waits for the partners of its segment, in ticks
 // of the 100 MHz wall clock, before the segment falls back to the tournament.  ODTK_SELECT_COOP_TICKS: 0 = route off (A/B),
-// 1 = every barrier times out at once unless the partners are already there (exercises the fall-back), default 3000 = 30 us.
+// 1 = every barrier times out at once unless the partners are already there (exercises the fall-back), default 1000 = 10 us:
+// measured where the kernel runs -- inside Model.forward, level streams on, 200 traced steps = 3200 shared segments
+// (profiles/r06_select_routes_instep.txt) -- every segment went the cooperative route and workgroup 0 sat 2.1 us (p50) / 3.1 us
+// (p99) / 3.4 us (max) between "slice fetched" and "barrier passed", its own histogram atomics included; the same with a 5 us
+// bound.  10 us is three times the longest wait seen; a partner that is NOT resident costs its segment 10 us, not round 5's 30.
 uint32_t select_coop_ticks() {
   static const uint32_t v = [] {
     const char *e = std::getenv("ODTK_SELECT_COOP_TICKS");
-    const long x = e ? std::atol(e) : 3000;
+    const long x = e ? std::atol(e) : 1000;
     return static_cast<uint32_t>(x < 0 ? 0 : (x > 1000000 ? 1000000 : x));
   }();
   return v;
 }
 
-// select_decode orders the selected keys by counting (histogram bases + in-bin ranks) and decodes each where it lies
-// (csrc/select_decode.hpp, round 6); ODTK_SELECT_RANK=0: the rank-merge sort + decode loop of rounds 4-5 (A/B; same result)
+// ODTK_SELECT_RANK=1: select_decode orders the selected keys by COUNTING (histogram bases + in-bin ranks) and decodes each where
+// it lies (csrc/select_decode.hpp, round 6) instead of the rank-merge sort + decode loop of rounds 4-5.  Same result
+// (the GPU suite passes either way); NOT the default: measured slower on the bench's bf16 heads, whose boundary score is a
+// plateau of 300-500 equal 16-bit scores (37.4 vs 30.0 us in the step; profiles/r06_select_rank_by_counting.txt).
 uint32_t select_rank_sort() {
-  static const uint32_t v = [] { const char *e = std::getenv("ODTK_SELECT_RANK"); return (e && e[0] == '0') ? 0u : 1u; }();
+  static const uint32_t v = [] { const char *e = std::getenv("ODTK_SELECT_RANK"); return (e && e[0] == '1') ? 1u : 0u; }();
+  return v;
+}
+
+// axis-aligned NMS rounds: batched push (round 6, csrc/nms.hpp) or, ODTK_NMS_CHUNKS=1, the chunk loop of rounds 3-5 (A/B; same result)
+bool nms_chunk_mode() {
+  static const bool v = [] { const char *e = std::getenv("ODTK_NMS_CHUNKS"); return e && e[0] == '1'; }();
   return v;
 }
 
@@ -486,7 +498,7 @@ int nms_impl(int batch, const void *const *inputs, void *const *outputs, int n_o
   na.run_valid = run_valid;
   na.ndet = ndet;
   na.thresh = thresh;
-  na.flags = flags;
+  na.flags = flags | (nms_chunk_mode() ? odtk::kNmsFlagChunks : 0u);
   na.trace = g_trace ? g_trace + 8 * 64 : nullptr;          // after the select_decode slots
   na.key_scratch = global_keys ? static_cast<uint64_t *>(workspace) : nullptr;
   const size_t lds = odtk::NmsLds(na.count, ndet, nb, global_keys).total;   // same carve-up the kernel computes

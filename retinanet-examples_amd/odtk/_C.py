@@ -872,7 +872,7 @@ def conv_available():
     return conv_library() is not None
 
 
-def conv_bias_act(x, weight, bias, stride=(1, 1), padding=(1, 1), relu=True):
+def conv_bias_act(x, weight, bias, stride=(1, 1), padding=(1, 1), relu=True, out=None):
     """act(conv2d(x, weight) + bias) of a channels_last bf16 / fp16 activation in ONE launch: a composable_kernel implicit-GEMM
     convolution with the bias and the ReLU in its epilogue (include/odtk_conv.h: odtk_conv_bias_act).  x [B, Cin, H, W]
     channels_last, weight [Cout, Cin, kh, kw] channels_last (= K, Y, X, C in memory), bias [Cout] of x.dtype.  The first call
@@ -897,7 +897,13 @@ def conv_bias_act(x, weight, bias, stride=(1, 1), padding=(1, 1), relu=True):
     # padding (before, after) per dimension: ((top, bottom), (left, right)) -- the space-to-depth stem needs (2, 1)
     (ph0, ph1), (pw0, pw1) = [(p, p) if isinstance(p, int) else p for p in (ph, pw)]
     ho, wo = (h + ph0 + ph1 - kh) // sh + 1, (w + pw0 + pw1 - kw) // sw + 1
-    y = torch.empty((b, k, ho, wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    if out is None:
+        y = torch.empty((b, k, ho, wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    else:                                                    # caller-owned output (the engine's head-tensor arena)
+        if tuple(out.shape) != (b, k, ho, wo) or out.dtype != x.dtype or out.device != x.device or \
+                not out.is_contiguous(memory_format=torch.channels_last):
+            raise RuntimeError('conv_bias_act: out must be a channels_last %s tensor of shape %s' % (x.dtype, (b, k, ho, wo)))
+        y = out
     with torch.cuda.device(x.device):
         stream = torch.cuda.current_stream(x.device).cuda_stream
         _check(lib.odtk_conv_bias_act_pads(y.data_ptr(), x.data_ptr(), weight.data_ptr(), bias.data_ptr(), b, c, h, w, k, kh, kw,

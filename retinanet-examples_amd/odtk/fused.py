@@ -128,7 +128,7 @@ class _Conv(nn.Module):
         self.learned = {}                                               # kind ('act' | 'only') -> the last measured decision: unplanned geometries follow it
         self.route = {}                                                 # input shape -> (use the library, us library, us miopen + epilogue)
 
-    def conv_only(self, x):
+    def conv_only(self, x, out=None):
         """The convolution without its epilogue (the caller owns the bias: the heads' last convolutions, whose bias the
         post-processing kernels add).  Routed like `forward`: the library's instance list is a second find space for the same
         contraction (a zero bias, no clamp), taken where the plan pass measured it faster than MIOpen's pick."""
@@ -139,17 +139,18 @@ class _Conv(nn.Module):
                 self.zero_bias = torch.zeros_like(self.bias_lp)
             if self._routed(key, 'only', x, self._miopen_only, self._library_only):
                 try:
-                    return self._library_only(x)
+                    return self._library_only(x, out)
                 except RuntimeError:
                     self.route[key] = (False, float('inf'), 0.0)
-        return self._miopen_only(x)
+        y = self._miopen_only(x)
+        return y if out is None else out.copy_(y)                       # (MIOpen owns its output: an arena then costs a copy)
 
     def _miopen_only(self, x):
         y = F.conv2d(x, self.weight, None, self.stride, self.padding, groups=self.groups)
         return y if y.is_contiguous(memory_format=torch.channels_last) else y.contiguous(memory_format=torch.channels_last)
 
-    def _library_only(self, x):
-        return _C.conv_bias_act(x, self.weight, self.zero_bias, self.stride, self.padding, False)
+    def _library_only(self, x, out=None):
+        return _C.conv_bias_act(x, self.weight, self.zero_bias, self.stride, self.padding, False, out=out)
 
     def _two_pass(self, x, residual=None):
         y = F.conv2d(x, self.weight, None, self.stride, self.padding, groups=self.groups)
@@ -308,6 +309,8 @@ class FusedRetinaNet(nn.Module):
         self._streams = None
         self.tower_plan = 0
         self._planned = set()                                           # input geometries whose k x k convolutions were routed (plan pass)
+        self.cls_arena = bool(os.environ.get('ODTK_CLS_ARENA'))           # experiment: cls head tensors in one 2 MiB-aligned buffer (_cls_arena)
+        self._arenas = {}
         self._loaded_geometries = set()                                 # input shapes routed by a loaded plan (load_plan): never measured
         self._plan_file_seen = False                                    # ODTK_CONV_PLAN was looked at
         self.libraries_taken = None                                     # (gemm, conv) lines the libraries took from the last loaded plan
@@ -380,16 +383,18 @@ class FusedRetinaNet(nn.Module):
         """Both head towers on every pyramid level.  The levels are independent and the small ones (P5-P7:
         8000 / 2080 / 560 pixels at bs 8) cannot fill 256 CUs on their own, so they run on side HIP streams
         next to P3's convolutions: [P3] on the caller's stream, [P4] and [P5, P6, P7] on two others."""
-        def level(t):
+        arena = self._cls_arena(feats) if (self.cls_arena and not last_bias and feats[0].is_cuda and not _planning()) else None
+
+        def level(t, i):
             if last_bias:
                 return self._run(self.cls_head, t), self._run(self.box_head, t)
-            return (self.cls_head[-1].conv_only(self._run(self.cls_head[:-1], t)),
+            return (self.cls_head[-1].conv_only(self._run(self.cls_head[:-1], t), None if arena is None else arena[i]),
                     self.box_head[-1].conv_only(self._run(self.box_head[:-1], t)))
 
         if level_streams is None:
             level_streams = self.level_streams
         if not level_streams or not feats[0].is_cuda or len(feats) < 3:
-            out = [level(t) for t in feats]
+            out = [level(t, i) for i, t in enumerate(feats)]
             return [o[0] for o in out], [o[1] for o in out]
         main = torch.cuda.current_stream(feats[0].device)
         if self._streams is None or self._streams[0].device != feats[0].device:
@@ -408,17 +413,41 @@ class FusedRetinaNet(nn.Module):
             stream.wait_event(ready)                                    # the pyramid is complete
             with torch.cuda.stream(stream):
                 for i in group:
-                    out[i] = level(feats[i])
+                    out[i] = level(feats[i], i)
                     for t in out[i]:
                         t.record_stream(main)                           # consumed by the post-processing on `main`
                 e = torch.cuda.Event()
                 e.record(stream)
                 done.append(e)
         for i in mine:
-            out[i] = level(feats[i])
+            out[i] = level(feats[i], i)
         for e in done:
             main.wait_event(e)
         return [o[0] for o in out], [o[1] for o in out]
+
+    def _cls_arena(self, feats):
+        """Experiment (ODTK_CLS_ARENA=1): the five cls head tensors -- the 245 MB the prefilter streams -- in ONE
+        engine-owned buffer, every level on a 2 MiB boundary, allocated once per geometry and kept (the same virtual pages every
+        step, aligned to the largest page-table fragment).  Views in channels_last layout; the convolution library writes into
+        them (`conv_only(x, out)`), MIOpen-routed levels are copied.  Measured: profiles/r06_prefilter_tlb.txt."""
+        channels = self.cls_head[-1].weight.shape[0]
+        key = tuple((t.shape[0], t.shape[2], t.shape[3]) for t in feats) + (feats[0].device,)
+        hit = self._arenas.get(key)
+        if hit is None:
+            step = 2 << 20
+            elt = torch.empty(0, dtype=self.dtype).element_size()
+            sizes = [t.shape[0] * t.shape[2] * t.shape[3] * channels * elt for t in feats]
+            total = sum((n + step - 1) // step * step for n in sizes) + step
+            buf = torch.empty(total, dtype=torch.uint8, device=feats[0].device)
+            off = (-buf.data_ptr()) % step
+            views = []
+            for t, n in zip(feats, sizes):
+                v = buf[off:off + n].view(self.dtype).view(t.shape[0], t.shape[2], t.shape[3], channels).permute(0, 3, 1, 2)
+                views.append(v)
+                off += (n + step - 1) // step * step
+            self._arenas.clear()
+            hit = self._arenas[key] = (buf, views)
+        return hit[1]
 
     # The engine owns its dtypes (weights are stored in `self.dtype`, every op runs in it): an enclosing
     # torch.autocast region -- which is how Model.forward picks the engine's dtype -- must not re-cast anything.

@@ -20,10 +20,13 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--fixture', default=os.path.join(ROOT, 'tests', 'golden', 'nms_trained_scenes_ties.npz'))
 ap.add_argument('--generic', action='store_true', help='the stand-alone op (arbitrary order in) instead of the sorted-run form')
 ap.add_argument('--images', type=int, default=0, help='first N images only (0 = all)')
+ap.add_argument('--first', type=int, default=0, help='put this image first (the phase trace is image 0\'s)')
 args = ap.parse_args()
 g = np.load(args.fixture)
 n = args.images or g['scores'].shape[0]
-scores, boxes, classes = (torch.from_numpy(g[k][:n]).cuda() for k in ('scores', 'boxes', 'classes'))
+order = [args.first] + [i for i in range(g['scores'].shape[0]) if i != args.first]
+order = order[:n]
+scores, boxes, classes = (torch.from_numpy(g[k][order]).cuda() for k in ('scores', 'boxes', 'classes'))
 nms, det = float(g['nms']), int(g['detections'])
 B, count = scores.shape
 run_len = count // 5
@@ -38,7 +41,7 @@ def run():
 for _ in range(5):
     out = run()
 torch.cuda.synchronize()
-ok = all(torch.equal(o.cpu(), torch.from_numpy(g[k][:n])) for o, k in zip(out, ('out_scores', 'out_boxes', 'out_classes')))
+ok = all(torch.equal(o.cpu(), torch.from_numpy(g[k][order])) for o, k in zip(out, ('out_scores', 'out_boxes', 'out_classes')))
 print('result == fixture (canonical rule), bit for bit:', ok)
 trace = torch.zeros(8192, dtype=torch.int64, device='cuda')
 _C.library().odtk_debug_set_trace(trace.data_ptr())
@@ -53,7 +56,8 @@ for i, r in enumerate(rows):
     us = lambda a, b: (int(r[b]) - int(r[a])) / 100.0
     print('%3d | %6d | %6d | %4d | %6.1f %6.1f %6.1f %7.1f | %7.1f' % (i, int(r[6]), int(r[5]), kept[i], us(0, 1), us(1, 2), us(2, 3), us(3, 4), us(0, 4)))
 ph = t[4096 + 96:4096 + 96 + 96].view(-1, 2)
-names = {1: 'round selected', 2: 'boxes staged', 3: 'chunks / push done', 4: 'filter done', 5: 'push over everything done'}
+names = {1: 'round selected', 2: 'boxes staged', 3: 'chunks / push done', 4: 'filter done', 5: 'push over everything done',
+         10: 'batch compacted', 11: 'rows', 12: 'resolved', 13: 'pushed'}
 line, prev_t = [], int(rows[0][0])
 for pid, pt in ph.tolist():
     if pid == 0:
