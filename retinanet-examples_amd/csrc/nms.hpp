@@ -488,6 +488,7 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsArgs a) {
   int kept = 0;                      // block-uniform copy of s_misc[34]
   int pulled = 0;                    // every candidate still listed is known to survive the boxes kept at ranks < pulled
   bool first_round = true;
+  bool push_all_done = false;        // the push over everything has had its kMaxPushAll boxes (round 6)
   int last_round_kept = 0;           // yield of the previous round (push / pull choice)
   uint32_t last_round_size = 0;
 
@@ -564,7 +565,14 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsArgs a) {
     // "best alive candidate next") and one parallel test of every alive candidate against it -- ~0.7 us per kept box, where a
     // round costs ~10 us of selection and sorting before its first box.
     if constexpr (NB == 4) {
-      if ((a.flags & kNmsFlagChunks) && !runs && !first_round && left <= 4u * kNmsThreads && list_n <= 4u * kNmsThreads &&
+      // (round 6: the push costs ~2 us per box it KEEPS -- one block-wide maximum, two barriers and an IoU block per owned slot in
+      //  every wave -- so it pays only while few more boxes are to come.  How many will come cannot be read off the first round's
+      //  yield (its candidates are the duplicates of the best objects; a trained detector's crowded image kept 4 of its first 250
+      //  and 80 of the 1500 behind them: 168 us here), so the push is given kMaxPushAll boxes: the pathological RN101 heads -- 9
+      //  kept of 2236, five of them here, 14 us -- finish inside it, anything that still has candidates alive after them leaves
+      //  with its survivors compacted and goes through sorted rounds of batched pushes.  profiles/r06_nms_clustered.txt)
+      constexpr int kMaxPushAll = 8;
+      if (!runs && !first_round && !push_all_done && left <= 4u * kNmsThreads && list_n <= 4u * kNmsThreads &&
           static_cast<uint32_t>(last_round_kept) * 20u < last_round_size) {
         constexpr int kOwn = 4;
         static_assert(kOwn == 4, "the pull below is written out four times");
@@ -592,6 +600,8 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsArgs a) {
           if (mk[2] && !pull_against_kept(s_kcls, s_kbox, pulled, kept, 1, mb[2], mc[2], true, thr)) mk[2] = 0;
           if (mk[3] && !pull_against_kept(s_kcls, s_kbox, pulled, kept, 1, mb[3], mc[3], true, thr)) mk[3] = 0;
         }
+        int pushes = 0;
+        bool bailed = false;
         while (kept < ndet) {                                  // block-uniform trip count
           const uint64_t b01 = mk[0] > mk[1] ? mk[0] : mk[1], b23 = mk[2] > mk[3] ? mk[2] : mk[3];
           uint64_t best = wave_max_u64(b01 > b23 ? b01 : b23);   // (DPP row shifts / broadcasts: no LDS crossbar round trips)
@@ -622,8 +632,30 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsArgs a) {
           for (int u = 0; u < kOwn; ++u)
             if (mk[u] && mc[u] == kc && axis_suppresses(kb, mb[u], thr)) mk[u] = 0;
           ++kept;
+          if (!(a.flags & kNmsFlagChunks) && ++pushes == kMaxPushAll && kept < ndet) { bailed = true; break; }   // (block-uniform)
         }
-        if (tid == 0) s_misc[34] = static_cast<uint32_t>(kept);
+        if (tid == 0) { s_misc[34] = static_cast<uint32_t>(kept); s_misc[37] = 0; }
+        if (bailed) {
+          // the candidates still alive (each has met every kept box) go back into the key list, compacted; the rounds below take over
+          __syncthreads();                                     // (every owner has read its slots of s_keys; s_misc[37] is cleared)
+#pragma unroll
+          for (int u = 0; u < kOwn; ++u) {
+            const bool live = mk[u] != 0;
+            const uint32_t slot = wave_append_slot(&s_misc[37], live);
+            if (live) s_keys[slot] = mk[u];
+          }
+          __syncthreads();
+          examined += left;
+          list_n = __builtin_amdgcn_readfirstlane(s_misc[37]);
+          examined -= list_n;
+          left = list_n;
+          upper = ~0ull;
+          pulled = kept;
+          push_all_done = true;
+          if (left > 0) key_range();
+          phase(5);
+          continue;
+        }
         examined += left;
         left = 0;
         phase(5);

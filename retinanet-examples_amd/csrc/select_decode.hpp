@@ -1002,6 +1002,14 @@ __global__ __launch_bounds__(kSelThreads) void select_decode_kernel(const Decode
     }
     const bool coop_try = CAP == kSortCap && a.coop_ticks != 0 && !has_raw && sort_size <= 2u * kSelThreads;   // (block- AND segment-uniform)
     if (!whole && coop_try && tid == 0) atomicCAS(&S.route, 0u, kRouteTournament);   // no global threshold from a partial histogram
+    // Ordering the protocol relies on: every access to SelSeg is an agent-scope ATOMIC (`sc1`: performed at the
+    // device's coherence point, past this XCD's L2), relaxed in the C++ sense.  A wave's returning atomics are complete --
+    // performed there, not merely issued -- once `s_waitcnt vmcnt(0)` retires; the workgroup barrier behind it makes that true
+    // for all sixteen waves before thread 0 takes the ticket, and an atomic that a partner issues AFTER it has observed the ticket
+    // (a sc1 load) is performed at the same point later.  So "ticket seen" implies "histogram contributions and the veto are
+    // visible to sc1 loads" without a fence -- which on this part would write back and invalidate the XCD's whole L2 (40-90 us per
+    // segment, measured in round 4).  The non-returning histogram atomics are covered by the same counter (vmcnt counts them
+    // until the memory side acknowledges them on gfx9-family parts).
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the histogram's atomics (and the veto) have been performed
     __syncthreads();
     if (tid == 0) {

@@ -106,11 +106,28 @@ def test_nms_on_a_trained_detectors_tied_candidates(path):
     """The NMS input of a TRAINED detector's bf16 engine (clusters of overlapping same-class candidates, 16-bit scores tying in the
     hundreds; oracle/gen_golden_trained_nms.py): the canonical rule (score desc, position asc), bit for bit -- through the
     stand-alone op (arbitrary order in, generic rounds) and with the candidates handed over in `detect`'s sorted-run form."""
+    from odtk import _C
     g = _load(path)
-    out = box.nms(cuda(g['scores']), cuda(g['boxes']), cuda(g['classes']), float(g['nms']), int(g['detections']))
-    assert_bits(out[0], g['out_scores'], 'scores')
-    assert_bits(out[1], g['out_boxes'], 'boxes')
-    assert_bits(out[2], g['out_classes'], 'classes')
+    args = (cuda(g['scores']), cuda(g['boxes']), cuda(g['classes']))
+    run_len = g['scores'].shape[1] // 5                      # five levels of top_n candidates, as decode_levels wrote them
+    for name, out in (('nms', box.nms(*args, float(g['nms']), int(g['detections']))),
+                      ('nms_sorted_runs', _C.nms_sorted_runs(*args, run_len, float(g['nms']), int(g['detections'])))):
+        assert_bits(out[0], g['out_scores'], name + ' scores')
+        assert_bits(out[1], g['out_boxes'], name + ' boxes')
+        assert_bits(out[2], g['out_classes'], name + ' classes')
+
+
+def test_nms_sorted_runs_equals_nms_on_decode_output():
+    """odtk_nms_sorted_runs on what decode_levels wrote == odtk_nms_ex on the same candidates == detect (which calls the same code)."""
+    from odtk import _C
+    cls, dl, strides = synthetic.pyramid(3, 9, 20, 256, 320, 'clustered', 77)
+    anchors = {s: box.generate_anchors(s, [1.0, 2.0, 0.5], [4 * 2 ** (i / 3) for i in range(3)]) for s in strides}
+    dec = box.decode_levels([cuda(c) for c in cls], [cuda(d) for d in dl], strides, 0.05, 300, anchors)
+    a = box.nms(dec[0], dec[1], dec[2], 0.5, 100)
+    b = _C.nms_sorted_runs(dec[0], dec[1], dec[2], 300, 0.5, 100)
+    c = box.detect([cuda(c) for c in cls], [cuda(d) for d in dl], strides, anchors, 0.05, 300, 0.5, 100)
+    for x, y, z in zip(a, b, c):
+        assert torch.equal(x, y) and torch.equal(x, z)
 
 
 @pytest.mark.parametrize('path', _cases('pipeline'), ids=os.path.basename)
