@@ -558,9 +558,9 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsArgs a) {
   };
 
   while (left > 0 && kept < ndet) {
-    // ---- heavy suppression, everything that is left fits four candidates per thread (axis-aligned): push over ALL of it ----
+    // ---- heavy suppression, everything that is left fits two candidates per thread (axis-aligned): push over ALL of it ----
     // After a filter pass the survivors are a key list, and when the last round kept fewer than 1 in 20 of its candidates
-    // most of them will die too.  No round, no sort, no further filter then: every thread owns up to four candidates (key,
+    // most of them will die too.  No round, no sort, no further filter then: every thread owns up to two candidates (key,
     // box, class in registers), and per KEPT box there is one block-wide maximum over the alive keys (the greedy order IS
     // "best alive candidate next") and one parallel test of every alive candidate against it -- ~0.7 us per kept box, where a
     // round costs ~10 us of selection and sorting before its first box.
@@ -572,10 +572,11 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsArgs a) {
       //  kept of 2236, five of them here, 14 us -- finish inside it, anything that still has candidates alive after them leaves
       //  with its survivors compacted and goes through sorted rounds of batched pushes.  profiles/r06_nms_clustered.txt)
       constexpr int kMaxPushAll = 8;
-      if (!runs && !first_round && !push_all_done && left <= 4u * kNmsThreads && list_n <= 4u * kNmsThreads &&
+      // (kOwn = 2 since the bail-out exists: four candidates per thread -- 28 registers -- pushed the 1024-thread kernel over its 128
+      //  and into scratch; the case this form is for, the RN101 heads' ~1100 survivors of a filter pass, fits two per thread)
+      constexpr int kOwn = 2;
+      if (!runs && !first_round && !push_all_done && left <= static_cast<uint32_t>(kOwn) * kNmsThreads && list_n <= static_cast<uint32_t>(kOwn) * kNmsThreads &&
           static_cast<uint32_t>(last_round_kept) * 20u < last_round_size) {
-        constexpr int kOwn = 4;
-        static_assert(kOwn == 4, "the pull below is written out four times");
         uint64_t mk[kOwn];
         float mb[kOwn][4], mc[kOwn];
 #pragma unroll
@@ -595,16 +596,15 @@ __global__ __launch_bounds__(kNmsThreads) void nms_kernel(const NmsArgs a) {
           }
         }
         if (kept > pulled) {                                   // (the boxes kept since the last filter pass)
-          if (mk[0] && !pull_against_kept(s_kcls, s_kbox, pulled, kept, 1, mb[0], mc[0], true, thr)) mk[0] = 0;
-          if (mk[1] && !pull_against_kept(s_kcls, s_kbox, pulled, kept, 1, mb[1], mc[1], true, thr)) mk[1] = 0;
-          if (mk[2] && !pull_against_kept(s_kcls, s_kbox, pulled, kept, 1, mb[2], mc[2], true, thr)) mk[2] = 0;
-          if (mk[3] && !pull_against_kept(s_kcls, s_kbox, pulled, kept, 1, mb[3], mc[3], true, thr)) mk[3] = 0;
+#pragma unroll
+          for (int u = 0; u < kOwn; ++u)
+            if (mk[u] && !pull_against_kept(s_kcls, s_kbox, pulled, kept, 1, mb[u], mc[u], true, thr)) mk[u] = 0;
         }
         int pushes = 0;
         bool bailed = false;
         while (kept < ndet) {                                  // block-uniform trip count
-          const uint64_t b01 = mk[0] > mk[1] ? mk[0] : mk[1], b23 = mk[2] > mk[3] ? mk[2] : mk[3];
-          uint64_t best = wave_max_u64(b01 > b23 ? b01 : b23);   // (DPP row shifts / broadcasts: no LDS crossbar round trips)
+          uint64_t best = wave_max_u64(mk[0] > mk[1] ? mk[0] : mk[1]);   // (DPP row shifts / broadcasts: no LDS crossbar round trips)
+          static_assert(kOwn == 2, "the maximum above is written for two");
           if (lane == 0) s_alive[wave] = best;
           __syncthreads();
           best = 0;

@@ -18,7 +18,8 @@ def test_library_exports_what_the_header_declares():
     lib = ctypes.CDLL(_C._CONV_LIB_PATH)
     header = open(os.path.join(ROOT, 'include', 'odtk_conv.h')).read()
     declared = set(re.findall(r'\b(odtk_[a-z0-9_]+)\s*\(', header))
-    assert declared == {'odtk_conv_bias_act', 'odtk_conv_bias_act_pads', 'odtk_conv_last_plan', 'odtk_conv_instance_count'}
+    assert declared == {'odtk_conv_bias_act', 'odtk_conv_bias_act_pads', 'odtk_conv_last_plan', 'odtk_conv_instance_count',
+                        'odtk_conv_plan_export', 'odtk_conv_plan_import'}
     for name in declared:
         getattr(lib, name)
     assert _C.conv_available()

@@ -57,7 +57,8 @@ for i, r in enumerate(rows):
     print('%3d | %6d | %6d | %4d | %6.1f %6.1f %6.1f %7.1f | %7.1f' % (i, int(r[6]), int(r[5]), kept[i], us(0, 1), us(1, 2), us(2, 3), us(3, 4), us(0, 4)))
 ph = t[4096 + 96:4096 + 96 + 96].view(-1, 2)
 names = {1: 'round selected', 2: 'boxes staged', 3: 'chunks / push done', 4: 'filter done', 5: 'push over everything done',
-         10: 'batch compacted', 11: 'rows', 12: 'resolved', 13: 'pushed'}
+         10: 'batch compacted', 11: 'rows', 12: 'resolved', 13: 'pushed',
+         20: 'partitioned by class', 21: 'classes resolved'}
 line, prev_t = [], int(rows[0][0])
 for pid, pt in ph.tolist():
     if pid == 0:

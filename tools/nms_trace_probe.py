@@ -81,7 +81,8 @@ for name, fn in (('in Model.forward', step), ('back to back', alone)):
                  (int(r[3]) - int(r[2])) / 100.0, (int(r[4]) - int(r[3])) / 100.0, wall, int(r[5]), int(r[6]),
                  int((out[0][i] > 0).sum()), int(r[7]) / max(wall * 1e3, 1e-9)))
     ph = t[4096 + 96:4096 + 96 + 96].view(-1, 2)
-    names = {1: 'round selected', 2: 'boxes staged', 3: 'chunks / push done', 4: 'filter done', 5: 'push over everything done'}
+    names = {1: 'round selected', 2: 'boxes staged', 3: 'chunks / push done', 4: 'filter done', 5: 'push over everything done',
+             10: 'batch compacted', 11: 'rows', 12: 'resolved', 13: 'pushed', 20: 'partitioned by class', 21: 'classes resolved'}
     line, prev_t = [], int(rows[0][0])
     for pid, pt in ph.tolist():
         if pid == 0:
