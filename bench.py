@@ -739,7 +739,7 @@ def run_infer(args, rank, world, dev):
         # (times of these kernels are never taken from a file into this object: what a committed rocprofv3 summary of this
         # command says about them goes under `quoted.epilogue_kernels`, with the file's name -- VERDICT r04 weak #11)
         profiled = {}
-        stats_name = next((n for n in ('r05_bench_steady_kernel_stats.csv',) if os.path.isfile(os.path.join(ROOT, 'profiles', n))), None)
+        stats_name = next((n for n in ('r06_bench_steady_kernel_stats.csv', 'r05_bench_steady_kernel_stats.csv') if os.path.isfile(os.path.join(ROOT, 'profiles', n))), None)
         stats = os.path.join(ROOT, 'profiles', stats_name or 'none')
         if default_workload(args) and stats_name:
             import csv
@@ -812,7 +812,7 @@ def run_infer(args, rank, world, dev):
     # an older file is named under `quoted` with its mismatch and `roofline.traffic` stays null.
     traffic, traffic_src, quoted = None, None, None
     src_hash = kernel_src_hash()
-    for name in ('r05_pmc_traffic.json', 'r04_pmc_traffic.json', 'r03_pmc_traffic.json'):
+    for name in ('r06_pmc_traffic.json', 'r05_pmc_traffic.json', 'r04_pmc_traffic.json', 'r03_pmc_traffic.json'):
         try:
             pmc = json.load(open(os.path.join(ROOT, 'profiles', name)))
             key = 'bf16_logits_channels_last' if (model.fused_postprocess and bytes_per_score == 2) else 'fp32_scores_nchw'
