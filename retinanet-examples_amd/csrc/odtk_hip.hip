@@ -142,6 +142,19 @@ int scan_image_major() {
 // (profiles/r06_select_routes_instep.txt) -- every segment went the cooperative route and workgroup 0 sat 2.1 us (p50) / 3.1 us
 // (p99) / 3.4 us (max) between "slice fetched" and "barrier passed", its own histogram atomics included; the same with a 5 us
 // bound.  10 us is three times the longest wait seen; a partner that is NOT resident costs its segment 10 us, not round 5's 30.
+// A/B knobs of select_decode's partition (defaults = the constants of csrc/select_decode.hpp): workgroups PROVIDED per segment =
+// ceil(spans / ODTK_SELECT_SPANS_PER_PART), workgroups that TAKE PART = ceil(candidates / ODTK_SELECT_KEYS_PER_PART) of them
+uint32_t select_spans_per_part() {
+  static const uint32_t v = [] { const char *e = std::getenv("ODTK_SELECT_SPANS_PER_PART"); const int x = e ? std::atoi(e) : 0;
+                                 return x >= 1 && x <= 4096 ? static_cast<uint32_t>(x) : odtk::kSpansPerPart; }();
+  return v;
+}
+uint32_t select_keys_per_part() {
+  static const uint32_t v = [] { const char *e = std::getenv("ODTK_SELECT_KEYS_PER_PART"); const int x = e ? std::atoi(e) : 0;
+                                 return x >= 64 && x <= 4096 ? static_cast<uint32_t>(x) : odtk::kKeysPerPart; }();
+  return v;
+}
+
 uint32_t select_coop_ticks() {
   static const uint32_t v = [] {
     const char *e = std::getenv("ODTK_SELECT_COOP_TICKS");
@@ -195,7 +208,7 @@ int decode_layout(int batch, int n_levels, const odtk_level_t *levels, int A, in
     out->spans[l] = static_cast<uint32_t>((n + out->span_elems - 1) / out->span_elems);
     // workgroups select_decode provides per segment: one per kSpansPerPart spans (they leave at once unless the segment
     // holds more than kKeysPerPart candidates each), and enough of them for a slice's sub-list lengths to fit in LDS
-    uint32_t parts = (out->spans[l] + odtk::kSpansPerPart - 1) / odtk::kSpansPerPart;
+    uint32_t parts = (out->spans[l] + select_spans_per_part() - 1) / select_spans_per_part();
     if (parts > odtk::kMaxParts) parts = odtk::kMaxParts;
     const uint32_t fit = (out->spans[l] * odtk::kScanWaves + odtk::kCntSlots - 1) / odtk::kCntSlots;
     if (parts < fit) parts = fit;
@@ -355,6 +368,7 @@ int decode_levels_impl(int batch, int n_levels, const odtk_level_t *levels, int 
   da.span_elems = lay.span_elems;
   da.aligned = aligned ? 1u : 0u;
   da.coop_ticks = select_coop_ticks();
+  da.keys_per_part = select_keys_per_part();
   da.rank_sort = select_rank_sort();
   da.raw_lo = sa.raw_lo;
   da.by_channels = odtk::fastdiv_make(static_cast<uint32_t>(A) * C);

@@ -87,6 +87,7 @@ struct DecodeArgs {
   uint32_t span_elems;                        // elements per span
   uint32_t aligned;                           // every image of every level starts on a 16-byte boundary (vector loads of raw spans)
   uint32_t coop_ticks;                        // cooperative route: 100 MHz ticks a workgroup waits for its segment's partners (0: route off)
+  uint32_t keys_per_part;                     // candidates per participating workgroup (kKeysPerPart; ODTK_SELECT_KEYS_PER_PART for A/B runs)
   uint32_t rank_sort;                         // order the selected keys by COUNTING (histogram bases + in-bin ranks) and decode each where it lies; 0: the rank-merge sort (A/B)
   float raw_lo;                               // logits: conservative lower bound of a candidate's logit (as the prefilter's)
   FastDiv by_channels;                        // A*C
@@ -833,7 +834,7 @@ __global__ __launch_bounds__(kSelThreads) void select_decode_kernel(const Decode
   has_raw = __builtin_amdgcn_readfirstlane(has_raw);
   // workgroups that take part: one per kKeysPerPart candidates (a slice then fits the sort buffer whole), all of them when
   // raw spans have to be walked
-  uint32_t G = (n_total + kKeysPerPart - 1) / kKeysPerPart;
+  uint32_t G = (n_total + a.keys_per_part - 1) / a.keys_per_part;
   const uint32_t g_min = (n_lists + kCntSlots - 1) / kCntSlots;              // a slice's lengths must fit s_cnt
   G = G < g_min ? g_min : G;
   G = G < 1u ? 1u : G;

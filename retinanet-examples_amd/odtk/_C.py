@@ -965,6 +965,22 @@ def loss_form(form):
     _check(library().odtk_debug_loss_form(int(form)), 'loss_form')
 
 
+TRACE_WORDS = 16384     # odtk_debug_set_trace: >= 128 KiB (include/odtk_hip.h): coarse stamps in the first 8192 words, select_decode's
+                        # per-segment fine stamps (16 words per segment, up to 512 segments) in the second 8192
+
+
+def debug_set_trace(trace):
+    """Debug trace buffer of the select_decode / nms kernels (include/odtk_hip.h: odtk_debug_set_trace), or None to switch it
+    off.  `trace`: a zero-filled int64 CUDA tensor of at least TRACE_WORDS elements -- checked HERE because the library cannot:
+    a 64 KiB buffer (the size of round 3's trace) is overrun by select_decode's fine stamps, which corrupts whatever the
+    allocator placed behind it or faults (round 6, call 12: "Memory access fault by GPU" at the end of an 18-minute run)."""
+    if trace is None:
+        return library().odtk_debug_set_trace(None)
+    if not (trace.is_cuda and trace.dtype == torch.int64 and trace.is_contiguous() and trace.numel() >= TRACE_WORDS):
+        raise ValueError('the trace buffer must be a contiguous int64 CUDA tensor of >= %d elements (128 KiB)' % TRACE_WORDS)
+    return library().odtk_debug_set_trace(trace.data_ptr())
+
+
 def profile_enable(on=True, kernels=None):
     """Bracket kernel launches of the library with hipEvent pairs on their launch stream.
     kernels: iterable of names from KERNEL_NAMES (default: all)."""

@@ -137,3 +137,15 @@ def test_launcher_world_mismatch_is_an_error_not_an_assert(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--device', 'cpu', '--tiny', '--gpus', '2', '--steps', '1'],
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and 'one rank per GPU' in r.stderr and r.stdout.strip() == ''
+
+
+def test_committed_pmc_traffic_is_for_these_kernel_sources():
+    """`roofline.traffic` goes on the bench line only when the newest committed PMC file was measured on THIS tree's kernel
+    sources (bench.kernel_src_hash over csrc/*.hpp + *.hip).  A kernel edit without a refreshed `tools/profile_round.sh` run
+    would silently turn the field into null on the driver's line: fail here instead."""
+    newest = next(n for n in ('r06_pmc_traffic.json', 'r05_pmc_traffic.json') if os.path.isfile(os.path.join(bench.ROOT, 'profiles', n)))
+    pmc = json.load(open(os.path.join(bench.ROOT, 'profiles', newest)))
+    assert pmc['kernel_src_sha16'] == bench.kernel_src_hash(), (newest, 'refresh with tools/profile_round.sh and copy the summaries into profiles/')
+    key = pmc['bf16_logits_channels_last']
+    assert key['scores_per_launch'] == 122860800                     # SURVEY 8d: 15 357 600 scores per image x 8
+    assert 1.0 <= key['traffic_bytes'] / float(key['algorithmic_bytes']) <= 1.05

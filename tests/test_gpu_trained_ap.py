@@ -92,27 +92,41 @@ def reference_detections(model, images):
                                   model.threshold, model.top_n, model.nms, model.detections)
 
 
-def gpu_paths(model, images):
+def gpu_paths(model, images, progress=None):
+    """progress (debug): called with the path's name after a device synchronisation behind every path -- a fault then surfaces
+    at the path that caused it (tools/trained_ap.py --progress)."""
     out = {}
+
+    def done(name):
+        if progress is not None:
+            torch.cuda.synchronize()
+            progress(name)
+
     with torch.no_grad():
         out['engine_fp32'] = model(images)
+        done('engine_fp32')
         with torch.autocast('cuda', dtype=torch.float16):
             out['engine_fp16'] = model(images)
+        done('engine_fp16')
         with torch.autocast('cuda', dtype=torch.bfloat16):
             out['engine_bf16'] = model(images)
+        done('engine_bf16')
         model.fused_graph = False
         try:
             out['eager_fp32_hip_postproc'] = model(images)
+            done('eager_fp32_hip_postproc')
             with torch.autocast('cuda', dtype=torch.float16):
                 out['eager_autocast_fp16'] = model(images)
+            done('eager_autocast_fp16')
             with torch.autocast('cuda', dtype=torch.bfloat16):
                 out['eager_autocast_bf16'] = model(images)
+            done('eager_autocast_bf16')
         finally:
             model.fused_graph = True
     return out
 
 
-def evaluate_paths(model, seed=0, images=64, batch=16, size=512, device='cuda', with_gpu_paths=True):
+def evaluate_paths(model, seed=0, images=64, batch=16, size=512, device='cuda', with_gpu_paths=True, progress=None):
     """Held-out scenes of `seed` -> {path: COCOeval.stats (12 numbers, AP first)} + {'examined': ...}."""
     from odtk.cocoeval import COCOeval
     from odtk.data import CocoIndex
@@ -126,8 +140,10 @@ def evaluate_paths(model, seed=0, images=64, batch=16, size=512, device='cuda', 
         ids = torch.arange(step * batch, (step + 1) * batch)
         all_targets.append(targets.cpu())
         found = {'reference': reference_detections(model, x)}
+        if progress is not None:
+            progress('step %d reference' % step)
         if with_gpu_paths:
-            found.update(gpu_paths(model, x))
+            found.update(gpu_paths(model, x, None if progress is None else (lambda name, step=step: progress('step %d %s' % (step, name)))))
         for name, (s, b, c) in found.items():
             dets.setdefault(name, []).extend(detections_to_coco(s.float().cpu(), b.float().cpu(), c.float().cpu(), ids, torch.ones(batch)))
     truth = CocoIndex(dataset=scenes.coco_ground_truth(torch.cat(all_targets), 0, CLASSES))

@@ -39,10 +39,10 @@ def clock_of(fn, warm=10, reps=5):
         fn()
     out = []
     for _ in range(reps):
-        trace = torch.zeros(8192, dtype=torch.int64, device='cuda')
-        _C.library().odtk_debug_set_trace(trace.data_ptr())
+        trace = torch.zeros(_C.TRACE_WORDS, dtype=torch.int64, device='cuda')
+        _C.debug_set_trace(trace)
         fn(); torch.cuda.synchronize()
-        _C.library().odtk_debug_set_trace(None)
+        _C.debug_set_trace(None)
         t = trace.cpu().view(-1, 8)[64 + 8:64 + 16]          # the 8 nms workgroups
         wall_us = (t[:, 4] - t[:, 0]).float() / 100.0
         ghz = t[:, 7].float() / (wall_us * 1e3)
@@ -59,10 +59,10 @@ print('back to back, idle chip: nms wall us, effective GHz', clock_of(alone))
 # per-chunk timeline of image 0 (in the step)
 for _ in range(3):
     step()
-trace = torch.zeros(8192, dtype=torch.int64, device='cuda')
-_C.library().odtk_debug_set_trace(trace.data_ptr())
+trace = torch.zeros(_C.TRACE_WORDS, dtype=torch.int64, device='cuda')
+_C.debug_set_trace(trace)
 step(); torch.cuda.synchronize()
-_C.library().odtk_debug_set_trace(None)
+_C.debug_set_trace(None)
 t = trace.cpu()
 rows = t[4096:4096 + 80].view(-1, 4)
 img0 = t.view(-1, 8)[64 + 8]

@@ -43,11 +43,11 @@ for _ in range(5):
 torch.cuda.synchronize()
 ok = all(torch.equal(o.cpu(), torch.from_numpy(g[k][order])) for o, k in zip(out, ('out_scores', 'out_boxes', 'out_classes')))
 print('result == fixture (canonical rule), bit for bit:', ok)
-trace = torch.zeros(8192, dtype=torch.int64, device='cuda')
-_C.library().odtk_debug_set_trace(trace.data_ptr())
+trace = torch.zeros(_C.TRACE_WORDS, dtype=torch.int64, device='cuda')
+_C.debug_set_trace(trace)
 run()
 torch.cuda.synchronize()
-_C.library().odtk_debug_set_trace(None)
+_C.debug_set_trace(None)
 t = trace.cpu()
 rows = t.view(-1, 8)[64 + B:64 + 2 * B]
 kept = (out[0] > 0).sum(1).tolist()

@@ -59,11 +59,11 @@ def alone():
 
 
 def traced(fn):
-    trace = torch.zeros(8192, dtype=torch.int64, device='cuda')
-    _C.library().odtk_debug_set_trace(trace.data_ptr())
+    trace = torch.zeros(_C.TRACE_WORDS, dtype=torch.int64, device='cuda')
+    _C.debug_set_trace(trace)
     out = fn()
     torch.cuda.synchronize()
-    _C.library().odtk_debug_set_trace(None)
+    _C.debug_set_trace(None)
     return trace.cpu(), out
 
 

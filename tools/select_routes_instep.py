@@ -51,7 +51,7 @@ def alone():
 
 
 def survey(fn, steps):
-    trace = torch.zeros(16384, dtype=torch.int64, device='cuda')
+    trace = torch.zeros(_C.TRACE_WORDS, dtype=torch.int64, device='cuda')
     for _ in range(10):
         fn()
     shared = coop = 0
@@ -59,10 +59,10 @@ def survey(fn, steps):
     per_level = {}
     for _ in range(steps):
         trace.zero_()
-        _C.library().odtk_debug_set_trace(trace.data_ptr())
+        _C.debug_set_trace(trace)
         fn()
         torch.cuda.synchronize()
-        _C.library().odtk_debug_set_trace(None)
+        _C.debug_set_trace(None)
         t = trace.cpu()
         seg = t[:8192].view(-1, 8)[:5 * B]
         fine = t[8192:8192 + 64 * 16].view(-1, 16)[:5 * B]

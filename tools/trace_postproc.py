@@ -23,10 +23,10 @@ strides = [8, 16, 32, 64, 128]
 for s in strides: m.level_anchors(s)
 run = lambda: box.detect(cls, dl, strides, m.anchors, 0.05, 1000, 0.5, 100, ROT, logits=True)
 for _ in range(3): run()
-trace = torch.zeros(16384, dtype=torch.int64, device='cuda')
-_C.library().odtk_debug_set_trace(trace.data_ptr())
+trace = torch.zeros(_C.TRACE_WORDS, dtype=torch.int64, device='cuda')
+_C.debug_set_trace(trace)
 run(); torch.cuda.synchronize()
-_C.library().odtk_debug_set_trace(None)
+_C.debug_set_trace(None)
 t = trace.cpu()[:8192].view(-1, 8)
 fine = trace.cpu()[8192:8192 + 64 * 16].view(-1, 16)
 us = lambda a, b: (b - a).float() / 100.0

@@ -30,6 +30,8 @@ ap_.add_argument('--backbone', default='ResNet18FPN')
 ap_.add_argument('--json', default=None)
 ap_.add_argument('--save-postproc-inputs', default=None, help='npz: what the post-processing sees on the first held-out batch of the '
                  'first seed -- decode_levels output (the NMS input) of the bf16 engine, for offline NMS studies and fixtures')
+ap_.add_argument('--progress', action='store_true', help='debug: synchronise behind every inference path of every held-out batch and '
+                 'say so on stderr (a device fault then names its path); the JSON is rewritten after every seed')
 args = ap_.parse_args()
 torch.backends.cudnn.benchmark = True
 
@@ -40,20 +42,23 @@ for seed in args.seeds:
     model, history = T.train_detector(seed=seed, iterations=args.iterations, batch=args.batch, size=args.size, backbone=args.backbone,
                                       log_interval=max(50, args.iterations // 20))
     t_train = time.time() - t0
-    stats = T.evaluate_paths(model, seed=seed, images=args.images, batch=args.batch, size=args.size)
+    say = (lambda msg, seed=seed: print('[seed %d] %s' % (seed, msg), file=sys.stderr, flush=True)) if args.progress else None
+    if say:
+        say('trained in %.0f s' % t_train)
+    stats = T.evaluate_paths(model, seed=seed, images=args.images, batch=args.batch, size=args.size, progress=say)
     table[seed] = stats
     # what the NMS sees on a trained model (bf16 engine, the timed path): candidates with a positive score per image (K) and how
     # many of them it examines before 100 are kept or the list is exhausted
     held = scenes.SceneBatches(args.batch, args.size, args.size, classes=T.CLASSES, seed=seed, device='cuda', start=T.HELD_OUT_START)
     x = held.batch_at(0)[0].contiguous(memory_format=torch.channels_last)
-    trace = torch.zeros(8192, dtype=torch.int64, device='cuda')
+    trace = torch.zeros(_C.TRACE_WORDS, dtype=torch.int64, device='cuda')
     with torch.no_grad(), torch.autocast('cuda', dtype=torch.bfloat16):
         for _ in range(3):
             model(x)
-        _C.library().odtk_debug_set_trace(trace.data_ptr())
+        _C.debug_set_trace(trace)
         det = model(x)
         torch.cuda.synchronize()
-        _C.library().odtk_debug_set_trace(None)
+        _C.debug_set_trace(None)
     rows = trace.cpu().view(-1, 8)[64 + args.batch:64 + 2 * args.batch]
     extra[seed] = {'train_s': round(t_train, 1), 'history': [(h[0], round(h[1], 4), round(h[2], 4)) for h in history],
                    'nms_examined': [int(r[5]) for r in rows], 'nms_candidates': [int(r[6]) for r in rows],
@@ -73,6 +78,9 @@ for seed in args.seeds:
                             top_n=model.top_n, nms=model.nms, detections=model.detections, levels=len(strides))
     del model
     torch.cuda.empty_cache()
+    if args.json:                                            # (after every seed: a later fault does not take the finished seeds with it)
+        with open(args.json, 'w') as f:
+            json.dump({'args': vars(args), 'table': {str(k): v for k, v in table.items()}, 'extra': {str(k): v for k, v in extra.items()}}, f, indent=1)
 
 print('COCO AP (IoU 0.50:0.95 | 0.50 | 0.75, odtk/cocoeval.py) against the TRUE boxes of %d held-out scenes per seed; %s trained %d '
       'iterations x batch %d at %dx%d by odtk/train.py (fp32, HIP target assignment + fused loss; 75 %% live batch norm from the random '
