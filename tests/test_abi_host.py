@@ -257,3 +257,14 @@ int main() {
     subprocess.run(['g++', '-O2', '-std=c++17', '-o', str(exe), str(src)], check=True)
     out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
     assert int(out[0]) > 3_000_000 and int(out[1]) == 0, out
+
+
+def test_debug_trace_buffer_is_size_checked_on_the_host():
+    """include/odtk_hip.h: odtk_debug_set_trace wants >= 128 KiB (select_decode's fine stamps start at word 8192).  The library cannot
+    check a bare pointer; the binding does -- four probes had passed 64 KiB and one of them faulted the GPU at exit (round 6)."""
+    import torch
+    from odtk import _C
+    assert _C.TRACE_WORDS * 8 == 128 * 1024
+    for bad in (torch.zeros(8192, dtype=torch.int64), torch.zeros(_C.TRACE_WORDS, dtype=torch.int32), torch.zeros(_C.TRACE_WORDS, dtype=torch.int64)):
+        with pytest.raises(ValueError):                      # too small | wrong dtype | not on the device: refused before any library call
+            _C.debug_set_trace(bad)
