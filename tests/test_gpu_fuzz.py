@@ -90,6 +90,21 @@ def test_nms_random_configs(seed):
         assert torch.equal(out[3].cpu().long(), t[3])
 
 
+@pytest.mark.parametrize('seed', range(32))
+def test_nms_on_detector_like_clusters_in_both_input_forms(seed):
+    """Clusters of overlapping same-class boxes around a few objects, tied 16-bit scores, one to eighty classes, 64 .. 9000 candidates in
+    one to six sorted runs (tools/nms_fuzz_long.py: the generator and the long run; round 6's batched pushes, the capped push over
+    everything and the filter passes are taken or not depending on the case): odtk_nms_ex == the C restatement of the reference's CPU
+    nms bit for bit, and odtk_nms_sorted_runs == odtk_nms_ex."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location('nms_fuzz_long', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                                                'tools', 'nms_fuzz_long.py'))
+    fuzz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fuzz)
+    assert fuzz.check_case(seed) == ''
+
+
 @pytest.mark.parametrize('shape', [(9, 20, 40, 40), (9, 80, 25, 40), (3, 7, 96, 100)])
 def test_every_score_passes_on_a_mid_size_level(shape):
     """Threshold 0 on levels of 0.2-0.7 M scores: every element is a candidate, so one prefilter
