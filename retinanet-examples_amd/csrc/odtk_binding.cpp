@@ -148,9 +148,12 @@ std::vector<torch::Tensor> detect(std::vector<torch::Tensor> cls_heads, std::vec
     const auto &c = cls_heads[i], &b = box_heads[i];
     TORCH_CHECK(c.is_cuda() && b.is_cuda() && c.dim() == 4 && b.dim() == 4 && c.scalar_type() == dtype && b.scalar_type() == dtype,
                 "detect: level ", i, ": CUDA 4-d tensors of one dtype expected");
-    const bool nchw = c.is_contiguous(), nhwc = c.is_contiguous(at::MemoryFormat::ChannelsLast);
-    TORCH_CHECK(nchw || nhwc, "cls_head[", i, "] must be contiguous (NCHW or channels_last)");
-    TORCH_CHECK(nchw ? b.is_contiguous() : b.is_contiguous(at::MemoryFormat::ChannelsLast), "box_head[", i, "] must share cls_head's memory format");
+    // (a one-channel head or a 1 x 1 level is contiguous in BOTH readings and follows its partner: odtk/_C.py:_pair_layout)
+    const bool c_nchw = c.is_contiguous(), c_nhwc = c.is_contiguous(at::MemoryFormat::ChannelsLast);
+    const bool b_nchw = b.is_contiguous(), b_nhwc = b.is_contiguous(at::MemoryFormat::ChannelsLast);
+    TORCH_CHECK(c_nchw || c_nhwc, "cls_head[", i, "] must be contiguous (NCHW or channels_last)");
+    TORCH_CHECK((c_nchw && b_nchw) || (c_nhwc && b_nhwc), "box_head[", i, "] must share cls_head's memory format");
+    const bool nchw = c_nchw && b_nchw;
     TORCH_CHECK(static_cast<int>(anchors[i].size()) == 4 * num_anchors && c.size(0) == batch && b.size(1) == num_anchors * nb, "detect: inconsistent level ", i);
     levels[i] = odtk_level_t{c.data_ptr(), b.data_ptr(), static_cast<int32_t>(c.size(2)), static_cast<int32_t>(c.size(3)), strides[i],
                              nchw ? 0 : 1, anchors[i].data(), nullptr, nullptr};

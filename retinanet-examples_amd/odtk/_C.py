@@ -337,18 +337,29 @@ def iou(boxes, anchors):
 _DTYPES = {torch.float32: F32, torch.bfloat16: BF16, torch.float16: F16}
 
 
-def _layout(t, name):
-    """0: NCHW-contiguous, 1: channels_last (NHWC-contiguous).  Anything else is rejected, like the
-    reference's CHECK_CONTIGUOUS (csrc/extensions.cpp:43) -- callers decide where copies happen."""
-    if not isinstance(t, torch.Tensor) or not t.is_cuda:
-        raise RuntimeError('%s must be a CUDA tensor' % name)
-    if t.dim() != 4:
-        raise RuntimeError('%s must be 4-d [B, C, H, W]' % name)
-    if t.is_contiguous():
-        return 0
-    if t.is_contiguous(memory_format=torch.channels_last):
+def _pair_layout(c, b, cname, bname, what, prefer_channels_last=False):
+    """Common memory format of a (cls_head, box_head) pair: 0 NCHW, 1 channels_last.  A tensor with ONE channel (a one-anchor,
+    one-class head) or ONE pixel (a 1 x 1 level) is contiguous in both readings -- torch says so for either format -- and follows
+    its partner instead of being pinned to NCHW (found by tools/decode_fuzz_long.py: A = C = 1 with channels_last heads was
+    refused as 'mixed formats').  prefer_channels_last: take that reading when both tensors allow both (the bias fold wants it)."""
+    def readings(t, name):
+        if not isinstance(t, torch.Tensor) or not t.is_cuda:
+            raise RuntimeError('%s must be a CUDA tensor' % name)
+        if t.dim() != 4:
+            raise RuntimeError('%s must be 4-d [B, C, H, W]' % name)
+        n, l = t.is_contiguous(), t.is_contiguous(memory_format=torch.channels_last)
+        if not (n or l):
+            raise RuntimeError('%s must be contiguous (NCHW or channels_last)' % name)
+        return n, l
+    cn, cl = readings(c, cname)
+    bn, bl = readings(b, bname)
+    if prefer_channels_last and cl and bl:
         return 1
-    raise RuntimeError('%s must be contiguous (NCHW or channels_last)' % name)
+    if cn and bn:
+        return 0
+    if cl and bl:
+        return 1
+    raise RuntimeError('%s%s and %s must share one memory format' % (what, cname, bname))
 
 
 def prefilter_thresholds(cls_bias, dtype, score_thresh):
@@ -383,11 +394,9 @@ def _levels(cls_heads, box_heads, anchors_list, strides, nb, cls_bias=None, box_
     keep = []
     num_anchors = None
     for i, (c, b, a, s) in enumerate(zip(cls_heads, box_heads, anchors_list, strides)):
-        lay = _layout(c, 'cls_head[%d]' % i)
-        if c.shape[2] * c.shape[3] == 1 and cls_bias is not None:
-            lay = 1       # a 1x1 level is NCHW- and NHWC-contiguous at once; the bias fold wants the channels_last reading
-        if _layout(b, 'box_head[%d]' % i) != lay and b.shape[2] * b.shape[3] > 1:
-            raise RuntimeError('cls_head[%d] and box_head[%d] must share one memory format' % (i, i))
+        # (a 1 x 1 level or a one-channel head is NCHW- and NHWC-contiguous at once: it follows its partner; the bias fold wants
+        #  the channels_last reading where both allow it)
+        lay = _pair_layout(c, b, 'cls_head[%d]' % i, 'box_head[%d]' % i, '', prefer_channels_last=cls_bias is not None)
         if c.dtype != dtype or b.dtype != dtype:
             raise RuntimeError('decode_levels: all head tensors must share one dtype')
         flat = a.reshape(-1).tolist() if isinstance(a, torch.Tensor) else list(a)
@@ -582,10 +591,8 @@ def _loss_geometry(cls_head, box_head, depth, box_target):
         raise RuntimeError('retina_loss: tensors must be on the GPU')
     if cls_head.dim() != 4 or box_head.dim() != 4 or depth.dim() != 5 or box_target.dim() != 5:
         raise RuntimeError('retina_loss: cls/box must be [B, ch, H, W], depth [B, A, 1, H, W], box_target [B, A, nb, H, W]')
-    lay = _layout(cls_head, 'cls_head')
+    lay = _pair_layout(cls_head, box_head, 'cls_head', 'box_head', 'retina_loss: ')
     b, ch, h, w = cls_head.shape
-    if h * w > 1 and _layout(box_head, 'box_head') != lay:
-        raise RuntimeError('retina_loss: cls_head and box_head must share one memory format')
     a, nb = box_target.shape[1], box_target.shape[2]
     if cls_head.dtype not in _DTYPES or box_head.dtype != cls_head.dtype:
         raise RuntimeError('retina_loss: heads must share one dtype out of float32 / bfloat16 / float16')

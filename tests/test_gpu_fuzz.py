@@ -105,6 +105,21 @@ def test_nms_on_detector_like_clusters_in_both_input_forms(seed):
     assert fuzz.check_case(seed) == ''
 
 
+def test_one_channel_heads_follow_their_partners_memory_format():
+    """A = C = 1: the class head has ONE channel and is NCHW- and channels_last-contiguous at once; as 16-bit channels_last tensors
+    the pair was refused as 'mixed formats' until round 6 (tools/decode_fuzz_long.py).  Same selection as the fp32 NCHW call."""
+    g = torch.Generator().manual_seed(3)
+    cls = torch.rand(2, 1, 17, 23, generator=g).bfloat16().float()
+    dl = torch.randn(2, 4, 17, 23, generator=g) * 0.3
+    anchors = box.generate_anchors(8, RATIOS, SCALES)[:1].contiguous()
+    a = _C.decode_levels([cls.cuda()], [dl.cuda()], [anchors], [8], 0.3, 50, False, return_indices=True)
+    b = _C.decode_levels([cls.cuda().bfloat16().contiguous(memory_format=torch.channels_last)],
+                         [dl.cuda().bfloat16().contiguous(memory_format=torch.channels_last)], [anchors], [8], 0.3, 50, False, return_indices=True)
+    assert torch.equal(a[3], b[3]) and torch.equal(a[0], b[0])
+    ref = box_oracle.decode(cls, dl, 8, 0.3, 50, anchors, return_indices=True)
+    assert torch.equal(a[3].cpu().long(), ref[3]) and torch.equal(a[0].cpu(), ref[0])
+
+
 @pytest.mark.parametrize('shape', [(9, 20, 40, 40), (9, 80, 25, 40), (3, 7, 96, 100)])
 def test_every_score_passes_on_a_mid_size_level(shape):
     """Threshold 0 on levels of 0.2-0.7 M scores: every element is a candidate, so one prefilter
