@@ -424,7 +424,8 @@ int odtk_retina_loss_levels_backward(int n_levels, const odtk_loss_level_t *leve
 #define ODTK_KERNEL_POOL      12  /* bias_act_maxpool_kernel (the stem's bias + ReLU + max-pool pass)  */
 #define ODTK_KERNEL_UPSAMPLE  13  /* upsample_nearest2x_kernel                                         */
 #define ODTK_KERNEL_STEM_PACK 14  /* stem_pack_kernel (space-to-depth pack of the network input)        */
-#define ODTK_KERNEL_COUNT     15
+#define ODTK_KERNEL_LOSS_REDUCE 15 /* loss_reduce_kernel (second launch of the forward through a workspace)   */
+#define ODTK_KERNEL_COUNT     16
 /* on: 0 = off, otherwise a bit mask of kernel ids (1 << ODTK_KERNEL_*), -1 = all.  An event pair
  * is a queue marker before and after the kernel: cheap for the 3 post-processing launches of a step,
  * measurably NOT free for the ~110 epilogue launches (about 10 % of an 8.7 ms step), so time those
@@ -441,6 +442,14 @@ int odtk_debug_set_trace(void *device_buffer);
  * best; results do not depend on the shape beyond the order of the partial sums.  Process-wide, not
  * thread-safe against concurrent loss launches; a workspace size queried before a change is stale after it. */
 int odtk_debug_loss_tuning(int which, int fp32_heads, int threads, int blocks_per_cu, int unroll, int box_blocks);
+/* Debug / A-B: memory layout of the loss kernels' logit walk, per form and head width as above.  per_wave (workspace form
+ * only, which = 2): 1 = every wave writes its own three sums to the workspace (3 doubles per WAVE of the launch -- the size
+ * query follows) and no workgroup barrier closes the walk; window: 0 = the vectors a lane loads per trip lie one grid
+ * stride apart, 1 = a wave's vectors of a trip are contiguous in memory; box_rows (read by the backward on
+ * channels_last heads): 1 (default) = the box-delta walk enumerates the cells in the order d(deltas) lies in memory and
+ * writes one vector per cell, 0 = in depth's order, one element per store (rounds 2-5).  Results do not depend on any of
+ * them beyond the order of the partial sums. */
+int odtk_debug_loss_layout(int which, int fp32_heads, int per_wave, int window, int box_rows);
 /* Debug / A-B: arithmetic form of the classification walk of the loss kernels when gamma == 2 (csrc/loss.hpp).
  * 0: every logit through the symmetric form (one select on the target, one on the sign);  1: 16-byte vectors that hold no
  * positive element and no logit above 64 (all but ~1 in 1000) through the negatives-only form u = exp(x), q = u / (1 + u),

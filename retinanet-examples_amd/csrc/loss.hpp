@@ -57,6 +57,11 @@ struct LossArgs {
   uint32_t batch, num_anchors, num_classes, hw, nb;
   uint32_t channels_last;   // layout of cls and box (0: NCHW, 1: NHWC)
   uint32_t cls_blocks;      // blocks [0, cls_blocks) walk the logits, the rest walk the deltas
+  uint32_t per_wave;        // forward, workspace form: 1 = every WAVE writes its own three sums (partial is [gridDim.x * waves][3]):
+                            // no workgroup barrier, the waves retire on their own as the prefilter's do
+  uint32_t box_rows;        // backward, channels_last: 1 = the box-delta walk follows d(deltas)' memory order (one vector store per cell)
+  uint32_t window;          // logit walk: 0 = a trip's kUnroll vectors lie `cls_blocks x blockDim` vectors apart (one window per
+                            // vector, every workgroup in every window); 1 = a wave's kUnroll vectors of a trip are contiguous
   float alpha, gamma, beta;
   FastDiv by_channels, by_hw, by_classes, by_anchors;   // A*C, H*W, C, A (host: fastdiv_make)
 };
@@ -139,6 +144,22 @@ __device__ __forceinline__ void store_elem(void *base, uint64_t idx, float v) {
   }
 }
 
+// four consecutive elements, element index 4 * idx4 (the base is 16-byte aligned: checked by the host)
+template <typename T>
+__device__ __forceinline__ void store_vec4(void *base, uint64_t idx4, const float *v) {
+  if constexpr (std::is_same_v<T, F32>) {
+    static_cast<vuint4 *>(base)[idx4] = vuint4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+  } else {
+    uint32_t h[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if constexpr (std::is_same_v<T, BF16>) h[e] = __float_as_uint(round_to_bf16(v[e])) >> 16;
+      else h[e] = __builtin_bit_cast(uint16_t, static_cast<_Float16>(v[e]));
+    }
+    static_cast<uint2 *>(base)[idx4] = uint2{h[0] | (h[1] << 16), h[2] | (h[3] << 16)};
+  }
+}
+
 template <typename T>
 __device__ __forceinline__ float vec_elem(const vuint4 &raw, int e) {
   if constexpr (std::is_same_v<T, F32>) {
@@ -213,16 +234,19 @@ __device__ __forceinline__ double focal_stream(const LossArgs &a, uint32_t block
   const uint32_t n_vec = n / kPer;
   const vuint4 *src = static_cast<const vuint4 *>(a.cls);
   const uint32_t stride = a.cls_blocks * blockDim.x;
+  const uint32_t ustride = a.window ? static_cast<uint32_t>(kWave) : stride;   // between the vectors of a trip (launch-uniform)
+  const uint32_t first = a.window ? (block * blockDim.x + (threadIdx.x & ~static_cast<uint32_t>(kWave - 1))) * kUnroll + (threadIdx.x & (kWave - 1))
+                                  : block * blockDim.x + threadIdx.x;
   double acc = 0.0;
 
-  for (uint32_t v0 = block * blockDim.x + threadIdx.x; v0 < n_vec; v0 += stride * kUnroll) {
+  for (uint32_t v0 = first; v0 < n_vec; v0 += stride * kUnroll) {
     vuint4 raw[kUnroll];
     float dep[kUnroll][kDep];
     uint32_t c0[kUnroll];                                  // class of the vector's first element
     bool fast[kUnroll];
 #pragma unroll
     for (int u = 0; u < kUnroll; ++u) {
-      const uint32_t v = v0 + u * stride;
+      const uint32_t v = v0 + u * ustride;
       fast[u] = false;
       c0[u] = 0;
 #pragma unroll
@@ -263,7 +287,7 @@ __device__ __forceinline__ double focal_stream(const LossArgs &a, uint32_t block
     float sum = 0.0f;                                      // fp32 partial of <= kUnroll * kPer <= 32 elements -> fp64
 #pragma unroll
     for (int u = 0; u < kUnroll; ++u) {
-      const uint32_t v = v0 + u * stride;
+      const uint32_t v = v0 + u * ustride;
       if (v >= n_vec) break;
       float out[kPer];
       if (fast[u]) {
@@ -382,6 +406,40 @@ __device__ __forceinline__ void retina_loss_block(const LossArgs &a, uint32_t bl
     float sum_box = 0.0f, n_fg = 0.0f;
     const uint32_t cells = a.batch * A * hw;                // < 2^32 (host)
     const uint32_t stride = (n_blocks - a.cls_blocks) * blockDim.x;
+    if (kBackward && a.channels_last && a.box_rows) {
+      // channels_last gradients (round 6): lanes enumerate the cells in the order d(deltas) lies in memory -- (image, pixel,
+      // anchor), NB consecutive parameters each -- so a wave's stores are one contiguous run (NB = 4: ONE 16- / 8-byte
+      // vector per lane) instead of NB stores of one element each, 4 A NB bytes apart from lane to lane: those were 64
+      // partial-line writes per wave and store, as many L2 requests again as half the logit stream
+      // (profiles/r05_loss_pmc.txt: 4.56 M requests in the backward for 2.9 M of logits).  depth / box_target are gathered
+      // (planes of hw floats); only foreground cells (~0.5 %) read the deltas and the targets at all.
+      for (uint32_t cell = (block - a.cls_blocks) * blockDim.x + threadIdx.x; cell < cells; cell += stride) {
+        uint32_t pix, an;
+        const uint32_t ip = fastdivmod(cell, a.by_anchors, &an);   // img * hw + pix
+        const uint32_t img = fastdivmod(ip, a.by_hw, &pix);
+        const uint32_t ia = img * A + an;
+        const bool fg = a.depth[ia * hw + pix] > 0.0f;                          // model.py:204 box_mask
+        const uint64_t off = static_cast<uint64_t>(cell) * NB;
+        if (NB == 4) {                                                           // (launch-uniform)
+          float out[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+          if (fg) {
+#pragma unroll
+            for (uint32_t k = 0; k < 4; ++k) {
+              float grad;
+              smooth_l1_element<true>(load_raw<T>(a.box, off + k), a.box_target[(static_cast<uint64_t>(ia) * 4 + k) * hw + pix], a.beta, &grad);
+              out[k] = g * grad;
+            }
+          }
+          store_vec4<T>(a.dbox, cell, out);
+        } else {
+          for (uint32_t k = 0; k < NB; ++k) {
+            float grad = 0.0f;
+            if (fg) smooth_l1_element<true>(load_raw<T>(a.box, off + k), a.box_target[(static_cast<uint64_t>(ia) * NB + k) * hw + pix], a.beta, &grad);
+            store_elem<T>(a.dbox, off + k, g * grad);
+          }
+        }
+      }
+    } else {
     for (uint32_t cell = (block - a.cls_blocks) * blockDim.x + threadIdx.x; cell < cells; cell += stride) {
       uint32_t pix, an;
       const uint32_t ia = fastdivmod(cell, a.by_hw, &pix);  // img * A + an
@@ -401,11 +459,25 @@ __device__ __forceinline__ void retina_loss_block(const LossArgs &a, uint32_t bl
         if constexpr (kBackward) store_elem<T>(a.dbox, off, g * grad);
       }
     }
+    }
     acc_box += sum_box;
     acc_fg += n_fg;
   }
 
   if constexpr (!kBackward) {
+    if (a.partial && a.per_wave) {                           // (launch-uniform) no barrier: wave sums straight to the workspace
+      double v3[3] = {acc_cls, acc_box, acc_fg};
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) v3[k] += __shfl_xor(v3[k], d, kWave);
+      }
+      if (lane_id() == 0) {
+        double *mine = a.partial + 3 * (static_cast<size_t>(blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6));
+        mine[0] = v3[0]; mine[1] = v3[1]; mine[2] = v3[2];
+      }
+      return;
+    }
     const double c_ = block_sum(acc_cls, s_red);
     const double b_ = block_sum(acc_box, s_red);
     const double f_ = block_sum(acc_fg, s_red);
@@ -441,21 +513,37 @@ __global__ __launch_bounds__(kLossMaxThreads) void retina_loss_kernel(const Loss
 }
 
 // Second launch of the workspace form of the forward: workgroup l adds up the per-workgroup sums of level l in a fixed
-// order (thread t takes partials t, t + 256, ...; then the wave / block tree) -> sums[l][0..2].  The loss is then bitwise
+// order (thread t takes partials t, t + 1024, ...; then the wave / block tree) -> sums[l][0..2].  The loss is then bitwise
 // reproducible from run to run, which the atomic form is not.
 struct LossReduceArgs {
-  const double *partial;                       // [total workgroups][3]
+  const double *partial;                       // [total workgroups x per][3]
+  uint32_t per;                                // partial sums per workgroup: 1, or its waves (LossArgs.per_wave)
   double *sums;                                // [n_levels][3]
   uint32_t block_begin[ODTK_MAX_LEVELS + 1];
 };
 
-__global__ __launch_bounds__(256) void loss_reduce_kernel(const LossReduceArgs a) {
-  __shared__ double s_red[256 / kWave];
-  const uint32_t l = blockIdx.x, b0 = a.block_begin[l], b1 = a.block_begin[l + 1];
+constexpr int kLossReduceThreads = 1024;
+
+__global__ __launch_bounds__(kLossReduceThreads) void loss_reduce_kernel(const LossReduceArgs a) {
+  __shared__ double s_red[kLossReduceThreads / kWave];
+  const uint32_t l = blockIdx.x, b0 = a.block_begin[l] * a.per, b1 = a.block_begin[l + 1] * a.per;
   double v[3] = {0.0, 0.0, 0.0};
-  for (uint32_t b = b0 + threadIdx.x; b < b1; b += 256) {
+  // four partial triples per thread and trip, all twelve loads in flight before the first addition (one workgroup per level
+  // reads up to tens of thousands of triples: with one dependent round trip per triple the launch took longer than the walk)
+  constexpr uint32_t kT = kLossReduceThreads;
+  for (uint32_t b = b0 + threadIdx.x; b < b1; b += 4 * kT) {
+    double t[4][3];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) v[k] += a.partial[3 * static_cast<size_t>(b) + k];
+    for (uint32_t u = 0; u < 4; ++u) {
+      const uint32_t i = b + u * kT;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) t[u][k] = i < b1 ? a.partial[3 * static_cast<size_t>(i) + k] : 0.0;
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < 4; ++u) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) v[k] += t[u][k];
+    }
   }
 #pragma unroll
   for (int k = 0; k < 3; ++k) {

@@ -578,14 +578,20 @@ int bias_act_dispatch(void *y, const float *bias, const void *res, uint64_t n, u
 // workgroup size, resident workgroups per CU the logit walk is capped at, 16-byte vectors a lane loads per trip.
 struct LossTuning {
   int threads, per_cu, unroll, box_blocks;
+  int per_wave, window, box_rows;   // odtk_debug_loss_layout: per-wave sums (workspace form only), contiguous trips, the backward's
+                                    // box-delta walk in memory order (csrc/loss.hpp LossArgs)
   int form;   // filled by loss_tuning_snapshot from g_loss_form (odtk_debug_loss_form): 1 = vectors of negatives take focal_plain
 };
 // [16-bit heads, fp32 heads][forward with atomics, backward, forward through a workspace] = threads, logit workgroups per
 // CU and level, vectors per trip, box workgroups per level; measured with tools/loss_probe.py (profiles/r03_loss_probe.txt)
 enum { kLossFwd = 0, kLossBwd = 1, kLossFwdWs = 2 };
 std::mutex g_loss_tuning_mu;
-LossTuning g_loss_tuning[2][3] = {{{512, 1, 2, 64, 0}, {256, 4, 1, 256, 0}, {256, 4, 1, 256, 0}},
-                                  {{512, 1, 4, 64, 0}, {1024, 16, 2, 1024, 0}, {256, 4, 1, 256, 0}}};
+// Round 6 (profiles/r06_loss_layout_probe.txt): the backward walks contiguous trips (window 1) with 256-thread workgroups and
+// writes d(deltas) in memory order -- fp32 50.6 -> 42.6-43.1 us, bf16 34.3 -> 27.4 us.
+// The forward through the workspace walks contiguous trips too (fp32: two vectors per trip); per-wave sums stay off (walk -1.3 us,
+// reduce launch +0.8 us: nothing).
+LossTuning g_loss_tuning[2][3] = {{{512, 1, 2, 64, 0, 0, 1, 0}, {256, 4, 1, 256, 0, 1, 1, 0}, {256, 4, 1, 256, 0, 1, 1, 0}},
+                                  {{512, 1, 4, 64, 0, 0, 1, 0}, {256, 8, 2, 1024, 0, 1, 1, 0}, {256, 4, 2, 256, 0, 1, 1, 0}}};
 
 // Arithmetic form of the classification walk with gamma = 2 (csrc/loss.hpp focal_plain): 0 = every element through the
 // symmetric focal_term (rounds 3-4), 1 = vectors that hold no positive element and no logit beyond kPlainMax through
@@ -639,6 +645,9 @@ unsigned retina_loss_fill(odtk::LossArgs &la, int which, const void *cls, const 
   unsigned long long box_blocks = (1ull * batch * A * height * width + threads - 1) / threads;
   if (box_blocks > static_cast<unsigned>(t.box_blocks)) box_blocks = t.box_blocks;
   la.cls_blocks = static_cast<uint32_t>(cls_blocks);
+  la.per_wave = (which == kLossFwdWs && t.per_wave) ? 1u : 0u;
+  la.window = t.window ? 1u : 0u;
+  la.box_rows = t.box_rows ? 1u : 0u;
   *rc = ODTK_OK;
   return static_cast<unsigned>(cls_blocks + box_blocks);
 }
@@ -708,9 +717,10 @@ int retina_loss_levels_launch(int which, int n_levels, const odtk_loss_level_t *
     odtk::LossReduceArgs ra;
     std::memset(&ra, 0, sizeof ra);
     ra.partial = partial;
+    ra.per = t.per_wave ? static_cast<uint32_t>(t.threads) / 64u : 1u;
     ra.sums = sums;
     for (int l = 0; l <= ODTK_MAX_LEVELS; ++l) ra.block_begin[l] = la.block_begin[l];
-    timed_launch(ODTK_KERNEL_LOSS, odtk::loss_reduce_kernel, dim3(n_levels), dim3(256), 0, stream, ra);
+    timed_launch(ODTK_KERNEL_LOSS_REDUCE, odtk::loss_reduce_kernel, dim3(n_levels), dim3(odtk::kLossReduceThreads), 0, stream, ra);
     ODTK_HIP_TRY(hipGetLastError());
   }
   return ODTK_OK;
@@ -797,7 +807,18 @@ int odtk_debug_loss_tuning(int which, int fp32_heads, int threads, int blocks_pe
       blocks_per_cu > 64 || (unroll != 1 && unroll != 2 && unroll != 4) || box_blocks < 1 || box_blocks > 16384)
     return ODTK_ERR_INVALID;
   std::lock_guard<std::mutex> lock(g_loss_tuning_mu);
-  g_loss_tuning[fp32_heads != 0][which] = LossTuning{threads, blocks_per_cu, unroll, box_blocks, 0};
+  LossTuning &t = g_loss_tuning[fp32_heads != 0][which];
+  t.threads = threads; t.per_cu = blocks_per_cu; t.unroll = unroll; t.box_blocks = box_blocks;   // (the layout switches stay)
+  return ODTK_OK;
+}
+
+int odtk_debug_loss_layout(int which, int fp32_heads, int per_wave, int window, int box_rows) {
+  if (which < 0 || which > 2 || (per_wave != 0 && per_wave != 1) || (window != 0 && window != 1) || (box_rows != 0 && box_rows != 1))
+    return ODTK_ERR_INVALID;
+  if (per_wave && which != kLossFwdWs) return ODTK_ERR_INVALID;   // per-wave sums exist in the workspace form only
+  std::lock_guard<std::mutex> lock(g_loss_tuning_mu);
+  LossTuning &t = g_loss_tuning[fp32_heads != 0][which];
+  t.per_wave = per_wave; t.window = window; t.box_rows = box_rows;
   return ODTK_OK;
 }
 
@@ -1047,7 +1068,7 @@ int odtk_retina_loss_levels_forward_ws(int n_levels, const odtk_loss_level_t *le
   const int blocks = retina_loss_levels_launch(kLossFwdWs, n_levels, levels, batch_size, num_anchors, num_classes, box_params,
                                                dtype, alpha, gamma, beta, nullptr, nullptr, nullptr, nullptr, true, nullptr, &t);
   if (blocks < 0) return blocks;
-  const size_t need = (static_cast<size_t>(blocks) * 3 * sizeof(double) + 255) & ~static_cast<size_t>(255);
+  const size_t need = (static_cast<size_t>(blocks) * (t.per_wave ? t.threads / 64 : 1) * 3 * sizeof(double) + 255) & ~static_cast<size_t>(255);
   if (!workspace) return static_cast<int>(need);                       // two-phase convention of the reference's plugins
   if (!sums) return ODTK_ERR_INVALID;
   if (workspace_size < need) return ODTK_ERR_WORKSPACE;

@@ -101,6 +101,7 @@ _SIGNATURES = {
     'odtk_profile_enable': (ctypes.c_int, [ctypes.c_int]),
     'odtk_debug_set_trace': (ctypes.c_int, [_vp]),
     'odtk_debug_loss_tuning': (ctypes.c_int, [ctypes.c_int] * 6),
+    'odtk_debug_loss_layout': (ctypes.c_int, [ctypes.c_int] * 5),
     'odtk_debug_loss_form': (ctypes.c_int, [ctypes.c_int]),
     'odtk_bias_act_maxpool': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
                                              ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
@@ -127,7 +128,7 @@ _SIGNATURES = {
 KERNEL_NAMES = ('prefilter_scan_kernel', 'select_decode_kernel', 'nms_kernel', 'iou_pairs_kernel', 'bias_act_kernel',
                 'snap_to_anchors_kernel', 'gemm_bias_act', 'retina_loss_kernel', 'select_hist_kernel', 'select_filter_kernel',
                 'nms_first_round_kernel', 'rotated_sup_matrix_kernel', 'bias_act_maxpool_kernel', 'upsample_nearest2x_kernel',
-                'stem_pack_kernel')
+                'stem_pack_kernel', 'loss_reduce_kernel')
 # HBM bytes the epilogue entry points move, per kernel name, while `traffic_count` is on (bench.py's epilogue_roofline: the
 # algorithmic bytes of every call -- each element read once and written once, + the skip input -- divided by the kernel time)
 traffic_count = False
@@ -961,6 +962,13 @@ def loss_tuning(which, fp32_heads, threads, blocks_per_cu, unroll, box_blocks):
     workspace) and head width (include/odtk_hip.h: odtk_debug_loss_tuning)."""
     _check(library().odtk_debug_loss_tuning(int(which), int(bool(fp32_heads)), int(threads), int(blocks_per_cu),
                                             int(unroll), int(box_blocks)), 'loss_tuning')
+
+
+def loss_layout(which, fp32_heads, per_wave=0, window=0, box_rows=1):
+    """Debug / A-B: per-wave partial sums (workspace form only), contiguous trips of the loss kernels' logit walk, the backward's
+    box-delta walk in memory order (include/odtk_hip.h: odtk_debug_loss_layout)."""
+    _check(library().odtk_debug_loss_layout(int(which), int(bool(fp32_heads)), int(bool(per_wave)), int(bool(window)),
+                                            int(bool(box_rows))), 'loss_layout')
 
 
 LOSS_FORM_DEFAULT = 1      # = ODTK_LOSS_FORM_DEFAULT of include/odtk_hip.h (tests/test_abi_host.py compares the two)

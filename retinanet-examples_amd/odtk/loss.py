@@ -8,6 +8,8 @@
 pass over the head tensors as the convolutions wrote them, and ONE pass in backward (csrc/loss.hpp) -- an
 `autograd.Function`, so it drops into the training graph; the torch modules below stay as the reference
 implementation it is tested against (tests/test_gpu_loss.py) and as the CPU path."""
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -92,10 +94,13 @@ class _FusedPyramidLoss(torch.autograd.Function):
         from . import _C
         cls_heads, box_heads = tensors[:n], tensors[n:2 * n]
         depths, box_targets = tensors[2 * n:3 * n], tensors[3 * n:4 * n]
-        # torch.use_deterministic_algorithms(True): the fixed-order reduction instead of double atomics (same speed, one
-        # more launch; csrc/loss.hpp:loss_reduce_kernel) -- the loss is then the same bits on every run
+        # Through the workspace (per-workgroup sums, added up in a fixed order by a second, tiny launch; csrc/loss.hpp:
+        # loss_reduce_kernel): no double atomics at the end of every workgroup -- the walk takes 25-27 us where the atomics
+        # form takes 31-35, the reduce launch 4 (profiles/r06_loss_layout_probe.txt) -- and the loss is the same bits on every
+        # run.  ODTK_LOSS_ATOMICS=1: the one-launch form of rounds 2-5.
         sums = _C.retina_loss_levels_forward(cls_heads, box_heads, depths, box_targets, alpha, gamma, beta,
-                                             reproducible=torch.are_deterministic_algorithms_enabled()).float()
+                                             reproducible=os.environ.get('ODTK_LOSS_ATOMICS', '0') != '1'
+                                             or torch.are_deterministic_algorithms_enabled()).float()
         ctx.save_for_backward(*tensors)
         ctx.meta = (n, alpha, gamma, beta)
         cls_sums, box_sums, foreground = sums[:, 0].contiguous(), sums[:, 1].contiguous(), sums[:, 2].contiguous()

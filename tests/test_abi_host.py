@@ -174,10 +174,34 @@ def test_loss_tuning_hook_validates_without_a_gpu():
     for bad in ((0, 1, 100, 1, 4, 64), (0, 1, 2048, 1, 4, 64), (0, 1, 512, 0, 4, 64), (0, 1, 512, 1, 3, 64),
                 (1, 0, 256, 4, 1, 0), (1, 0, 256, 65, 1, 256), (3, 0, 256, 4, 1, 256), (-1, 1, 256, 4, 1, 256)):
         assert lib.odtk_debug_loss_tuning(*bad) == _C.ERR_INVALID, bad
-    for good in ((0, 0, 512, 1, 2, 64), (1, 0, 256, 4, 1, 256), (0, 1, 512, 1, 4, 64), (1, 1, 1024, 16, 2, 1024)):   # = the defaults
+    for good in ((0, 0, 512, 1, 2, 64), (1, 0, 256, 4, 1, 256), (0, 1, 512, 1, 4, 64), (1, 1, 256, 8, 2, 1024)):   # = the defaults
         assert lib.odtk_debug_loss_tuning(*good) == 0, good
     with pytest.raises(RuntimeError, match='invalid argument'):
         _C.loss_tuning(0, 1, 100, 1, 4, 64)
+
+
+def test_loss_layout_hook_validates_without_a_gpu():
+    """odtk_debug_loss_layout (per-wave sums of the workspace form, contiguous trips, the backward's box-delta walk in memory
+    order) never touches HIP; per-wave sums exist in the workspace form only, and the workspace size query follows the switch
+    (3 doubles per WAVE instead of per workgroup)."""
+    lib = _C.library()
+    for bad in ((3, 1, 0, 0, 1), (-1, 0, 0, 0, 1), (2, 1, 2, 0, 1), (2, 1, 0, 2, 1), (1, 1, 0, 0, 2), (0, 1, 1, 0, 1), (1, 0, 1, 1, 1)):
+        assert lib.odtk_debug_loss_layout(*bad) == _C.ERR_INVALID, bad
+    levels = (_C.LossLevel * 1)()
+    levels[0].cls = levels[0].box = levels[0].depth = levels[0].box_target = 1 << 20       # never dereferenced on this path
+    levels[0].height, levels[0].width, levels[0].channels_last = 100, 160, 1
+    args = (1, levels, 2, 9, 80, 4, _C.F32, 0.25, 2.0, 0.11)
+    lib.odtk_debug_loss_tuning(2, 1, 256, 4, 1, 256)
+    assert lib.odtk_debug_loss_layout(2, 1, 0, 0, 1) == 0
+    per_group = lib.odtk_retina_loss_levels_forward_ws(*args, None, None, 0, None)
+    assert lib.odtk_debug_loss_layout(2, 1, 1, 1, 1) == 0
+    per_wave = lib.odtk_retina_loss_levels_forward_ws(*args, None, None, 0, None)
+    assert per_group > 0 and per_wave == 4 * per_group                                      # 256 threads = 4 waves
+    lib.odtk_debug_loss_tuning(2, 1, 256, 4, 2, 256)
+    for which, fp32, window in ((0, 0, 0), (0, 1, 0), (1, 0, 1), (1, 1, 1), (2, 0, 1), (2, 1, 1)):   # = the defaults
+        _C.loss_layout(which, fp32, 0, window, 1)
+    with pytest.raises(RuntimeError, match='invalid argument'):
+        _C.loss_layout(0, 1, 1, 0, 1)
 
 
 def test_loss_form_hook_validates_without_a_gpu():
