@@ -45,7 +45,7 @@ __device__ __forceinline__ vuint4 bias_act_vec(vuint4 v, vuint4 r, const float *
     }
     float o = x + b[e];
     if (kResidual) o += s;
-    if (kRelu) o = o > 0.0f ? o : 0.0f;
+    if (kRelu) o = o > 0.0f ? o : (o != o ? o : 0.0f);     // NaN goes through, as torch.relu (round 6: it became 0 before)
     f[e] = o;
   }
   if constexpr (std::is_same_v<T, F32>) {
@@ -97,7 +97,7 @@ __global__ void bias_act_scalar_kernel(void *y, const float *bias, const void *r
   for (uint64_t i = begin + static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += step) {
     float o = load_raw<T>(y, i) + bias[i % channels];
     if (kResidual) o += load_raw<T>(res, i);
-    if (kRelu) o = o > 0.0f ? o : 0.0f;
+    if (kRelu) o = o > 0.0f ? o : (o != o ? o : 0.0f);     // NaN goes through, as torch.relu (round 6: it became 0 before)
     if constexpr (std::is_same_v<T, F32>) static_cast<float *>(y)[i] = o;
     else static_cast<uint16_t *>(y)[i] = static_cast<uint16_t>(float_to_storage<T>(o));
   }
@@ -117,6 +117,19 @@ __global__ void bias_act_scalar_kernel(void *y, const float *bias, const void *r
 // k32 (every real size: fewer than 2^32 output vectors): the output index is split into (image, row, column, channel
 // group) by multiply-high (fastdiv.hpp).  Three 64-bit divisions by run-time divisors were ~360 of the ~700 vector
 // instructions per output vector of a kernel that the instruction count, not the stream, bounds (round 3).
+typedef short pk_short2 __attribute__((ext_vector_type(2)));
+// two sign-magnitude 16-bit floats (bf16 or fp16) in a dword -> two order-preserving signed 16-bit keys, and back
+__device__ __forceinline__ uint32_t order_keys16(uint32_t w) {
+  const pk_short2 sign = __builtin_bit_cast(pk_short2, w) >> 15;                 // v_pk_ashrrev_i16: 0 / -1 per half
+  return w ^ (__builtin_bit_cast(uint32_t, sign) & 0x7fff7fffu);
+}
+__device__ __forceinline__ uint32_t pk_max_i16(uint32_t a, uint32_t b) {
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(pk_short2, a), __builtin_bit_cast(pk_short2, b)));
+}
+__device__ __forceinline__ uint32_t pk_min_i16(uint32_t a, uint32_t b) {
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(pk_short2, a), __builtin_bit_cast(pk_short2, b)));
+}
+
 struct PoolDivisors {
   FastDiv groups, wo, ho;
 };
@@ -143,26 +156,51 @@ __global__ __launch_bounds__(256) void bias_act_maxpool_kernel(const uint16_t *_
       oy = static_cast<uint32_t>(p % ho);
       b = static_cast<uint32_t>(p / ho);
     }
-    float m[kPer];
+    // Round 6: the maximum is taken on the 16-bit patterns themselves, two per instruction.  A sign-magnitude half h becomes an
+    // order-preserving two's-complement key by k = h ^ ((h >> 15) & 0x7fff) (an involution); keys of positive NaNs lie above
+    // +inf's, keys of negative NaNs below -inf's, so a running packed maximum AND minimum see every NaN of the window: five
+    // packed operations per dword of a neighbour where the fp32 form (unpack, two compares, select: per element) took sixteen.
+    // (Equal values have equal bits except +0 / -0, where the key order picks +0; the sum with the bias hides the difference
+    // unless the bias is -0.)
+    uint32_t kmax[4], kmin[4];
 #pragma unroll
-    for (int e = 0; e < kPer; ++e) m[e] = -__builtin_inff();
+    for (int d = 0; d < 4; ++d) { kmax[d] = 0x80008000u; kmin[d] = 0x7fff7fffu; }
+    // Coordinates are clamped instead of tested: a clamped row / column is one the window holds anyway (padding never wins;
+    // the maximum ignores duplicates), so the nine loads are unconditional, issued together, and addressed as one 64-bit image
+    // base + 32-bit row / column offsets (the host checks h * w * c < 2^32).
     const int y0 = static_cast<int>(oy) * 2 - 1, x0 = static_cast<int>(ox) * 2 - 1;
+    const uint16_t *img = y + static_cast<uint64_t>(b) * h * w * c + g * kPer;
+    uint32_t ro[3], co[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      const int yy = y0 + d < 0 ? 0 : (y0 + d >= static_cast<int>(h) ? static_cast<int>(h) - 1 : y0 + d);
+      const int xx = x0 + d < 0 ? 0 : (x0 + d >= static_cast<int>(w) ? static_cast<int>(w) - 1 : x0 + d);
+      ro[d] = static_cast<uint32_t>(yy) * w * c;
+      co[d] = static_cast<uint32_t>(xx) * c;
+    }
+    vuint4 v[9];
 #pragma unroll
     for (int dy = 0; dy < 3; ++dy) {
-      const int yy = y0 + dy;
-      if (yy < 0 || yy >= static_cast<int>(h)) continue;
 #pragma unroll
-      for (int dx = 0; dx < 3; ++dx) {
-        const int xx = x0 + dx;
-        if (xx < 0 || xx >= static_cast<int>(w)) continue;
-        const vuint4 v = *reinterpret_cast<const vuint4 *>(y + ((static_cast<uint64_t>(b) * h + yy) * w + xx) * c + g * kPer);
+      for (int dx = 0; dx < 3; ++dx) v[dy * 3 + dx] = *reinterpret_cast<const vuint4 *>(img + (ro[dy] + co[dx]));
+    }
 #pragma unroll
-        for (int e = 0; e < kPer; ++e) {
-          const uint32_t hx = (v[e >> 1] >> (16 * (e & 1))) & 0xffffu;
-          const float f = std::is_same_v<T, BF16> ? bf16_bits_to_float(hx) : f16_bits_to_float(hx);
-          m[e] = (f > m[e] || f != f) ? f : m[e];            // NaN propagates, as torch's max_pool2d
-        }
+    for (int n9 = 0; n9 < 9; ++n9) {
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        const uint32_t k = order_keys16(v[n9][d]);
+        kmax[d] = pk_max_i16(kmax[d], k);
+        kmin[d] = pk_min_i16(kmin[d], k);
       }
+    }
+    float m[kPer];
+#pragma unroll
+    for (int e = 0; e < kPer; ++e) {
+      const int32_t kx = static_cast<int16_t>(kmax[e >> 1] >> (16 * (e & 1)));
+      const int32_t kn = static_cast<int16_t>(kmin[e >> 1] >> (16 * (e & 1)));
+      const int32_t kk = kn < -32641 ? kn : kx;            // below -inf's key (0x807f): a negative NaN -- NaN propagates, as torch's max_pool2d
+      const uint32_t hx = static_cast<uint32_t>(kk ^ ((kk >> 15) & 0x7fff)) & 0xffffu;
+      m[e] = std::is_same_v<T, BF16> ? bf16_bits_to_float(hx) : f16_bits_to_float(hx);
     }
     vuint4 o;
 #pragma unroll
@@ -209,21 +247,44 @@ __global__ __launch_bounds__(256) void stem_pack_kernel(const void *x, void *out
                                                         uint32_t channels_last, FastDiv by_wo, FastDiv by_howo) {
   const uint32_t ho = height / 2, wo = width / 2;
   const uint64_t total = static_cast<uint64_t>(batch) * ho * wo;
+  const bool pairs = width % 2 == 0 && (reinterpret_cast<uintptr_t>(x) & 7u) == 0;   // (launch-uniform) rows of pixel pairs are 8-byte aligned
   for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < total; i += static_cast<uint64_t>(gridDim.x) * blockDim.x) {
     uint32_t rem, xo;
     const uint32_t n = fastdivmod(static_cast<uint32_t>(i), by_howo, &rem);   // (batch * ho * wo < 2^32: checked by the host)
     const uint32_t yo = fastdivmod(rem, by_wo, &xo);
     float v[12];
+    if (std::is_same_v<TIn, F32> && pairs) {
+      // fp32 images (round 6): the two pixels of a row are 8 / 24 contiguous, 8-byte aligned bytes -- six float2 loads, not twelve
+      const float *xf = static_cast<const float *>(x) + static_cast<uint64_t>(n) * 3 * height * width;   // (3 * H * W < 2^32: host)
 #pragma unroll
-    for (int dy = 0; dy < 2; ++dy) {
+      for (int dy = 0; dy < 2; ++dy) {
+        const uint32_t yy = 2 * yo + dy, xx = 2 * xo;
+        if (channels_last) {
+          const float2 *p = reinterpret_cast<const float2 *>(xf + (yy * width + xx) * 3u);
+          const float2 a0 = p[0], a1 = p[1], a2 = p[2];      // (c0 c1) (c2 | c0) (c1 c2) of the pixels dx = 0, 1
+          v[(dy * 2) * 3 + 0] = a0.x; v[(dy * 2) * 3 + 1] = a0.y; v[(dy * 2) * 3 + 2] = a1.x;
+          v[(dy * 2 + 1) * 3 + 0] = a1.y; v[(dy * 2 + 1) * 3 + 1] = a2.x; v[(dy * 2 + 1) * 3 + 2] = a2.y;
+        } else {
 #pragma unroll
-      for (int dx = 0; dx < 2; ++dx) {
+          for (int c = 0; c < 3; ++c) {
+            const float2 a0 = *reinterpret_cast<const float2 *>(xf + ((static_cast<uint32_t>(c) * height + yy) * width + xx));
+            v[(dy * 2) * 3 + c] = a0.x;
+            v[(dy * 2 + 1) * 3 + c] = a0.y;
+          }
+        }
+      }
+    } else {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          const uint64_t yy = 2 * yo + dy, xx = 2 * xo + dx;
-          const uint64_t off = channels_last ? ((static_cast<uint64_t>(n) * height + yy) * width + xx) * 3 + c
-                                             : ((static_cast<uint64_t>(n) * 3 + c) * height + yy) * width + xx;
-          v[(dy * 2 + dx) * 3 + c] = load_raw<TIn>(x, off);
+      for (int dy = 0; dy < 2; ++dy) {
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            const uint64_t yy = 2 * yo + dy, xx = 2 * xo + dx;
+            const uint64_t off = channels_last ? ((static_cast<uint64_t>(n) * height + yy) * width + xx) * 3 + c
+                                               : ((static_cast<uint64_t>(n) * 3 + c) * height + yy) * width + xx;
+            v[(dy * 2 + dx) * 3 + c] = load_raw<TIn>(x, off);
+          }
         }
       }
     }

@@ -1091,6 +1091,7 @@ int odtk_bias_act_maxpool(const void *y, const float *bias, void *out, int batch
   if (dtype != ODTK_BF16 && dtype != ODTK_F16) return ODTK_ERR_UNSUPPORTED;
   if (channels % 8 != 0) return ODTK_ERR_UNSUPPORTED;
   if ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(out)) & 15u) return ODTK_ERR_INVALID;
+  if (1ull * height * width * channels >= (1ull << 32)) return ODTK_ERR_UNSUPPORTED;   // 32-bit offsets inside one image
   const uint32_t ho = (static_cast<uint32_t>(height) + 1) / 2, wo = (static_cast<uint32_t>(width) + 1) / 2;
   const uint64_t work = static_cast<uint64_t>(batch_size) * ho * wo * (channels / 8);
   uint64_t blocks = (work + 255) / 256;
@@ -1161,6 +1162,7 @@ int odtk_stem_pack(const void *x, void *out, int batch_size, int height, int wid
   if (out_dtype != ODTK_BF16 && out_dtype != ODTK_F16) return ODTK_ERR_UNSUPPORTED;
   if (reinterpret_cast<uintptr_t>(out) & 15u) return ODTK_ERR_INVALID;
   if (1ull * batch_size * (height / 2) * (width / 2) > 0xf0000000ull) return ODTK_ERR_INVALID;
+  if (3ull * height * width >= (1ull << 32)) return ODTK_ERR_INVALID;       // 32-bit offsets inside one image
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (in_dtype == ODTK_F32) return stem_pack_launch<odtk::F32>(x, out, batch_size, height, width, channels_last, out_dtype, s);
   if (in_dtype == ODTK_BF16) return stem_pack_launch<odtk::BF16>(x, out, batch_size, height, width, channels_last, out_dtype, s);

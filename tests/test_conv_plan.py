@@ -155,6 +155,7 @@ sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, 'retinan
 import torch
 from odtk import fused
 from odtk.model import Model
+torch.backends.cudnn.deterministic = True   # the layers the plan leaves on MIOpen (every convolution with a skip input) must reproduce themselves
 torch.manual_seed(0)
 model = Model('ResNet18FPN', classes=6).eval()
 model.initialize(None)
@@ -174,8 +175,12 @@ print(json.dumps({'digest': h.hexdigest(), 'plan_hash': e.plan_hash(), 'taken': 
 
 @pytest.mark.gpu
 def test_plan_file_replays_across_processes(tmp_path):
-    """Every k x k layer through the library (ODTK_CONV_ROUTE=library: no MIOpen find in the graph), first process writes the
-    plan file, second one loads it: same plan hash, same head-tensor digest, and the libraries took their lines."""
+    """Every k x k layer the library supports goes through it (ODTK_CONV_ROUTE=library: no stopwatch between routes), first process
+    writes the plan file, second one loads it: same plan hash, same head-tensor digest, and the libraries took their lines.
+    The convolutions with a skip input stay on MIOpen + odtk_bias_act (a ResNet18 block's second convolution): the children run
+    under cudnn.deterministic like the one-process test above -- MIOpen's find mode picks, per process and per box, kernels that
+    need not reproduce their own bits (round 6, GPU calls 28-29: on one box every process, and every call
+    inside a process, gave other head tensors from layers.1 on, with the stem and the plan hash equal: tools/plan_replay_probe.py)."""
     from odtk import _C
     if not _C.conv_available():
         pytest.skip('libodtk_conv.so not built')

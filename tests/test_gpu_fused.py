@@ -170,6 +170,46 @@ def test_bias_act_maxpool_is_epilogue_then_pool(shape, dtype):
 
 
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16], ids=['bf16', 'fp16'])
+def test_bias_act_maxpool_special_values(dtype):
+    """Round 6: the pool takes its maximum on order-preserving 16-bit keys of the raw patterns (csrc/epilogue.hpp
+    order_keys16).  What the float form did by comparing must still hold: NaNs of EITHER sign propagate (as torch's
+    max_pool2d), +-inf order as numbers, windows over the borders see clamped coordinates only.  Every finite position is bit
+    for bit the reference; NaN positions are NaN in both."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(21)
+    b, c, h, w = 2, 16, 23, 31
+    y = torch.randn(b, c, h, w, generator=g).to(dtype)
+    flat = y.view(-1)
+    bits = flat.view(torch.int16)
+    n = flat.numel()
+    pick = torch.randperm(n, generator=g)
+    flat[pick[:60]] = float('inf')
+    flat[pick[60:160]] = float('-inf')
+    flat[pick[160:200]] = float('nan')
+    nan_bits = {torch.bfloat16: 0x7fc1, torch.float16: 0x7e01}[dtype]
+    bits[pick[200:240]] = (nan_bits | 0x8000) - 0x10000                                      # NEGATIVE NaNs (sign bit set), a payload
+    bits[pick[240:260]] = nan_bits | 0x3f                                        # positive NaNs with another payload
+    flat[pick[260:400]] = 0.0
+    bits[pick[400:520]] = -0x8000                                                # -0.0
+    y[0, :, :3, :] = float('-inf')                                               # whole windows of -inf at a border
+    y = y.cuda().contiguous(memory_format=torch.channels_last)
+    bias = torch.randn(c, generator=g).cuda()
+    for relu in (True, False):
+        got = _C.bias_act_maxpool(y, bias, relu)
+        ref = F.max_pool2d(_C.bias_act_(y.clone(memory_format=torch.channels_last), bias, None, relu), 3, 2, 1)
+        # ... and torch's own operators: relu and max_pool2d hand a NaN on (odtk_bias_act's ReLU turned it into 0 until round 6)
+        t = y.float() + bias.view(1, -1, 1, 1)
+        ref_torch = F.max_pool2d((torch.relu(t) if relu else t).to(dtype), 3, 2, 1)
+        assert torch.equal(torch.isnan(ref), torch.isnan(ref_torch))
+        assert torch.equal(ref[~torch.isnan(ref)].view(torch.int16), ref_torch[~torch.isnan(ref)].view(torch.int16))
+        assert torch.equal(torch.isnan(got), torch.isnan(ref))
+        assert int(torch.isnan(ref).sum()) > 100
+        fin = ~torch.isnan(ref)
+        assert torch.equal(got[fin].view(torch.int16), ref[fin].view(torch.int16))
+        assert bool(torch.isinf(ref).any())
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16], ids=['bf16', 'fp16'])
 @pytest.mark.parametrize('rotated', [False, True], ids=['axis', 'rotated'])
 def test_head_bias_folded_into_the_kernels(dtype, rotated):
     """decode_levels(raw heads, cls_bias, box_bias) == the strict op on torch-materialised inputs:
