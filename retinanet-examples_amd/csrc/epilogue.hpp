@@ -198,7 +198,9 @@ __global__ __launch_bounds__(256) void bias_act_maxpool_kernel(const uint16_t *_
     for (int e = 0; e < kPer; ++e) {
       const int32_t kx = static_cast<int16_t>(kmax[e >> 1] >> (16 * (e & 1)));
       const int32_t kn = static_cast<int16_t>(kmin[e >> 1] >> (16 * (e & 1)));
-      const int32_t kk = kn < -32641 ? kn : kx;            // below -inf's key (0x807f): a negative NaN -- NaN propagates, as torch's max_pool2d
+      // below -inf's key (bf16: 0xff80 -> 0x807f, fp16: 0xfc00 -> 0x83ff): a negative NaN -- NaN propagates, as torch's max_pool2d
+      constexpr int32_t kNegInfKey = std::is_same_v<T, BF16> ? -32641 : -31745;
+      const int32_t kk = kn < kNegInfKey ? kn : kx;
       const uint32_t hx = static_cast<uint32_t>(kk ^ ((kk >> 15) & 0x7fff)) & 0xffffu;
       m[e] = std::is_same_v<T, BF16> ? bf16_bits_to_float(hx) : f16_bits_to_float(hx);
     }
