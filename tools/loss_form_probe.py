@@ -137,7 +137,7 @@ def main():
         ok &= good
         say('NaN / +-inf logits (%s): forms agree %s' % ('nhwc' if cl else 'nchw', 'ok' if good else 'BAD'))
     # ---- 2. time ----
-    _C.profile_enable(True, ('retina_loss_kernel',))
+    _C.profile_enable(True, ('retina_loss_kernel', 'loss_reduce_kernel'))   # (the workspace form's second launch has its own id since round 6)
     logits = sum(B * A * C * h * w for h, w in SIZES)
     for dtype, name, cl in ((torch.float32, 'fp32', True), (torch.bfloat16, 'bf16', True), (torch.float32, 'fp32', False)):
         sets = [make_set(dtype, 10 + i, cl) for i in range(3)]
@@ -196,9 +196,9 @@ def main():
                 for i in range(20):
                     ws(sets[i % 3])
                 torch.cuda.synchronize()
-                ms, n = _C.profile_collect()['retina_loss_kernel']
-                rows.append((ms * 1e3 / 20, threads, per_cu, unroll))
-    _C.loss_tuning(2, True, 256, 4, 1, 256)
+                got = _C.profile_collect()
+                rows.append(((got['retina_loss_kernel'][0] + got['loss_reduce_kernel'][0]) * 1e3 / 20, threads, per_cu, unroll))
+    _C.loss_tuning(2, True, 256, 4, 2, 256)          # (the default since round 6)
     rows.sort()
     for r in rows[:4] + rows[-1:]:
         say('shape fp32 nhwc forward (workspace, 2 launches) form 1: %6.2f us  threads %4d  per_cu %2d  unroll %d' % r)
